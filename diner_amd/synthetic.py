@@ -1,0 +1,134 @@
+"""Synthetic 4-view scenes for parity tests and bench.py.
+
+There is no DTU / Facescape data and no checkpoint in the build or bench environment,
+so the workload is an analytic scene: a sphere (r = 0.25) in front of a finite back plane,
+seen by NV source cameras on a +-20 degree arc of radius 1 and one target camera at the
+arc centre.  Depth maps are rendered analytically (background depth 0), the depth
+standard deviation follows the DTU confidence law of the reference (dtu.py:68-70:
+std = 0.0328 - 0.0257 * conf), the latent feature map is seeded N(0,1) (the ResNet34
+trunk is not part of the hot path) and the MLP keeps the reference initialisation except
+for fc_1, which the reference zero-initialises (resnetfc.py:47) and which would hide
+MLP bugs if left at zero.
+
+Everything here is plain torch on the CPU (deterministic given the seed); callers move
+the tensors to the GPU.
+"""
+import math
+
+import torch
+
+
+def look_at_extrinsics(cam_pos, target=(0.0, 0.0, 0.0), up=(0.0, -1.0, 0.0)):
+    """world->camera (4,4), OpenCV convention (x right, y down, z forward)."""
+    p = torch.tensor(cam_pos, dtype=torch.float64)
+    t = torch.tensor(target, dtype=torch.float64)
+    z = t - p
+    z = z / z.norm()
+    upv = torch.tensor(up, dtype=torch.float64)
+    x = torch.linalg.cross(z, upv)      # y-down camera: x = z x (-y_world_up) handled by `up`
+    x = x / x.norm()
+    y = torch.linalg.cross(z, x)
+    R = torch.stack((x, y, z), dim=0)   # rows = camera axes in world coords
+    E = torch.eye(4, dtype=torch.float64)
+    E[:3, :3] = R
+    E[:3, 3] = -R @ p
+    return E.float()
+
+
+def _analytic_depth(E, Kmat, W, H, radius=0.25, plane_z=0.35, plane_half=0.6):
+    """z-depth (camera frame) of the first hit of the sphere / finite back plane; 0 = background."""
+    E = E.double()
+    Kd = Kmat.double()
+    ys, xs = torch.meshgrid(torch.arange(0.5, H, 1.0, dtype=torch.float64),
+                            torch.arange(0.5, W, 1.0, dtype=torch.float64), indexing="ij")
+    dc = torch.stack(((xs - Kd[0, 2]) / Kd[0, 0], (ys - Kd[1, 2]) / Kd[1, 1], torch.ones_like(xs)), -1)
+    R, t = E[:3, :3], E[:3, 3]
+    o = -R.T @ t
+    dw = dc @ R            # (H,W,3): R^T applied to each row vector
+    # sphere |o + s d|^2 = r^2   (s is the camera-frame z-depth because dc.z == 1)
+    a = (dw * dw).sum(-1)
+    b = 2 * (dw * o).sum(-1)
+    c = (o * o).sum() - radius ** 2
+    disc = b * b - 4 * a * c
+    s_sph = torch.where(disc > 0, (-b - torch.sqrt(disc.clamp(min=0))) / (2 * a), torch.full_like(a, float("inf")))
+    s_sph = torch.where(s_sph > 0, s_sph, torch.full_like(a, float("inf")))
+    # plane z_world = plane_z, finite extent
+    s_pl = (plane_z - o[2]) / dw[..., 2]
+    hit = o + s_pl.unsqueeze(-1) * dw
+    ok = (s_pl > 0) & (hit[..., 0].abs() <= plane_half) & (hit[..., 1].abs() <= plane_half)
+    s_pl = torch.where(ok, s_pl, torch.full_like(a, float("inf")))
+    s = torch.minimum(s_sph, s_pl)
+    return torch.where(torch.isfinite(s), s, torch.zeros_like(s)).float()
+
+
+def make_scene(W=64, H=64, nv=4, seed=0, latent_ch=512, image_padding=64, znear=0.5, zfar=1.5,
+               bg_std_zero=False, latent=True):
+    """Returns a dict of CPU tensors describing one object:
+        src_extrinsics (NV,4,4), src_intrinsics (NV,3,3), depths / depths_std (NV,1,H,W),
+        latent (NV,C,Hf,Wf) [if latent], target_extrinsics (4,4), target_intrinsics (3,3),
+        image_shape (2,) = [W,H], znear, zfar, feature_padding.
+    Normals are NOT included: they are derived from the depth maps by depth2normal at encode time.
+    """
+    g = torch.Generator().manual_seed(seed)
+    Kmat = torch.tensor([[1.2 * W, 0.0, W / 2.0], [0.0, 1.2 * W, H / 2.0], [0.0, 0.0, 1.0]])
+    angs = torch.linspace(-20.0, 20.0, nv) if nv > 1 else torch.zeros(1)
+    extr = []
+    for i, a in enumerate(angs.tolist()):
+        th = math.radians(a)
+        elev = 0.06 * ((-1) ** i)
+        extr.append(look_at_extrinsics((math.sin(th), elev, -math.cos(th))))
+    extr = torch.stack(extr)
+    intr = Kmat.unsqueeze(0).repeat(nv, 1, 1).clone()
+    depths = torch.stack([_analytic_depth(extr[i], intr[i], W, H) for i in range(nv)]).unsqueeze(1)
+    conf = torch.rand(nv, 1, H, W, generator=g) * 0.7 + 0.3
+    std = 0.0328 - 0.0257 * conf                       # dtu.py:68-70
+    if bg_std_zero:
+        std = torch.where(depths == 0, torch.zeros_like(std), std)   # multiface.py:310 variant
+    out = dict(src_extrinsics=extr, src_intrinsics=intr, depths=depths, depths_std=std,
+               target_extrinsics=look_at_extrinsics((0.03, -0.02, -1.0)), target_intrinsics=Kmat.clone(),
+               image_shape=torch.tensor([float(W), float(H)]), znear=znear, zfar=zfar,
+               feature_padding=image_padding / 2.0, W=W, H=H)
+    if latent:
+        Hf, Wf = (H + 2 * image_padding) // 2, (W + 2 * image_padding) // 2
+        out["latent"] = torch.randn(nv, latent_ch, Hf, Wf, generator=g)
+    return out
+
+
+def randomize_mlp_(mlp, seed=1234, fc1_std=0.03, bias_std=0.05):
+    """Keep the reference init (kaiming fan_in weights) but give fc_1 and the biases non-zero values."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for blk in mlp.blocks:
+            blk.fc_1.weight.copy_(torch.randn(blk.fc_1.weight.shape, generator=g) * fc1_std)
+            blk.fc_0.bias.copy_(torch.randn(blk.fc_0.bias.shape, generator=g) * bias_std)
+            blk.fc_1.bias.copy_(torch.randn(blk.fc_1.bias.shape, generator=g) * bias_std)
+        for lz in mlp.lin_z:
+            lz.bias.copy_(torch.randn(lz.bias.shape, generator=g) * bias_std)
+        mlp.lin_in.bias.copy_(torch.randn(mlp.lin_in.bias.shape, generator=g) * bias_std)
+        mlp.lin_out.bias.copy_(torch.randn(mlp.lin_out.bias.shape, generator=g) * bias_std)
+    return mlp
+
+
+def make_mlp_state_dict(seed=1234, d_in=55, d_latent=512, d_hidden=512, d_out=4, n_blocks=5,
+                        combine_layer=3, fc1_std=0.03, bias_std=0.05):
+    """ResnetFC state_dict (reference key names, resnetfc.py:72-127) drawn from an explicit CPU
+    generator: kaiming-normal(fan_in) weights like the reference init, but non-zero fc_1 and biases."""
+    g = torch.Generator().manual_seed(seed)
+
+    def kaiming(o, i):
+        return torch.randn(o, i, generator=g) * math.sqrt(2.0 / i)
+
+    def bias(o):
+        return torch.randn(o, generator=g) * bias_std
+
+    sd = {"lin_in.weight": kaiming(d_hidden, d_in), "lin_in.bias": bias(d_hidden),
+          "lin_out.weight": kaiming(d_out, d_hidden), "lin_out.bias": bias(d_out)}
+    for b in range(n_blocks):
+        sd[f"blocks.{b}.fc_0.weight"] = kaiming(d_hidden, d_hidden)
+        sd[f"blocks.{b}.fc_0.bias"] = bias(d_hidden)
+        sd[f"blocks.{b}.fc_1.weight"] = torch.randn(d_hidden, d_hidden, generator=g) * fc1_std
+        sd[f"blocks.{b}.fc_1.bias"] = bias(d_hidden)
+    for b in range(min(combine_layer, n_blocks)):
+        sd[f"lin_z.{b}.weight"] = kaiming(d_hidden, d_latent)
+        sd[f"lin_z.{b}.bias"] = bias(d_hidden)
+    return sd

@@ -1,0 +1,260 @@
+"""Generate the golden vectors under tests/golden/ from the IMPORTED reference (build container only).
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz and prints the pin report
+
+For every stage the reference function is run with injected noise (torch.rand_like / randn_like are
+patched for the duration of the call), the oracle restatement is run on the same
+inputs, the two are compared, and the reference's outputs are stored as the fixture.  Inputs are NOT
+stored when they can be regenerated from a seed (diner_amd.synthetic); their sha256 is stored instead.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import diner_oracle as O          # noqa: E402
+from oracle.ref_import import import_reference, build_reference_nerf   # noqa: E402
+from diner_amd.synthetic import make_scene, make_mlp_state_dict        # noqa: E402
+from src.util.depth2normal import depth2normal                          # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(*tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+class inject_noise:
+    """Patch torch.rand_like / randn_like while the reference renderer runs."""
+
+    def __init__(self, noise_coarse, noise_gauss, noise_fill):
+        self.nc, self.ng, self.nf = noise_coarse, noise_gauss, noise_fill
+
+    def __enter__(self):
+        self._rand, self._randn = torch.rand_like, torch.randn_like
+        nc, ng, nf = self.nc, self.ng, self.nf
+
+        def rand_like(t, *a, **k):
+            fl = sys._getframe(1).f_locals
+            if t.dim() == 2 and nc is not None and tuple(t.shape) == tuple(nc.shape):
+                return nc.clone()
+            if t.dim() == 1 and "missing_iray" in fl:
+                return nf[fl["missing_iray"], fl["missing_isample"]].clone()
+            raise RuntimeError(f"unexpected rand_like request {tuple(t.shape)}")
+
+        def randn_like(t, *a, **k):
+            fl = sys._getframe(1).f_locals
+            if "ray_mask" in fl:
+                return ng[fl["ray_mask"][0]].clone()
+            raise RuntimeError("unexpected randn_like request")
+
+        torch.rand_like, torch.randn_like = rand_like, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, torch.randn_like = self._rand, self._randn
+
+
+def setup(ns, W, H, seed, bg_std_zero=False):
+    sc = make_scene(W, H, seed=seed, bg_std_zero=bg_std_zero)
+    normals = depth2normal(sc["depths"], sc["src_intrinsics"])
+    ref_n = ns.depth2normal.depth2normal(sc["depths"], sc["src_intrinsics"])
+    assert torch.equal(normals, ref_n), "product depth2normal != reference"
+    nerf = build_reference_nerf(ns)
+    msd = make_mlp_state_dict()
+    nerf.mlp_fine.load_state_dict(msd, strict=True)
+    enc = nerf.encoder
+    enc.depths, enc.depths_std, enc.normals = sc["depths"][None], sc["depths_std"][None], normals[None]
+    enc.latent = sc["latent"][None]
+    enc.nviews, enc.nobjects = sc["src_extrinsics"].shape[0], 1
+    nerf.poses = sc["src_extrinsics"][None]
+    nerf.c = sc["src_intrinsics"][None, :, :2, -1]
+    nerf.focal = sc["src_intrinsics"][None][:, :, [0, 1], [0, 1]]
+    nerf.image_shape = sc["image_shape"].clone()
+    scene = O.Scene(latent=sc["latent"], depths=sc["depths"], depths_std=sc["depths_std"], normals=normals,
+                    poses=sc["src_extrinsics"], focal=nerf.focal[0], c=nerf.c[0], image_shape=sc["image_shape"],
+                    feature_padding=float(enc.feature_padding))
+    w = O.MLPWeights.from_state_dict(msd)
+    rays_ref = ns.cam_geometry.gen_rays(sc["target_extrinsics"][None], sc["target_intrinsics"][None], W, H,
+                                        torch.tensor([sc["znear"]]), torch.tensor([sc["zfar"]])).view(1, H * W, 8)
+    rays = O.gen_rays(sc["target_extrinsics"], sc["target_intrinsics"], W, H, sc["znear"], sc["zfar"])
+    assert torch.equal(rays_ref[0], rays), "oracle gen_rays != reference"
+    return sc, nerf, scene, w, rays
+
+
+def report(name, ref, ora, exact=False):
+    ref, ora = ref.float(), ora.float()
+    eq = torch.equal(ref, ora)
+    err = (ref - ora).abs().max().item() if ref.numel() else 0.0
+    rel = err / max(ref.abs().max().item(), 1e-30) if ref.numel() else 0.0
+    print(f"  {name:28s} bit-exact={eq}  max-abs={err:.3e}  max-norm-rel={rel:.3e}")
+    if exact:
+        assert eq, name
+    else:
+        assert rel < 2e-6, (name, rel)
+    return rel
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    os.makedirs(OUT, exist_ok=True)
+    ns = import_reference()
+    R = ns.nerf_renderer.NeRFRendererDGS
+    with torch.no_grad():
+        # ------------------------------------------------------------------ G1 poscode
+        print("G1 positional encoding")
+        g = torch.Generator().manual_seed(101)
+        x3 = torch.rand(257, 3, generator=g) * 4 - 2
+        x1 = torch.rand(257, 1, generator=g) * 4 - 2
+        pe3 = ns.positional_encoding.PositionalEncoding(num_freqs=6, d_in=3, freq_factor=6.28, include_input=True)
+        pe1 = ns.positional_encoding.PositionalEncoding(num_freqs=6, d_in=1, freq_factor=6.28, include_input=True)
+        r3, r1 = pe3(x3), pe1(x1)
+        report("posenc d_in=3", r3, O.posenc(x3), exact=True)
+        report("posenc d_in=1", r1, O.posenc(x1), exact=True)
+        np.savez_compressed(os.path.join(OUT, "g1_posenc.npz"), x3=x3.numpy(), x1=x1.numpy(),
+                            y3=r3.numpy(), y1=r1.numpy())
+
+        # ------------------------------------------------------------------ G2 gathers
+        print("G2 gathers")
+        W, H = 48, 40
+        sc, nerf, scene, w, rays = setup(ns, W, H, seed=7, bg_std_zero=True)
+        g = torch.Generator().manual_seed(102)
+        N = 600
+        uv = torch.rand(4, N, 2, generator=g) * 2.6 - 1.3             # inside, <100px outside
+        uv[:, :40] = torch.rand(4, 40, 2, generator=g) * 16 - 8       # far outside (beyond the 100px ring)
+        # exactly-half-pixel coordinates: p = ((u+1)*S-1)/2 = k+0.5  ->  u = (2k+2)/S - 1
+        ks = torch.arange(0, 20).float()
+        uv[:, 40:60, 0] = (2 * ks + 2) / W - 1
+        uv[:, 40:60, 1] = (2 * ks + 2) / H - 1
+        uv[:, 60:64] = torch.tensor([[-1., -1.], [1., 1.], [-1., 1.], [0., 0.]])
+        enc = nerf.encoder
+        outs = dict(latent=enc.index(uv[None])[0], depth=enc.index_depth(uv[None])[0],
+                    std=enc.index_depth_std(uv[None])[0], normal=enc.index_normal(uv[None])[0])
+        report("index (bilinear/border)", outs["latent"], O.index_latent(scene, uv), exact=True)
+        report("index_depth", outs["depth"], O.index_depth(scene, uv), exact=True)
+        report("index_depth_std", outs["std"], O.index_depth_std(scene, uv), exact=True)
+        report("index_normal", outs["normal"], O.index_normal(scene, uv), exact=True)
+        np.savez_compressed(os.path.join(OUT, "g2_gathers.npz"), W=W, H=H, seed=7, uv=uv.numpy(),
+                            in_sha=sha(sc["latent"], sc["depths"], sc["depths_std"], scene.normals),
+                            latent_sub=outs["latent"][:, ::16].numpy(),   # every 16th channel keeps it small
+                            depth=outs["depth"].numpy(), std=outs["std"].numpy(), normal=outs["normal"].numpy())
+
+        # ------------------------------------------------------------------ G3/G4 sampler + fill
+        print("G3/G4 depth-guided sampler and fill  (K=64,G=24 and K=128,G=48)")
+        W, H = 64, 64
+        sc, nerf, scene, w, rays = setup(ns, W, H, seed=0)
+        g = torch.Generator().manual_seed(103)
+        sel = torch.randperm(W * H, generator=g)[:512].sort().values
+        rs = rays[sel].contiguous()
+        n_cand = 1000
+        for (K, G) in [(64, 24), (128, 48)]:
+            ncz = torch.rand(512, n_cand, generator=g)
+            ngz = torch.randn(512, G, generator=g)
+            nfz = torch.rand(512, K, generator=g)
+            ren = R(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=False)
+            with inject_noise(ncz, ngz, nfz):
+                z0_ref = ren.sample_depthguided(rs[None], nerf, n_samples=K, n_candidates=n_cand, n_gaussian=G)
+                z_ref = ren.fill_up_uniform_samples(z0_ref.clone(), rs[None])
+            z0, aux = O.sample_depthguided(scene, rs, K, n_cand, G, ncz, ngz, return_aux=True)
+            z = O.fill_up_uniform_samples(z0, rs, nfz)
+            report(f"z unfilled K={K}", z0_ref[0], z0, exact=True)
+            report(f"z filled   K={K}", z_ref[0], z, exact=True)
+            # tie check at the (K-G) cut-off: fixtures must have none
+            Ls = aux["L"].sort(dim=-1, descending=True).values
+            ties = ((Ls[:, K - G - 1] == Ls[:, K - G]) & (Ls[:, K - G] > 0)).sum().item()
+            print(f"    rays with surface: {(aux['O'] != 0).any(-1).sum().item()}/512, "
+                  f"rays with a tie at the cut-off: {ties}, zeros before fill: {(z0 == 0).sum().item()}")
+            assert ties == 0
+            np.savez_compressed(os.path.join(OUT, f"g3_sampler_K{K}.npz"), W=W, H=H, seed=0, ray_idx=sel.numpy(),
+                                K=K, G=G, n_cand=n_cand, noise_seed=103, in_sha=sha(rs, ncz, ngz, nfz),
+                                L_sum=aux["L"].sum(-1).numpy(), O_sum=aux["O"].sum(-1).numpy(),
+                                z_unfilled=z0_ref[0].numpy(), z=z_ref[0].numpy())
+        # a hand-made fill case: negative gaussian sample, all-empty ray, full ray
+        zt = torch.zeros(4, 16)
+        zt[0, :5] = torch.tensor([0.9, -0.2, 0.7, 1.1, 0.6])
+        zt[2] = torch.linspace(0.55, 1.45, 16)
+        zt[3, 3] = 1.0
+        rt = rs[:4].clone()
+        nft = torch.rand(4, 16, generator=g)
+        with inject_noise(None, None, nft):
+            zt_ref = R().fill_up_uniform_samples(zt.clone()[None], rt[None])[0]
+        report("fill hand-made", zt_ref, O.fill_up_uniform_samples(zt, rt, nft), exact=True)
+        np.savez_compressed(os.path.join(OUT, "g4_fill.npz"), z_in=zt.numpy(), rays=rt.numpy(), noise=nft.numpy(),
+                            z_out=zt_ref.numpy())
+
+        # ------------------------------------------------------------------ G5 MLP
+        print("G5 ResnetFC")
+        g = torch.Generator().manual_seed(105)
+        zx = torch.randn(4, 300, 567, generator=g)
+        y_ref = nerf.mlp_fine(zx[None], combine_dim=1)[0]
+        report("mlp (4,300,567)->(300,4)", y_ref, O.mlp_forward(w, zx))
+        np.savez_compressed(os.path.join(OUT, "g5_mlp.npz"), zx_seed=105, in_sha=sha(zx), y=y_ref.numpy())
+
+        # ------------------------------------------------------------------ G6 PixelNeRF.forward
+        print("G6 PixelNeRF.forward")
+        g = torch.Generator().manual_seed(106)
+        sel6 = torch.randperm(W * H, generator=g)[:64]
+        zs = torch.rand(64, 8, generator=g) * 0.9 + 0.55
+        pts = (rays[sel6, None, :3] + zs.unsqueeze(-1) * rays[sel6, None, 3:6]).reshape(-1, 3)
+        dirs = rays[sel6, None, 3:6].expand(-1, 8, -1).reshape(-1, 3)
+        f_ref = nerf(pts[None], viewdirs=dirs[None])[0]
+        report("pixelnerf (512 pts)", f_ref, O.pixelnerf_forward(scene, w, pts, dirs))
+        zx6 = O.mlp_input(scene, pts, dirs)
+        np.savez_compressed(os.path.join(OUT, "g6_pixelnerf.npz"), W=W, H=H, seed=0, pts=pts.numpy(), dirs=dirs.numpy(),
+                            feat55=zx6[..., 512:].numpy(), latent_sub=zx6[..., :512:16].numpy(), out=f_ref.numpy())
+
+        # ------------------------------------------------------------------ G7 composite
+        print("G7 composite (incl. z_K > far, white_bkgd on/off)")
+        g = torch.Generator().manual_seed(107)
+        sel7 = torch.randperm(W * H, generator=g)[:96].sort().values
+        r7 = rays[sel7].contiguous()
+        z7 = (torch.rand(96, 32, generator=g) * 0.95 + 0.52).sort(-1).values
+        z7[:8, -1] = 1.6                                            # beyond far=1.5 -> negative last delta
+        gold = dict(rays=r7.numpy(), z=z7.numpy())
+        for wb in (False, True):
+            ren = R(n_samples=32, white_bkgd=wb)
+            w_ref, rgb_ref, d_ref = ren.composite(nerf, r7[None], z7[None])
+            wo, rgbo, do, field = O.composite(scene, w, r7, z7, wb)
+            report(f"composite rgb  white={wb}", rgb_ref[0], rgbo)
+            report(f"composite depth white={wb}", d_ref[0], do)
+            report(f"composite wts  white={wb}", w_ref[0], wo)
+            gold.update({f"weights_{int(wb)}": w_ref[0].numpy(), f"rgb_{int(wb)}": rgb_ref[0].numpy(),
+                         f"depth_{int(wb)}": d_ref[0].numpy()})
+        gold["field"] = field.numpy()
+        np.savez_compressed(os.path.join(OUT, "g7_composite.npz"), W=W, H=H, seed=0, **gold)
+
+        # ------------------------------------------------------------------ G8 end-to-end cfg 1
+        print("G8 renderer.forward, cfg 1: 64x64 rays, K=64, G=24, 1000 candidates (takes ~1-2 min)")
+        K, G = 64, 24
+        g = torch.Generator().manual_seed(108)
+        NRr = W * H
+        ncz = torch.rand(NRr, n_cand, generator=g)
+        ngz = torch.randn(NRr, G, generator=g)
+        nfz = torch.rand(NRr, K, generator=g)
+        ren = R(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=False)
+        with inject_noise(ncz, ngz, nfz):
+            out = ren.forward(nerf, rays[None], want_weights=True)
+        sub = slice(0, NRr, 8)      # the oracle re-runs every 8th ray (rays are independent)
+        o = O.render(scene, w, rays[sub].contiguous(), K, n_cand, G, False, ncz[sub], ngz[sub], nfz[sub])
+        report("e2e rgb", out.fine.rgb[0][sub], o["rgb"])
+        report("e2e depth", out.fine.depth[0][sub], o["depth"])
+        report("e2e weights", out.fine.weights[0][sub], o["weights"])
+        np.savez_compressed(os.path.join(OUT, "g8_render_cfg1.npz"), W=W, H=H, seed=0, K=K, G=G, n_cand=n_cand,
+                            noise_seed=108, in_sha=sha(rays, ncz[:64], ngz[:64], nfz[:64]),
+                            rgb=out.fine.rgb[0].numpy(), depth=out.fine.depth[0].numpy(),
+                            weights_sum=out.fine.weights[0].sum(-1).numpy(),
+                            weights_sub=out.fine.weights[0][::16].numpy())
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
