@@ -1,0 +1,79 @@
+"""ctypes binding of libdiner_hip.so (the C ABI declared in include/diner_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiner_hip.so")
+
+
+class DinerScene(C.Structure):
+    _fields_ = [("latent_cl", C.c_void_p), ("depth", C.c_void_p), ("depth_std", C.c_void_p),
+                ("normals", C.c_void_p), ("poses", C.c_void_p), ("focal", C.c_void_p), ("c", C.c_void_p),
+                ("std_pad_scale", C.c_void_p),
+                ("img_w", C.c_float), ("img_h", C.c_float), ("feature_padding", C.c_float),
+                ("nv", C.c_int32), ("C", C.c_int32), ("Hf", C.c_int32), ("Wf", C.c_int32),
+                ("Hs", C.c_int32), ("Ws", C.c_int32)]
+
+
+class DinerMlpParams(C.Structure):
+    _fields_ = [("d_in", C.c_int32), ("d_latent", C.c_int32), ("d_hidden", C.c_int32), ("d_out", C.c_int32),
+                ("n_blocks", C.c_int32), ("combine_layer", C.c_int32),
+                ("lin_in_w", C.c_void_p), ("lin_in_b", C.c_void_p),
+                ("lin_out_w", C.c_void_p), ("lin_out_b", C.c_void_p),
+                ("fc0_w", C.POINTER(C.c_void_p)), ("fc0_b", C.POINTER(C.c_void_p)),
+                ("fc1_w", C.POINTER(C.c_void_p)), ("fc1_b", C.POINTER(C.c_void_p)),
+                ("lin_z_w", C.POINTER(C.c_void_p)), ("lin_z_b", C.POINTER(C.c_void_p))]
+
+
+# name -> (restype, argtypes); must list every symbol include/diner_hip.h declares
+SIGNATURES = {
+    "diner_abi_version": (C.c_int, []),
+    "diner_last_error": (C.c_char_p, []),
+    "diner_mlp_create": (C.c_int, [C.POINTER(DinerMlpParams), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "diner_mlp_destroy": (C.c_int, [C.c_void_p]),
+    "diner_sample_depthguided_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_fill_uniform_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
+                                         C.c_void_p, C.c_void_p]),
+    "diner_field_workspace_bytes": (C.c_size_t, [C.c_longlong]),
+    "diner_field_from_rays_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_from_points_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_mlp_forward_workspace_bytes": (C.c_size_t, [C.c_longlong]),
+    "diner_mlp_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_composite_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_render_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_posenc_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                   C.c_void_p]),
+    "diner_index_f32": (C.c_int, [C.POINTER(DinerScene), C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError -- never falls back -- when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: the HIP extension is not built. "
+                          f"Run `python -m diner_amd.build` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.diner_abi_version() != 1:
+        raise ImportError(f"libdiner_hip.so ABI version {lib.diner_abi_version()} != 1; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().diner_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libdiner_hip: {msg} (code {rc})")

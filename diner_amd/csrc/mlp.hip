@@ -1,0 +1,656 @@
+// Fused per-sample radiance-field evaluation: projection + positional encoding + bilinear feature gather +
+// ResnetFC, with every activation resident in MFMA accumulator registers.
+//
+// Replaces PixelNeRF.forward (reference pixelnerf.py:55-145), PositionalEncoding.forward
+// (positional_encoding.py:33-53), SpatialEncoder.index / index_depth (image_encoder.py:97-170) and
+// ResnetFC.forward (resnetfc.py:61-69, :129-159).
+//
+// Design (gfx950):
+//  * GEMMs run TRANSPOSED on v_mfma_f32_16x16x4_f32 (exact fp32, 157 TFLOP/s peak): D[feature][point] =
+//    sum_k W[feature][k] * act[k][point].  A = weights, B = activations, D = activations of the next
+//    layer.  The D register layout of that instruction (lane (q,pt) holds features 4q..4q+3 of a 16-row
+//    tile for point pt) is exactly the B layout of the next layer's k-steps once the contraction index is
+//    permuted, and the permutation is absorbed by the order in which the weights are packed.  So a
+//    wave's 16 (point,view) columns x 512 features = 128 registers never leave the register file between
+//    lin_in and the view-mean: no LDS round trip, no HBM round trip for activations.
+//  * one wave = one source view x 16 consecutive points; a 256-thread workgroup = the 4 views of those
+//    points.  Two 128-register accumulator sets (residual stream x, hidden net) + fragments fit the
+//    512-entry unified VGPR/AGPR file at one wave per SIMD.
+//  * weights (13.8 MB fp32, L2 / Infinity-Cache resident) are streamed by all four waves through a
+//    double-buffered 2 x 32 KB LDS ring with global_load_lds (one barrier per 32 KB stage), packed on
+//    the host side of the C ABI into the exact ds_read_b128 fragment order (conflict-free, lane-linear).
+//  * the 512-channel latent is gathered straight into B-operand registers from the channels-last map:
+//    each lane reads 16 B (4 channels) per tap, the 4 lanes of a point cover one 64 B segment.
+//  * the view-mean boundary (resnetfc.py:148-151) splits the network into two persistent kernels;
+//    the hand-over is 8 KB/point of pre-mean activations stored in accumulator layout (coalesced 1 KB
+//    wave stores), 6 % of the gather traffic.
+#include "common.hpp"
+
+namespace diner {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHidden = 512;
+constexpr int kLatent = 512;
+constexpr int kDIn = 55;
+constexpr int kDInPad = 64;
+constexpr int kTiles = kHidden / 16;          // 32 accumulator tiles of 16 features
+constexpr int kStageFloats = 8192;            // 32 KB: 128 output features x 64 k
+constexpr int kStagesPerLayer = 32;           // 8 k-chunks x 4 feature groups
+constexpr int kPreStages = 4 + 3 * 3 * kStagesPerLayer;    // lin_in + 3 x (lin_z, fc_0, fc_1) = 292
+constexpr int kPostStages = 2 * 2 * kStagesPerLayer + 1;   // 2 x (fc_0, fc_1) + lin_out      = 129
+constexpr int kPtsPerWave = 16;
+
+struct DinerMlpImpl {
+  float* w_pre;    // kPreStages  x 8192 floats, stage-tile order
+  float* w_post;   // kPostStages x 8192 floats
+  float* b_pre;    // biases: lin_in, then per block b<3: lin_z, fc_0, fc_1  -> 10 x 512
+  float* b_post;   // per block b=3,4: fc_0, fc_1 -> 4 x 512, then lin_out (4, padded to 16)
+};
+
+// ------------------------------------------------------------------------------------------------------
+// weight packing (runs once per parameter version, on the device)
+//   stage tile layout [mo 8][ml 4][lane 64][4]:  W[128 mg + 16 mo + (lane&15)][64 kc + 16 ml + 4 (lane>>4) + j]
+//   stages of a layer are ordered s = 4 kc + mg
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_pack_layer(const float* __restrict__ W, int rows, int cols, int n_kc, float* __restrict__ dst) {
+  // W is (rows, cols) row-major nn.Linear weight; rows padded to 512 and cols to 64*n_kc with zeros
+  const int total = n_kc * 4 * kStageFloats;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 3, lane = (i >> 2) & 63, ml = (i >> 8) & 3, mo = (i >> 10) & 7, s = i >> 13;
+    const int kc = s >> 2, mg = s & 3;
+    const int row = 128 * mg + 16 * mo + (lane & 15);
+    const int col = 64 * kc + 16 * ml + 4 * (lane >> 4) + j;
+    dst[i] = (row < rows && col < cols) ? W[(size_t)row * cols + col] : 0.0f;
+  }
+}
+// lin_out: one stage, layout [m 32][lane 64][4]: Wout[lane&15][16 m + 4 (lane>>4) + j], rows >= d_out are zero
+__global__ void k_pack_lin_out(const float* __restrict__ W, int rows, int cols, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kStageFloats; i += gridDim.x * blockDim.x) {
+    const int j = i & 3, lane = (i >> 2) & 63, m = i >> 8;
+    const int row = lane & 15, col = 16 * m + 4 * (lane >> 4) + j;
+    dst[i] = (row < rows && col < cols) ? W[(size_t)row * cols + col] : 0.0f;
+  }
+}
+__global__ void k_copy_pad(const float* __restrict__ src, int n, int n_pad, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x)
+    dst[i] = i < n ? src[i] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// device building blocks
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) float lds_float;
+
+// Issue the LDS-DMA of one 32 KB stage: 32 pieces of 1 KB, wave w moves pieces w, w+4, ...
+__device__ __forceinline__ void stage_prefetch(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int piece = wave + 4 * j;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
+  }
+}
+
+// The weight stream of a persistent workgroup: a fixed cyclic sequence of stages.
+struct WeightStream {
+  const float* base;   // packed stages in global memory
+  float* lds;          // 2 x kStageFloats
+  int n_stages;
+  int cur;             // index (in the cyclic sequence) of the stage about to be consumed
+  int parity;
+  int wave, lane;
+  __device__ __forceinline__ void start() {
+    cur = 0;
+    parity = 0;
+    stage_prefetch(base, lds, wave, lane);
+  }
+  // make stage `cur` readable in lds[parity], then start the DMA of the following stage into the other
+  // buffer (free: every wave finished reading it before it reached this barrier)
+  __device__ __forceinline__ const float* acquire() {
+    __builtin_amdgcn_s_waitcnt(0x0f70 | 0);  // vmcnt(0): my pieces of stage `cur` have landed (expcnt/lgkmcnt untouched)
+    __syncthreads();
+    int nxt = cur + 1;
+    if (nxt == n_stages) nxt = 0;
+    stage_prefetch(base + (size_t)nxt * kStageFloats, lds + (parity ^ 1) * kStageFloats, wave, lane);
+    const float* ready = lds + parity * kStageFloats;
+    cur = nxt;
+    parity ^= 1;
+    return ready;
+  }
+};
+
+// one 32 KB stage = 128 output features (accumulators acc[8 mg .. 8 mg+7]) x 64 k (B operands bop[0..15])
+template <int MG>
+__device__ __forceinline__ void stage_mma(const float* __restrict__ st, int lane, const float (&bop)[16],
+                                          f32x4 (&acc)[kTiles]) {
+  const f32x4* st4 = reinterpret_cast<const f32x4*>(st) + lane;
+#pragma unroll
+  for (int ml = 0; ml < 4; ++ml) {
+    f32x4 a[8];
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo) a[mo] = st4[(mo * 4 + ml) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mo = 0; mo < 8; ++mo)
+        acc[8 * MG + mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo][r], bop[4 * ml + r], acc[8 * MG + mo], 0, 0, 0);
+    }
+  }
+}
+
+template <int KC>
+__device__ __forceinline__ void bops_relu(const f32x4 (&src)[kTiles], float (&bop)[16]) {
+#pragma unroll
+  for (int ml = 0; ml < 4; ++ml)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bop[4 * ml + r] = fmaxf(src[4 * KC + ml][r], 0.0f);
+}
+
+__device__ __forceinline__ void add_bias(f32x4 (&acc)[kTiles], const float* __restrict__ bias, int q) {
+#pragma unroll
+  for (int mo = 0; mo < kTiles; ++mo) acc[mo] += *reinterpret_cast<const f32x4*>(bias + 16 * mo + 4 * q);
+}
+__device__ __forceinline__ void set_bias(f32x4 (&acc)[kTiles], const float* __restrict__ bias, int q) {
+#pragma unroll
+  for (int mo = 0; mo < kTiles; ++mo) acc[mo] = *reinterpret_cast<const f32x4*>(bias + 16 * mo + 4 * q);
+}
+
+// dst (+)= W . relu(src)  : a full 512x512 layer, 32 stages
+__device__ __forceinline__ void layer_from_acc(WeightStream& ws, const f32x4 (&src)[kTiles], f32x4 (&dst)[kTiles]) {
+#define DINER_KC(KC_)                                       \
+  {                                                         \
+    float bop[16];                                          \
+    bops_relu<KC_>(src, bop);                               \
+    stage_mma<0>(ws.acquire(), ws.lane, bop, dst);          \
+    stage_mma<1>(ws.acquire(), ws.lane, bop, dst);          \
+    stage_mma<2>(ws.acquire(), ws.lane, bop, dst);          \
+    stage_mma<3>(ws.acquire(), ws.lane, bop, dst);          \
+  }
+  DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
+#undef DINER_KC
+}
+
+// bilinear taps of one (point, view) on the channels-last latent map
+struct Taps {
+  const float* p[4];
+  float w[4];
+};
+
+__device__ __forceinline__ void taps_load(const Taps& t, int kc, int q, f32x4 (&raw)[16]) {
+#pragma unroll
+  for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+    for (int ml = 0; ml < 4; ++ml)
+      raw[tap * 4 + ml] = *reinterpret_cast<const f32x4*>(t.p[tap] + 64 * kc + 16 * ml + 4 * q);
+}
+__device__ __forceinline__ void taps_blend(const Taps& t, const f32x4 (&raw)[16], float (&bop)[16]) {
+#pragma unroll
+  for (int ml = 0; ml < 4; ++ml) {
+    const f32x4 v = raw[0 + ml] * t.w[0] + raw[4 + ml] * t.w[1] + raw[8 + ml] * t.w[2] + raw[12 + ml] * t.w[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bop[4 * ml + r] = v[r];
+  }
+}
+
+// x += Wz . latent   (latent gathered on the fly, next k-chunk's taps in flight under the current MFMAs)
+__device__ __forceinline__ void layer_from_latent(WeightStream& ws, const Taps& t, int q, f32x4 (&dst)[kTiles]) {
+  f32x4 raw[16];
+  taps_load(t, 0, q, raw);
+#define DINER_KC(KC_)                                       \
+  {                                                         \
+    float bop[16];                                          \
+    taps_blend(t, raw, bop);                                \
+    if (KC_ < 7) taps_load(t, KC_ + 1, q, raw);             \
+    stage_mma<0>(ws.acquire(), ws.lane, bop, dst);          \
+    stage_mma<1>(ws.acquire(), ws.lane, bop, dst);          \
+    stage_mma<2>(ws.acquire(), ws.lane, bop, dst);          \
+    stage_mma<3>(ws.acquire(), ws.lane, bop, dst);          \
+  }
+  DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
+#undef DINER_KC
+}
+
+// MLP input feature f of [x_c(3), 36 sin/cos of x_c, R d (3), dd, 12 sin/cos of dd]  (pixelnerf.py:96-128)
+__device__ __forceinline__ float input_feature(int f, const float* xc, const float* vd, float dd) {
+  float arg;
+  int j;
+  if (f < 3) return f == 0 ? xc[0] : (f == 1 ? xc[1] : xc[2]);
+  if (f < 39) {
+    j = (f - 3) / 3;
+    const int d = (f - 3) - 3 * j;
+    arg = d == 0 ? xc[0] : (d == 1 ? xc[1] : xc[2]);
+  } else if (f < 42) {
+    return f == 39 ? vd[0] : (f == 40 ? vd[1] : vd[2]);
+  } else if (f == 42) {
+    return dd;
+  } else if (f < kDIn) {
+    j = f - 43;
+    arg = dd;
+  } else {
+    return 0.0f;
+  }
+  const float freq = __fmul_rn(6.28f, (float)(1 << (j >> 1)));                  // positional_encoding.py:18
+  const float phase = (j & 1) ? 1.57079637050628662109375f : 0.0f;               // fp32(pi/2), :30
+  return sinf(__fmaf_rn(arg, freq, phase));                                       // addcmul is fused, :46
+}
+
+struct FieldArgs {
+  // point source: (rays, z) with K samples per ray, or explicit xyz / viewdirs, or a pre-split zx matrix
+  const float* rays;
+  const float* z;
+  const float* xyz;
+  const float* viewdirs;
+  const float* direct_latent;   // (NV*P, 512)  rows used as-is (ResnetFC.forward on an explicit matrix)
+  const float* direct_feat;     // (NV*P, 64)
+  long long P;
+  int K;
+  float freq_factor;
+  const float* w_pre;
+  const float* b_pre;
+  float* xpre;                  // (P/16 tiles, NV, 32, 64) f32x4
+};
+
+__global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, pt = lane & 15;
+  const int v = wave;                                   // one wave per source view
+  const long long n_tiles = (a.P + kPtsPerWave - 1) / kPtsPerWave;
+
+  WeightStream ws;
+  ws.base = a.w_pre;
+  ws.lds = smem;
+  ws.n_stages = kPreStages;
+  ws.wave = wave;
+  ws.lane = lane;
+  ws.start();
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    long long p = tile * kPtsPerWave + pt;
+    if (p >= a.P) p = a.P - 1;                          // tail lanes shadow the last point; stores are whole tiles
+                                                        // into a workspace padded to a multiple of 16 points
+    Taps taps;
+    float feat[16];
+    if (a.direct_latent) {
+      const float* row = a.direct_latent + ((size_t)v * a.P + p) * kLatent;
+      taps.p[0] = taps.p[1] = taps.p[2] = taps.p[3] = row;
+      taps.w[0] = 1.0f;
+      taps.w[1] = taps.w[2] = taps.w[3] = 0.0f;
+      const float* fr = a.direct_feat + ((size_t)v * a.P + p) * kDInPad;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(fr + 16 * m + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) feat[4 * m + r] = t4[r];
+      }
+    } else {
+      float px, py, pz, dx, dy, dz;
+      if (a.xyz) {
+        px = a.xyz[p * 3 + 0]; py = a.xyz[p * 3 + 1]; pz = a.xyz[p * 3 + 2];
+        dx = a.viewdirs[p * 3 + 0]; dy = a.viewdirs[p * 3 + 1]; dz = a.viewdirs[p * 3 + 2];
+      } else {
+        const long long ray = p / a.K;
+        const float* r = a.rays + ray * 8;
+        const float zz = a.z[p];
+        dx = r[3]; dy = r[4]; dz = r[5];
+        px = __fadd_rn(r[0], __fmul_rn(zz, dx));                                 // nerf_renderer.py:304
+        py = __fadd_rn(r[1], __fmul_rn(zz, dy));
+        pz = __fadd_rn(r[2], __fmul_rn(zz, dz));
+      }
+      float xc[3], vd[3];
+      world_to_cam(sc.R[v], sc.t[v], px, py, pz, xc[0], xc[1], xc[2]);           // pixelnerf.py:91-93
+      vd[0] = rot_row(sc.R[v] + 0, dx, dy, dz);                                  // :100
+      vd[1] = rot_row(sc.R[v] + 3, dx, dy, dz);
+      vd[2] = rot_row(sc.R[v] + 6, dx, dy, dz);
+      const float u = project_axis(xc[0], xc[2], sc.focal[v][0], sc.c[v][0], sc.img_w);   // :105-108
+      const float w = project_axis(xc[1], xc[2], sc.focal[v][1], sc.c[v][1], sc.img_h);
+      // nearest depth tap -> distance-to-depth code (:114-116)
+      const int ix = nearest_border(u, sc.Ws), iy = nearest_border(w, sc.Hs);
+      const float dd = __fsub_rn(sc.depth[(size_t)v * sc.Hs * sc.Ws + (size_t)iy * sc.Ws + ix], xc[2]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) feat[4 * m + r] = input_feature(16 * m + 4 * q + r, xc, vd, dd);
+      // bilinear / border taps on the padded feature map (image_encoder.py:112-123)
+      const int Wf = sc.Wf, Hf = sc.Hf;
+      const float su = __fmul_rn(u, __fdiv_rn(__fsub_rn((float)Wf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Wf));
+      const float sv = __fmul_rn(w, __fdiv_rn(__fsub_rn((float)Hf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Hf));
+      const float fx = clip_border(unnormalize(su, Wf), Wf), fy = clip_border(unnormalize(sv, Hf), Hf);
+      const float x0f = floorf(fx), y0f = floorf(fy);
+      const float wx = fx - x0f, wy = fy - y0f;
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      const int x1 = min(x0 + 1, Wf - 1), y1 = min(y0 + 1, Hf - 1);
+      const float* base = sc.latent_cl + (size_t)v * Hf * Wf * kLatent;
+      taps.p[0] = base + ((size_t)y0 * Wf + x0) * kLatent;
+      taps.p[1] = base + ((size_t)y0 * Wf + x1) * kLatent;
+      taps.p[2] = base + ((size_t)y1 * Wf + x0) * kLatent;
+      taps.p[3] = base + ((size_t)y1 * Wf + x1) * kLatent;
+      taps.w[0] = (1.0f - wy) * (1.0f - wx);
+      taps.w[1] = (1.0f - wy) * wx;
+      taps.w[2] = wy * (1.0f - wx);
+      taps.w[3] = wy * wx;
+    }
+
+    f32x4 x[kTiles], net[kTiles];
+    // ---- lin_in: x = W_in f + b_in                                             (resnetfc.py:141)
+    set_bias(x, a.b_pre, q);
+    stage_mma<0>(ws.acquire(), lane, feat, x);
+    stage_mma<1>(ws.acquire(), lane, feat, x);
+    stage_mma<2>(ws.acquire(), lane, feat, x);
+    stage_mma<3>(ws.acquire(), lane, feat, x);
+    // ---- blocks 0..2 (per view)                                                 (:145-157, :61-69)
+    for (int b = 0; b < 3; ++b) {
+      const float* bias = a.b_pre + kHidden * (1 + 3 * b);
+      add_bias(x, bias, q);
+      layer_from_latent(ws, taps, q, x);               // x += lin_z[b](latent)
+      set_bias(net, bias + kHidden, q);
+      layer_from_acc(ws, x, net);                      // net = fc_0(relu(x))
+      add_bias(x, bias + 2 * kHidden, q);
+      layer_from_acc(ws, net, x);                      // x += fc_1(relu(net))
+    }
+    // ---- hand the pre-mean activations to the second kernel in accumulator layout
+    f32x4* out = reinterpret_cast<f32x4*>(a.xpre) + ((size_t)tile * sc.nv + v) * (kTiles * 64) + lane;
+#pragma unroll
+    for (int mo = 0; mo < kTiles; ++mo) out[mo * 64] = x[mo];
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // drain the last (unused) stage prefetch before the LDS is released
+}
+
+struct PostArgs {
+  const float* xpre;
+  const float* w_post;
+  const float* b_post;
+  float* out;          // (P, 4)
+  long long P;
+  int nv;
+  int raw;             // 1: ResnetFC.forward output; 0: sigmoid(rgb), relu(sigma) (pixelnerf.py:139-143)
+};
+
+__global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, pt = lane & 15;
+  const long long n_t16 = (a.P + kPtsPerWave - 1) / kPtsPerWave;
+  const long long n_tiles = (n_t16 + 3) / 4;           // 4 waves x 16 points per workgroup tile
+
+  WeightStream ws;
+  ws.base = a.w_post;
+  ws.lds = smem;
+  ws.n_stages = kPostStages;
+  ws.wave = wave;
+  ws.lane = lane;
+  ws.start();
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    long long t16 = tile * 4 + wave;
+    const bool live = t16 < n_t16;
+    if (!live) t16 = n_t16 - 1;
+    f32x4 x[kTiles], net[kTiles];
+    // ---- mean over the source views (resnetfc.py:148-151)
+    {
+      const f32x4* in = reinterpret_cast<const f32x4*>(a.xpre) + (size_t)t16 * a.nv * (kTiles * 64) + lane;
+#pragma unroll
+      for (int mo = 0; mo < kTiles; ++mo) {
+        f32x4 s = in[mo * 64];
+        for (int vv = 1; vv < a.nv; ++vv) s += in[(size_t)vv * (kTiles * 64) + mo * 64];
+        x[mo] = s / (float)a.nv;
+      }
+    }
+    // ---- blocks 3, 4
+    for (int b = 0; b < 2; ++b) {
+      const float* bias = a.b_post + 2 * kHidden * b;
+      set_bias(net, bias, q);
+      layer_from_acc(ws, x, net);
+      add_bias(x, bias + kHidden, q);
+      layer_from_acc(ws, net, x);
+    }
+    // ---- lin_out (one stage: 16 padded output rows x 512)                       (resnetfc.py:158)
+    {
+      const f32x4* st4 = reinterpret_cast<const f32x4*>(ws.acquire()) + lane;
+      f32x4 o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < kTiles; ++m) {
+        const f32x4 a4 = st4[m * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], fmaxf(x[m][r], 0.0f), o[r], 0, 0, 0);
+      }
+      f32x4 res = (o[0] + o[1]) + (o[2] + o[3]);
+      res += *reinterpret_cast<const f32x4*>(a.b_post + 4 * kHidden + 4 * q);
+      const long long p = t16 * kPtsPerWave + pt;
+      if (live && q == 0 && p < a.P) {
+        if (!a.raw) {
+          res[0] = 1.0f / (1.0f + expf(-res[0]));
+          res[1] = 1.0f / (1.0f + expf(-res[1]));
+          res[2] = 1.0f / (1.0f + expf(-res[2]));
+          res[3] = fmaxf(res[3], 0.0f);
+        }
+        reinterpret_cast<f32x4*>(a.out)[p] = res;
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+// split an explicit (NV, B, 512+55) ResnetFC input into aligned latent rows and 64-padded feature rows
+__global__ void k_split_zx(const float* __restrict__ zx, long long rows, float* __restrict__ lat,
+                           float* __restrict__ feat) {
+  const long long total = rows * (kLatent + kDInPad);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / (kLatent + kDInPad);
+    const int c = (int)(i - row * (kLatent + kDInPad));
+    if (c < kLatent) lat[row * kLatent + c] = zx[row * (kLatent + kDIn) + c];
+    else {
+      const int f = c - kLatent;
+      feat[row * kDInPad + f] = f < kDIn ? zx[row * (kLatent + kDIn) + kLatent + f] : 0.0f;
+    }
+  }
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+static size_t xpre_bytes(long long P, int nv) {
+  const long long n_t16 = (P + kPtsPerWave - 1) / kPtsPerWave;
+  return (size_t)n_t16 * nv * kTiles * 64 * sizeof(f32x4);
+}
+
+static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa, int nv, float* out, int raw,
+                        void* workspace, hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds_bytes = 2 * kStageFloats * sizeof(float);
+  if (!attr_set) {
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  fa.w_pre = m->w_pre;
+  fa.b_pre = m->b_pre;
+  fa.xpre = (float*)workspace;
+  fa.freq_factor = 6.28f;
+  const long long n_t16 = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
+  const int cus = num_cus();
+  SceneDev dummy;
+  if (!sc) {
+    memset(&dummy, 0, sizeof(dummy));
+    dummy.nv = nv;
+    sc = &dummy;
+  }
+  const int grid_pre = (int)(n_t16 < cus ? n_t16 : cus);
+  hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), lds_bytes, stream, *sc, fa);
+  DINER_LAUNCH_OK();
+  PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw};
+  const long long n_tiles = (n_t16 + 3) / 4;
+  const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
+  hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), lds_bytes, stream, pa);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace diner
+
+using namespace diner;
+
+struct DinerMlp {
+  DinerMlpImpl impl;
+};
+
+extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp** out) {
+  DINER_CHECK_ARG(p && out, "mlp_create: null argument");
+  if (p->d_in != kDIn || p->d_latent != kLatent || p->d_hidden != kHidden || p->d_out != 4 || p->n_blocks != 5 ||
+      p->combine_layer != 3) {
+    set_error("mlp_create: unsupported ResnetFC configuration d_in=%d d_latent=%d d_hidden=%d d_out=%d n_blocks=%d "
+              "combine_layer=%d (built for 55/512/512/4/5/3, configs/train_dtu.yaml:44-50)",
+              p->d_in, p->d_latent, p->d_hidden, p->d_out, p->n_blocks, p->combine_layer);
+    return DINER_E_UNSUPPORTED;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  DinerMlp* m = new DinerMlp();
+  memset(&m->impl, 0, sizeof(m->impl));
+  DINER_HIP_OK(hipMalloc(&m->impl.w_pre, (size_t)kPreStages * kStageFloats * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&m->impl.w_post, (size_t)kPostStages * kStageFloats * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&m->impl.b_pre, 10 * kHidden * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&m->impl.b_post, (4 * kHidden + 16) * sizeof(float)));
+  auto pack = [&](const float* W, int rows, int cols, int n_kc, float* dst) {
+    hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, W, rows, cols, n_kc, dst);
+  };
+  auto bias = [&](const float* b, int n, int n_pad, float* dst) {
+    hipLaunchKernelGGL(k_copy_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, dst);
+  };
+  float* wp = m->impl.w_pre;
+  pack(p->lin_in_w, kHidden, kDIn, 1, wp);
+  wp += 4 * kStageFloats;
+  bias(p->lin_in_b, kHidden, kHidden, m->impl.b_pre);
+  for (int b = 0; b < 3; ++b) {
+    pack(p->lin_z_w[b], kHidden, kLatent, 8, wp); wp += kStagesPerLayer * kStageFloats;
+    pack(p->fc0_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
+    pack(p->fc1_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
+    float* bb = m->impl.b_pre + kHidden * (1 + 3 * b);
+    bias(p->lin_z_b[b], kHidden, kHidden, bb);
+    bias(p->fc0_b[b], kHidden, kHidden, bb + kHidden);
+    bias(p->fc1_b[b], kHidden, kHidden, bb + 2 * kHidden);
+  }
+  wp = m->impl.w_post;
+  for (int b = 3; b < 5; ++b) {
+    pack(p->fc0_w[b], kHidden, kHidden, 8, wp); wp += kStagesPerLayer * kStageFloats;
+    pack(p->fc1_w[b], kHidden, kHidden, 8, wp); wp += kStagesPerLayer * kStageFloats;
+    float* bb = m->impl.b_post + 2 * kHidden * (b - 3);
+    bias(p->fc0_b[b], kHidden, kHidden, bb);
+    bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
+  }
+  hipLaunchKernelGGL(k_pack_lin_out, dim3(32), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, wp);
+  bias(p->lin_out_b, 4, 16, m->impl.b_post + 4 * kHidden);
+  DINER_LAUNCH_OK();
+  *out = m;
+  return 0;
+}
+
+extern "C" int diner_mlp_destroy(DinerMlp* m) {
+  if (!m) return 0;
+  hipFree(m->impl.w_pre);
+  hipFree(m->impl.w_post);
+  hipFree(m->impl.b_pre);
+  hipFree(m->impl.b_post);
+  delete m;
+  return 0;
+}
+
+extern "C" size_t diner_field_workspace_bytes(long long n_points) {
+  if (n_points <= 0) return 0;
+  return xpre_bytes(n_points, kMaxViews);     // pre-mean activations in accumulator layout (8 KB / point)
+}
+
+extern "C" size_t diner_mlp_forward_workspace_bytes(long long B) {
+  if (B <= 0) return 0;
+  // as above plus the aligned split of the explicit zx matrix
+  return xpre_bytes(B, kMaxViews) + (size_t)B * kMaxViews * (kLatent + kDInPad) * sizeof(float);
+}
+
+static int check_field_scene(const DinerScene* scene, SceneDev* sd) {
+  int rc = make_scene_dev(scene, sd);
+  if (rc) return rc;
+  DINER_CHECK_ARG(scene->nv == kMaxViews, "field: the fused kernel is built for NV=%d source views (got %d)", kMaxViews,
+                  scene->nv);
+  DINER_CHECK_ARG(scene->C == kLatent, "field: latent size %d != %d", scene->C, kLatent);
+  DINER_CHECK_ARG(scene->latent_cl && scene->depth, "field: latent / depth map missing");
+  DINER_CHECK_ARG(scene->Hf > 0 && scene->Wf > 0 && scene->Hs > 0 && scene->Ws > 0, "field: bad map sizes");
+  return 0;
+}
+
+extern "C" int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays,
+                                         const float* z, int NR, int K, float* field_out, void* workspace,
+                                         void* stream) {
+  DINER_CHECK_ARG(scene && mlp && rays && z && field_out && workspace, "field_from_rays: null pointer argument");
+  DINER_CHECK_ARG(NR > 0 && K > 0, "field_from_rays: bad sizes NR=%d K=%d", NR, K);
+  SceneDev sd;
+  int rc = check_field_scene(scene, &sd);
+  if (rc) return rc;
+  FieldArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.rays = rays;
+  fa.z = z;
+  fa.K = K;
+  fa.P = (long long)NR * K;
+  return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, (hipStream_t)stream);
+}
+
+extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerMlp* mlp, const float* xyz,
+                                           const float* viewdirs, long long P, float* field_out, void* workspace,
+                                           void* stream) {
+  DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && field_out && workspace, "field_from_points: null pointer argument");
+  DINER_CHECK_ARG(P > 0, "field_from_points: P must be positive");
+  SceneDev sd;
+  int rc = check_field_scene(scene, &sd);
+  if (rc) return rc;
+  FieldArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.xyz = xyz;
+  fa.viewdirs = viewdirs;
+  fa.K = 1;
+  fa.P = P;
+  return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, (hipStream_t)stream);
+}
+
+extern "C" int diner_mlp_forward_f32(const DinerMlp* mlp, const float* zx, long long B, float* out, void* workspace,
+                                     void* stream_) {
+  DINER_CHECK_ARG(mlp && zx && out && workspace, "mlp_forward: null pointer argument");
+  DINER_CHECK_ARG(B > 0, "mlp_forward: B must be positive");
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  float* lat = (float*)(ws + xpre_bytes(B, kMaxViews));
+  float* feat = lat + (size_t)kMaxViews * B * kLatent;
+  const long long rows = (long long)kMaxViews * B;
+  hipLaunchKernelGGL(k_split_zx, dim3(2048), dim3(256), 0, stream, zx, rows, lat, feat);
+  DINER_LAUNCH_OK();
+  FieldArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.direct_latent = lat;
+  fa.direct_feat = feat;
+  fa.K = 1;
+  fa.P = B;
+  return launch_field(nullptr, &mlp->impl, fa, kMaxViews, out, 1, workspace, stream);
+}
+
+extern "C" int diner_render_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z, int NR,
+                                int K, int white_bkgd, float* rgb_out, float* depth_out, float* weights_out,
+                                float* field_ws, void* workspace, void* stream) {
+  DINER_CHECK_ARG(field_ws, "render: field scratch missing");
+  int rc = diner_field_from_rays_f32(scene, mlp, rays, z, NR, K, field_ws, workspace, stream);
+  if (rc) return rc;
+  return diner_composite_f32(field_ws, z, rays, NR, K, white_bkgd, rgb_out, depth_out, weights_out, stream);
+}

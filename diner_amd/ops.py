@@ -1,0 +1,305 @@
+"""torch-facing wrappers around the C ABI of libdiner_hip.so.
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the stream and (for multi-GPU) the
+process group.  Every function takes/returns torch tensors on a HIP device and enqueues kernels on the
+current stream.  There is no CPU path and no eager-torch fallback: CPU tensors raise.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+
+lib = _lib.load()          # ImportError when the extension is not built -- by design
+
+MAX_POINTS_PER_LAUNCH = int(os.environ.get("DINER_AMD_MAX_POINTS", 1 << 20))   # bounds the 8 KB/point workspace
+
+
+def _require_hip(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("diner_amd: tensors must live on a HIP device (MI355X); there is no CPU fallback "
+                               "for the rendering hot path")
+        if t.dtype != torch.float32:
+            raise TypeError(f"diner_amd: expected float32, got {t.dtype}")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+_const_cache = {}
+_const_lock = threading.Lock()
+
+
+def _t_base(n_cand, device):
+    """torch.linspace(0, 1 - 1/n, n): the stratification offsets of sample_coarse (nerf_renderer.py:53-55),
+    evaluated by the same torch op the reference uses, then uploaded once."""
+    key = ("t_base", n_cand, str(device))
+    with _const_lock:
+        if key not in _const_cache:
+            step = 1.0 / n_cand
+            _const_cache[key] = torch.linspace(0, 1 - step, n_cand).to(device)
+        return _const_cache[key]
+
+
+def _std_pad_scale(device):
+    """exp(e / 12 * ln 2) for e = 0..99, computed exactly like torch_helpers.py:120."""
+    key = ("std_pad", str(device))
+    with _const_lock:
+        if key not in _const_cache:
+            e = torch.arange(100, dtype=torch.float32)
+            _const_cache[key] = torch.exp(e / 12 * np.log(2)).to(device)
+        return _const_cache[key]
+
+
+class HipScene:
+    """Per-object scene state in the layout the kernels want (DinerScene of include/diner_hip.h).
+
+    latent (NV,C,Hf,Wf) is re-laid-out to channels-last ONCE here (each bilinear tap then is one contiguous
+    2 KB read instead of 512 strided 4-byte reads); depth/std/normal maps are used as they are; the three tiny
+    camera arrays are kept on the host and travel inside the kernel arguments.
+    """
+
+    def __init__(self, latent, depths, depths_std, normals, poses, focal, c, image_shape, feature_padding):
+        dev = None
+        for t in (latent, depths, depths_std, normals):
+            if t is not None:
+                _require_hip(t)
+                dev = t.device
+        if dev is None:
+            raise ValueError("HipScene needs at least one map on a HIP device")
+        self.device = dev
+        self.nv = int(poses.shape[0])
+        self.latent_cl = None
+        self.C = self.Hf = self.Wf = 0
+        if latent is not None:
+            assert latent.dim() == 4 and latent.shape[0] == self.nv
+            self.latent_cl = _f32c(latent.permute(0, 2, 3, 1))          # (NV,Hf,Wf,C)
+            self.C, self.Hf, self.Wf = int(latent.shape[1]), int(latent.shape[2]), int(latent.shape[3])
+        self.depth = _f32c(depths).view(self.nv, *depths.shape[-2:]) if depths is not None else None
+        self.depth_std = _f32c(depths_std).view(self.nv, *depths_std.shape[-2:]) if depths_std is not None else None
+        self.normals = _f32c(normals) if normals is not None else None
+        ref = self.depth if self.depth is not None else (self.depth_std if self.depth_std is not None else self.normals)
+        self.Hs, self.Ws = (int(ref.shape[-2]), int(ref.shape[-1])) if ref is not None else (0, 0)
+        # tiny camera arrays -> host (one sync per scene, at encode time; never inside a render call)
+        self.poses_h = _f32c(poses).cpu().contiguous()
+        if self.poses_h.shape[-2:] != (4, 4):
+            p44 = torch.eye(4).repeat(self.nv, 1, 1)
+            p44[:, :self.poses_h.shape[-2], :] = self.poses_h
+            self.poses_h = p44.contiguous()
+        self.focal_h = _f32c(focal).cpu().contiguous()
+        self.c_h = _f32c(c).cpu().contiguous()
+        ish = image_shape.detach().cpu().float()
+        self.img_w, self.img_h = float(ish[0]), float(ish[1])
+        self.feature_padding = float(feature_padding)
+        self.std_pad_scale = _std_pad_scale(dev)
+        s = _lib.DinerScene()
+        s.latent_cl = self.latent_cl.data_ptr() if self.latent_cl is not None else None
+        s.depth = self.depth.data_ptr() if self.depth is not None else None
+        s.depth_std = self.depth_std.data_ptr() if self.depth_std is not None else None
+        s.normals = self.normals.data_ptr() if self.normals is not None else None
+        s.poses, s.focal, s.c = self.poses_h.data_ptr(), self.focal_h.data_ptr(), self.c_h.data_ptr()
+        s.std_pad_scale = self.std_pad_scale.data_ptr()
+        s.img_w, s.img_h, s.feature_padding = self.img_w, self.img_h, self.feature_padding
+        s.nv, s.C, s.Hf, s.Wf, s.Hs, s.Ws = self.nv, self.C, self.Hf, self.Wf, self.Hs, self.Ws
+        self.struct = s
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
+
+class HipMlp:
+    """Packed ResnetFC weights (opaque DinerMlp handle).  Built from a state_dict-like mapping with the
+    reference key names (resnetfc.py:72-127); tensors must be on the HIP device."""
+
+    def __init__(self, sd, prefix="", combine_layer=3, d_latent=512):
+        g = lambda k: _f32c(sd[prefix + k])
+        n_blocks = len([k for k in sd if k.startswith(prefix + "blocks.") and k.endswith("fc_0.weight")])
+        n_z = len([k for k in sd if k.startswith(prefix + "lin_z.") and k.endswith(".weight")])
+        keep = {"lin_in_w": g("lin_in.weight"), "lin_in_b": g("lin_in.bias"),
+                "lin_out_w": g("lin_out.weight"), "lin_out_b": g("lin_out.bias")}
+        lists = {"fc0_w": [g(f"blocks.{i}.fc_0.weight") for i in range(n_blocks)],
+                 "fc0_b": [g(f"blocks.{i}.fc_0.bias") for i in range(n_blocks)],
+                 "fc1_w": [g(f"blocks.{i}.fc_1.weight") for i in range(n_blocks)],
+                 "fc1_b": [g(f"blocks.{i}.fc_1.bias") for i in range(n_blocks)],
+                 "lin_z_w": [g(f"lin_z.{i}.weight") for i in range(n_z)],
+                 "lin_z_b": [g(f"lin_z.{i}.bias") for i in range(n_z)]}
+        for t in list(keep.values()) + [t for l in lists.values() for t in l]:
+            _require_hip(t)
+        p = _lib.DinerMlpParams()
+        p.d_in = keep["lin_in_w"].shape[1]
+        p.d_hidden = keep["lin_in_w"].shape[0]
+        p.d_out = keep["lin_out_w"].shape[0]
+        p.d_latent = lists["lin_z_w"][0].shape[1] if n_z else 0
+        p.n_blocks, p.combine_layer = n_blocks, combine_layer
+        p.lin_in_w, p.lin_in_b = keep["lin_in_w"].data_ptr(), keep["lin_in_b"].data_ptr()
+        p.lin_out_w, p.lin_out_b = keep["lin_out_w"].data_ptr(), keep["lin_out_b"].data_ptr()
+        self._arrays = {}
+        for name, ts in lists.items():
+            arr = (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
+            self._arrays[name] = arr
+            setattr(p, name, C.cast(arr, C.POINTER(C.c_void_p)))
+        self.device = keep["lin_in_w"].device
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.diner_mlp_create(C.byref(p), _stream(), C.byref(h)))
+            torch.cuda.current_stream().synchronize()     # sources may be freed after packing
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib.diner_mlp_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------------
+def sample_depthguided(scene: HipScene, rays, n_samples, n_candidates, n_gaussian, depth_diff_max=0.05,
+                       noise=None, seed=0, want_unfilled=False):
+    """rays (NR,8) -> ascending z (NR,K) [, unfilled z with zeros].  noise = (coarse, gauss, fill) or None
+    (in-kernel Philox keyed by `seed`)."""
+    _require_hip(rays)
+    rays = _f32c(rays)
+    NR = rays.shape[0]
+    K, G = int(n_samples), int(n_gaussian)
+    z = torch.empty(NR, K, device=rays.device, dtype=torch.float32)
+    zu = torch.empty(NR, K, device=rays.device, dtype=torch.float32) if want_unfilled else None
+    nc = ng = nf = None
+    if noise is not None:
+        nc, ng, nf = (_f32c(t) if t is not None else None for t in noise)
+        _require_hip(nc, ng, nf)
+        assert nc is None or tuple(nc.shape) == (NR, n_candidates)
+        assert ng is None or tuple(ng.shape) == (NR, G)
+        assert nf is None or tuple(nf.shape) == (NR, K)
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.diner_sample_depthguided_f32(
+            scene.ref, _ptr(rays), NR, int(n_candidates), K, G, float(depth_diff_max),
+            _ptr(_t_base(int(n_candidates), rays.device)), _ptr(nc), _ptr(ng), _ptr(nf),
+            C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(z), _ptr(zu), _stream()))
+    return (z, zu) if want_unfilled else z
+
+
+def fill_uniform(z_in, rays, noise_fill=None, seed=0):
+    _require_hip(z_in, rays, noise_fill)
+    z_in, rays = _f32c(z_in), _f32c(rays)
+    NR, K = z_in.shape
+    out = torch.empty_like(z_in)
+    nf = _f32c(noise_fill) if noise_fill is not None else None
+    with torch.cuda.device(rays.device):
+        _lib.check(lib.diner_fill_uniform_f32(_ptr(z_in), _ptr(rays), NR, K, _ptr(nf),
+                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(out), _stream()))
+    return out
+
+
+def _workspace(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z):
+    """PixelNeRF.forward at every (ray, sample): (NR,8),(NR,K) -> (NR,K,4) [sigmoid rgb, relu sigma]."""
+    _require_hip(rays, z)
+    rays, z = _f32c(rays), _f32c(z)
+    NR, K = z.shape
+    out = torch.empty(NR, K, 4, device=rays.device, dtype=torch.float32)
+    rays_per = max(1, MAX_POINTS_PER_LAUNCH // K)
+    with torch.cuda.device(rays.device):
+        ws = _workspace(lib.diner_field_workspace_bytes(min(NR, rays_per) * K), rays.device)
+        for r0 in range(0, NR, rays_per):
+            r1 = min(NR, r0 + rays_per)
+            _lib.check(lib.diner_field_from_rays_f32(scene.ref, mlp.handle, _ptr(rays[r0:r1]), _ptr(z[r0:r1]),
+                                                     r1 - r0, K, _ptr(out[r0:r1]), _ptr(ws), _stream()))
+    return out
+
+
+def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs):
+    """PixelNeRF.forward(xyz, viewdirs): (P,3),(P,3) -> (P,4)."""
+    _require_hip(xyz, viewdirs)
+    xyz, viewdirs = _f32c(xyz), _f32c(viewdirs)
+    P = xyz.shape[0]
+    out = torch.empty(P, 4, device=xyz.device, dtype=torch.float32)
+    step = MAX_POINTS_PER_LAUNCH
+    with torch.cuda.device(xyz.device):
+        ws = _workspace(lib.diner_field_workspace_bytes(min(P, step)), xyz.device)
+        for p0 in range(0, P, step):
+            p1 = min(P, p0 + step)
+            _lib.check(lib.diner_field_from_points_f32(scene.ref, mlp.handle, _ptr(xyz[p0:p1]), _ptr(viewdirs[p0:p1]),
+                                                       p1 - p0, _ptr(out[p0:p1]), _ptr(ws), _stream()))
+    return out
+
+
+def mlp_forward(mlp: HipMlp, zx):
+    """ResnetFC.forward on an explicit (NV,B,567) matrix -> raw (B,4)."""
+    _require_hip(zx)
+    zx = _f32c(zx)
+    NV, B, D = zx.shape
+    if NV != 4 or D != 567:
+        raise ValueError(f"diner_amd: fused ResnetFC is built for (4, B, 567) inputs, got {tuple(zx.shape)}")
+    out = torch.empty(B, 4, device=zx.device, dtype=torch.float32)
+    with torch.cuda.device(zx.device):
+        ws = _workspace(lib.diner_mlp_forward_workspace_bytes(B), zx.device)
+        _lib.check(lib.diner_mlp_forward_f32(mlp.handle, _ptr(zx), B, _ptr(out), _ptr(ws), _stream()))
+    return out
+
+
+def composite(field, z, rays, white_bkgd, want_weights=True):
+    """(NR,K,4),(NR,K),(NR,8) -> weights (NR,K) | None, rgb (NR,3), depth (NR)."""
+    _require_hip(field, z, rays)
+    field, z, rays = _f32c(field), _f32c(z), _f32c(rays)
+    NR, K = z.shape
+    rgb = torch.empty(NR, 3, device=z.device, dtype=torch.float32)
+    depth = torch.empty(NR, device=z.device, dtype=torch.float32)
+    w = torch.empty(NR, K, device=z.device, dtype=torch.float32) if want_weights else None
+    with torch.cuda.device(z.device):
+        _lib.check(lib.diner_composite_f32(_ptr(field), _ptr(z), _ptr(rays), NR, K, int(bool(white_bkgd)),
+                                           _ptr(rgb), _ptr(depth), _ptr(w), _stream()))
+    return w, rgb, depth
+
+
+def render(scene: HipScene, mlp: HipMlp, rays, z, white_bkgd, want_weights=False):
+    """field + composite (NeRFRendererDGS.composite): -> weights | None, rgb, depth."""
+    field = field_from_rays(scene, mlp, rays, z)
+    return composite(field, z, rays, white_bkgd, want_weights)
+
+
+def posenc(x, num_freqs, freq_factor, include_input=True):
+    _require_hip(x)
+    shp = x.shape
+    xf = _f32c(x).reshape(-1, shp[-1])
+    d_out = shp[-1] * (2 * num_freqs + (1 if include_input else 0))
+    out = torch.empty(xf.shape[0], d_out, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.diner_posenc_f32(_ptr(xf), xf.shape[0], shp[-1], int(num_freqs), float(freq_factor),
+                                        int(bool(include_input)), _ptr(out), _stream()))
+    return out.reshape(*shp[:-1], d_out)
+
+
+INDEX_LATENT, INDEX_DEPTH, INDEX_DEPTH_STD, INDEX_NORMAL = 0, 1, 2, 3
+
+
+def index(scene: HipScene, mode, uv):
+    """uv (NV,N,2) -> (NV,Cout,N)."""
+    _require_hip(uv)
+    uv = _f32c(uv)
+    NV, N, _ = uv.shape
+    cout = {0: scene.C, 1: 1, 2: 1, 3: 3}[mode]
+    out = torch.empty(NV, cout, N, device=uv.device, dtype=torch.float32)
+    with torch.cuda.device(uv.device):
+        _lib.check(lib.diner_index_f32(scene.ref, int(mode), _ptr(uv), N, _ptr(out), _stream()))
+    return out

@@ -19,44 +19,47 @@ import torch
 
 
 def look_at_extrinsics(cam_pos, target=(0.0, 0.0, 0.0), up=(0.0, -1.0, 0.0)):
-    """world->camera (4,4), OpenCV convention (x right, y down, z forward)."""
-    p = torch.tensor(cam_pos, dtype=torch.float64)
-    t = torch.tensor(target, dtype=torch.float64)
-    z = t - p
-    z = z / z.norm()
-    upv = torch.tensor(up, dtype=torch.float64)
-    x = torch.linalg.cross(z, upv)      # y-down camera: x = z x (-y_world_up) handled by `up`
-    x = x / x.norm()
-    y = torch.linalg.cross(z, x)
-    R = torch.stack((x, y, z), dim=0)   # rows = camera axes in world coords
-    E = torch.eye(4, dtype=torch.float64)
-    E[:3, :3] = R
-    E[:3, 3] = -R @ p
-    return E.float()
+    """world->camera (4,4), OpenCV convention (x right, y down, z forward).  Pure Python float math so that
+    the matrix is bit-identical on every host (torch reductions are not)."""
+    def sub(a, b): return [a[i] - b[i] for i in range(3)]
+    def cross(a, b): return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+    def unit(a):
+        n = math.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
+        return [a[0] / n, a[1] / n, a[2] / n]
+    p = [float(v) for v in cam_pos]
+    z = unit(sub([float(v) for v in target], p))
+    x = unit(cross(z, [float(v) for v in up]))
+    y = cross(z, x)
+    R = [x, y, z]                       # rows = camera axes in world coordinates
+    E = [[R[i][0], R[i][1], R[i][2], -(R[i][0] * p[0] + R[i][1] * p[1] + R[i][2] * p[2])] for i in range(3)]
+    E.append([0.0, 0.0, 0.0, 1.0])
+    return torch.tensor(E, dtype=torch.float64).float()
 
 
 def _analytic_depth(E, Kmat, W, H, radius=0.25, plane_z=0.35, plane_half=0.6):
-    """z-depth (camera frame) of the first hit of the sphere / finite back plane; 0 = background."""
+    """z-depth (camera frame) of the first hit of the sphere / finite back plane; 0 = background.
+    Element-wise float64 ops only (IEEE, host independent)."""
     E = E.double()
     Kd = Kmat.double()
     ys, xs = torch.meshgrid(torch.arange(0.5, H, 1.0, dtype=torch.float64),
                             torch.arange(0.5, W, 1.0, dtype=torch.float64), indexing="ij")
-    dc = torch.stack(((xs - Kd[0, 2]) / Kd[0, 0], (ys - Kd[1, 2]) / Kd[1, 1], torch.ones_like(xs)), -1)
+    dcx, dcy = (xs - Kd[0, 2]) / Kd[0, 0], (ys - Kd[1, 2]) / Kd[1, 1]
     R, t = E[:3, :3], E[:3, 3]
-    o = -R.T @ t
-    dw = dc @ R            # (H,W,3): R^T applied to each row vector
-    # sphere |o + s d|^2 = r^2   (s is the camera-frame z-depth because dc.z == 1)
-    a = (dw * dw).sum(-1)
-    b = 2 * (dw * o).sum(-1)
-    c = (o * o).sum() - radius ** 2
+    o = [-(R[0, i] * t[0] + R[1, i] * t[1] + R[2, i] * t[2]) for i in range(3)]          # -R^T t
+    dw = [R[0, i] * dcx + R[1, i] * dcy + R[2, i] for i in range(3)]                     # R^T [dcx, dcy, 1]
+    # sphere |o + s d|^2 = r^2   (s is the camera-frame z-depth because the camera-frame direction has z == 1)
+    a = dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]
+    b = 2 * (dw[0] * o[0] + dw[1] * o[1] + dw[2] * o[2])
+    c = (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) - radius ** 2
     disc = b * b - 4 * a * c
-    s_sph = torch.where(disc > 0, (-b - torch.sqrt(disc.clamp(min=0))) / (2 * a), torch.full_like(a, float("inf")))
-    s_sph = torch.where(s_sph > 0, s_sph, torch.full_like(a, float("inf")))
+    inf = torch.full_like(a, float("inf"))
+    s_sph = torch.where(disc > 0, (-b - torch.sqrt(disc.clamp(min=0))) / (2 * a), inf)
+    s_sph = torch.where(s_sph > 0, s_sph, inf)
     # plane z_world = plane_z, finite extent
-    s_pl = (plane_z - o[2]) / dw[..., 2]
-    hit = o + s_pl.unsqueeze(-1) * dw
-    ok = (s_pl > 0) & (hit[..., 0].abs() <= plane_half) & (hit[..., 1].abs() <= plane_half)
-    s_pl = torch.where(ok, s_pl, torch.full_like(a, float("inf")))
+    s_pl = (plane_z - o[2]) / dw[2]
+    hx, hy = o[0] + s_pl * dw[0], o[1] + s_pl * dw[1]
+    ok = (s_pl > 0) & (hx.abs() <= plane_half) & (hy.abs() <= plane_half)
+    s_pl = torch.where(ok, s_pl, inf)
     s = torch.minimum(s_sph, s_pl)
     return torch.where(torch.isfinite(s), s, torch.zeros_like(s)).float()
 

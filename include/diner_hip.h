@@ -1,0 +1,136 @@
+/*
+ * diner_hip.h -- C ABI of libdiner_hip.so: DINER's volumetric-rendering hot path on MI355X (gfx950).
+ *
+ * The reference (malteprinzler/diner) is pure Python/PyTorch and has no FFI of its own; the
+ * boundary it offers is the Python module API of the src/models Python modules.  Each entry point below replaces
+ * the body of one of those Python functions (cited as file:line in /root/reference) and is what a
+ * maintainer would bind with ctypes from those modules -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HIP) to contiguous row-major fp32 unless stated;
+ *   - every call only ENQUEUES work on the caller's stream (hipStream_t passed as void*);
+ *     no hidden synchronisation, no allocation, no global mutable state besides the
+ *     thread-local error string;
+ *   - return value: 0 = ok, negative = DINER_E_*; diner_last_error() gives the message;
+ *   - the caller (PyTorch's caching allocator in the Python host) owns all buffers; the library
+ *     owns only the packed-weights handle created by diner_mlp_create().
+ */
+#ifndef DINER_HIP_H
+#define DINER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINER_ABI_VERSION 1
+
+#define DINER_E_INVALID     (-1)  /* bad argument (null pointer, size, unsupported configuration) */
+#define DINER_E_UNSUPPORTED (-2)  /* configuration outside what the kernels are built for        */
+#define DINER_E_HIP         (-3)  /* a HIP runtime call failed                                     */
+
+/* Per-object scene state: what the reference keeps on PixelNeRF / SpatialEncoder after encode()
+ * (pixelnerf.py:47-51; image_encoder.py:232-236, :290-291). */
+typedef struct DinerScene {
+  const float* latent_cl;   /* (NV, Hf, Wf, C)  feature map, CHANNELS-LAST (re-laid-out once per encode) */
+  const float* depth;       /* (NV, Hs, Ws)     source depth maps, 0 = background                          */
+  const float* depth_std;   /* (NV, Hs, Ws)     depth standard deviation                                    */
+  const float* normals;     /* (NV, 3, Hs, Ws)  normal maps (planar, as produced by depth2normal)          */
+  const float* poses;       /* HOST (NV, 4, 4)  world->camera extrinsics, row-major  -- the three camera arrays are  */
+  const float* focal;       /* HOST (NV, 2)     fx, fy                                  tiny and are copied by value  */
+  const float* c;           /* HOST (NV, 2)     cx, cy                                  into the kernel arguments     */
+  const float* std_pad_scale; /* (100)          multipliers exp(e/12*ln2), e = 0..99, of the exponential std padding
+                                                 (torch_helpers.py:110-120 with pad_size=100, pad_double_width=12,
+                                                 image_encoder.py:185-194); computed by the host exactly as the
+                                                 reference does so that padded sigma values are bit-identical        */
+  float img_w, img_h;       /* PixelNeRF.image_shape = [W, H] (pixelnerf.py:50-51)                         */
+  float feature_padding;    /* SpatialEncoder.feature_padding (image_encoder.py:59), 32 in the shipped configs */
+  int32_t nv, C, Hf, Wf, Hs, Ws;
+} DinerScene;
+
+/* ResnetFC parameters as the reference stores them (nn.Linear: weight (out,in), bias (out));
+ * resnetfc.py:72-127.  Host or device pointers are both accepted by diner_mlp_create (flag). */
+typedef struct DinerMlpParams {
+  int32_t d_in, d_latent, d_hidden, d_out, n_blocks, combine_layer;
+  const float* lin_in_w;  const float* lin_in_b;       /* (d_hidden, d_in), (d_hidden)          */
+  const float* lin_out_w; const float* lin_out_b;      /* (d_out, d_hidden), (d_out)            */
+  const float* const* fc0_w; const float* const* fc0_b; /* n_blocks x (d_hidden,d_hidden),(d_hidden) */
+  const float* const* fc1_w; const float* const* fc1_b;
+  const float* const* lin_z_w; const float* const* lin_z_b; /* min(combine_layer,n_blocks) x (d_hidden,d_latent) */
+} DinerMlpParams;
+
+typedef struct DinerMlp DinerMlp;   /* opaque: weights re-packed into MFMA-fragment order, resident in HBM */
+
+int         diner_abi_version(void);
+const char* diner_last_error(void);
+
+/* ---- packed weights ---------------------------------------------------------------------------
+ * Packs the ResnetFC parameters (DEVICE pointers) into stage-tile order on `stream`.
+ * Supported: d_in=55, d_latent=512, d_hidden=512, d_out=4, n_blocks=5, combine_layer=3 (the
+ * configuration of configs/train_dtu.yaml:44-50 and train_facescape.yaml), NV = 4. */
+int diner_mlp_create(const DinerMlpParams* p, void* stream, DinerMlp** out);
+int diner_mlp_destroy(DinerMlp* mlp);
+
+/* ---- a1+a2+a3+a4: NeRFRendererDGS.sample_depthguided + fill_up_uniform_samples ---------------
+ * (nerf_renderer.py:39-63, :65-190, :367-397; torch_helpers.py:215-223; image_encoder.py:148-223)
+ *   rays         (NR, 8)  [o(3), d(3), near, far]
+ *   t_base       (n_cand) the stratification offsets torch.linspace(0, 1-1/n_cand, n_cand)
+ *   noise_*      explicit noise (parity mode) or NULL -> counter-based Philox4x32-10 keyed by `seed`
+ *                noise_coarse (NR,n_cand) U[0,1); noise_gauss (NR,G) N(0,1); noise_fill (NR,K) U[0,1)
+ *                indexed by the SORTED column of the empty slot
+ *   z_out        (NR, K)  ascending z per ray
+ *   z_unfilled   optional (NR, K): the sampler output before the fill (zeros = empty), or NULL
+ * Limits: n_cand <= 1024, K <= 256, 0 <= G <= K. */
+int diner_sample_depthguided_f32(const DinerScene* scene, const float* rays, int NR, int n_cand, int K, int G,
+                                 float depth_diff_max, const float* t_base,
+                                 const float* noise_coarse, const float* noise_gauss, const float* noise_fill,
+                                 uint64_t seed, float* z_out, float* z_unfilled, void* stream);
+
+/* Stage-level entry for tests: fill_up_uniform_samples alone (nerf_renderer.py:367-397). */
+int diner_fill_uniform_f32(const float* z_in, const float* rays, int NR, int K, const float* noise_fill,
+                           uint64_t seed, float* z_out, void* stream);
+
+/* ---- a5+a6+a7+a8: PixelNeRF.forward at ray samples -------------------------------------------
+ * (pixelnerf.py:55-145; positional_encoding.py:33-53; image_encoder.py:97-170; resnetfc.py:129-159)
+ * Points are o + z*d for every (ray, sample); view directions are the ray directions.
+ *   field_out  (NR*K, 4) = [sigmoid(r,g,b), relu(sigma)]
+ *   workspace  diner_field_workspace_bytes(NR*K) bytes of device scratch */
+size_t diner_field_workspace_bytes(long long n_points);
+int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z,
+                              int NR, int K, float* field_out, void* workspace, void* stream);
+/* Same, explicit points / view directions (P,3): PixelNeRF.forward(xyz, viewdirs) (pixelnerf.py:55). */
+int diner_field_from_points_f32(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs,
+                                long long P, float* field_out, void* workspace, void* stream);
+
+/* ---- a7 alone: ResnetFC.forward(zx, combine_dim) on an explicit (NV, B, d_latent+d_in) matrix --
+ * workspace: diner_mlp_forward_workspace_bytes(B) bytes. */
+size_t diner_mlp_forward_workspace_bytes(long long B);
+int diner_mlp_forward_f32(const DinerMlp* mlp, const float* zx, long long B, float* out /* (B,4) raw */,
+                          void* workspace, void* stream);
+
+/* ---- a9: compositing (nerf_renderer.py:299-301, :341-360) ------------------------------------
+ *   field (NR*K,4), z (NR,K), rays (NR,8) -> rgb (NR,3), depth (NR), weights (NR,K) or NULL */
+int diner_composite_f32(const float* field, const float* z, const float* rays, int NR, int K, int white_bkgd,
+                        float* rgb_out, float* depth_out, float* weights_out, void* stream);
+
+/* ---- a10: NeRFRendererDGS.composite / forward (nerf_renderer.py:286-365, :399-424) -----------
+ * field + composite in one call; `field_ws` is (NR*K,4) scratch the caller provides. */
+int diner_render_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z, int NR, int K,
+                     int white_bkgd, float* rgb_out, float* depth_out, float* weights_out,
+                     float* field_ws, void* workspace, void* stream);
+
+/* ---- stage-level entries that back the reference's small public methods ---------------------- */
+/* PositionalEncoding.forward (positional_encoding.py:33-53): x (N,d_in) -> (N, d_in*(2F+include_input)) */
+int diner_posenc_f32(const float* x, long long N, int d_in, int num_freqs, float freq_factor, int include_input,
+                     float* out, void* stream);
+/* SpatialEncoder.index / index_depth / index_depth_std / index_normal (image_encoder.py:97-223):
+ *   uv (NV, N, 2) in [-1,1] -> out (NV, Cout, N); mode: 0 latent (bilinear/border, Cout=C),
+ *   1 depth (nearest/border), 2 depth_std (nearest on the 100px exponential padding, zeros), 3 normal. */
+int diner_index_f32(const DinerScene* scene, int mode, const float* uv, long long N, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINER_HIP_H */

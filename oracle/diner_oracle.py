@@ -160,12 +160,33 @@ def index_normal(scene: Scene, uv):
 # --------------------------------------------------------------------------------------
 # shared geometry
 # --------------------------------------------------------------------------------------
+def _fma32(a, b, c):
+    """fp32 fused multiply-add, emulated through float64 (a*b is exact there)."""
+    return (a.double() * b.double() + c.double()).float()
+
+
+def rot3(R, x):
+    """R (NV,3,3) applied to x (B,3) or (NV,B,3) -> (NV,B,3).
+
+    The reference writes this as torch.matmul(R, x^T)^T (pixelnerf.py:92,:100; nerf_renderer.py:100,:103).
+    MKL's sgemm evaluates the K=3 contraction as r0*x0, fma(r1,x1,.), fma(r2,x2,.) on the machine the oracle
+    was pinned on, but its kernel choice (hence the last bit of the result) differs between CPUs; nearest-
+    neighbour taps downstream turn such a bit into a different pixel.  The oracle therefore spells the
+    contraction out -- bit-identical to the reference's matmul where it was pinned (oracle/make_golden.py
+    asserts this on every fixture) and identical on every host."""
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    x0, x1, x2 = x[..., 0], x[..., 1], x[..., 2]
+    rows = []
+    for i in range(3):
+        r0, r1, r2 = (R[:, i, k].view(-1, 1) for k in range(3))
+        rows.append(_fma32(r2, x2, _fma32(r1, x1, r0 * x0)))
+    return torch.stack(rows, dim=-1)
+
+
 def world_to_cam(scene: Scene, xyz):
     """xyz (B,3) world -> (NV,B,3) camera frames: R x + t  (pixelnerf.py:91-93, nerf_renderer.py:99-101)."""
-    NV = scene.nv
-    x = xyz.unsqueeze(0).expand(NV, -1, -1)
-    rot = torch.matmul(scene.poses[:, :3, :3], x.transpose(-2, -1)).transpose(-2, -1)
-    return rot + scene.poses[:, :3, -1].unsqueeze(-2)
+    return rot3(scene.poses[:, :3, :3], xyz) + scene.poses[:, :3, -1].unsqueeze(-2)
 
 
 def project_uv(scene: Scene, xyz_cam):
@@ -197,8 +218,7 @@ def point_likelihood(scene: Scene, rays, z_cand, depth_diff_max=0.05):
     step_size = (rays[:, 7] - rays[:, 6]) / n_cand                               # :95
     xyz = rays[:, None, :3] + z_cand.unsqueeze(-1) * rays[:, None, 3:6]           # :96
     xyz_cam = world_to_cam(scene, xyz.reshape(-1, 3))                            # :99-101
-    dirs = rays[:, 3:6].unsqueeze(0).expand(NV, NR, 3)
-    dirs_cam = (scene.poses[:, :3, :3] @ dirs.transpose(-2, -1)).transpose(-2, -1)  # :103
+    dirs_cam = rot3(scene.poses[:, :3, :3], rays[:, 3:6])                         # :103
     pdirs_cam = dirs_cam.repeat_interleave(n_cand, dim=-2)                       # :104
     uv = project_uv(scene, xyz_cam)                                              # :107-110
     ref_d = index_depth(scene, uv)                                               # (NV,1,B)
@@ -206,7 +226,8 @@ def point_likelihood(scene: Scene, rays, z_cand, depth_diff_max=0.05):
     ref_n = index_normal(scene, uv)                                              # (NV,3,B)
     ref_z = xyz_cam[..., 2:].permute(0, 2, 1)                                    # (NV,1,B)
     ss = step_size.repeat_interleave(n_cand).view(1, 1, -1).expand_as(ref_d)
-    cosd = (pdirs_cam.transpose(-2, -1) * ref_n).sum(dim=-2, keepdim=True)       # :119
+    pd = pdirs_cam.transpose(-2, -1)                                             # (NV,3,B)
+    cosd = ((pd[:, 0:1] * ref_n[:, 0:1] + pd[:, 1:2] * ref_n[:, 1:2]) + pd[:, 2:3] * ref_n[:, 2:3])   # :119 (sum over 3)
     mask = (ref_s != 0) & ((ref_d - ref_z).abs() < depth_diff_max) & (cosd <= 0)  # :121-124
     L = torch.zeros_like(ref_d)
     sq2 = np.sqrt(2)
@@ -290,8 +311,7 @@ def mlp_input(scene: Scene, xyz, viewdirs, num_freqs=6, freq_factor=6.28):
     NV = scene.nv
     xc = world_to_cam(scene, xyz)                                                # :91-93
     zf = posenc(xc, num_freqs, freq_factor)                                      # :96
-    vd = viewdirs.unsqueeze(0).expand(NV, -1, -1)
-    vd = torch.matmul(scene.poses[:, :3, :3], vd.transpose(-1, -2)).transpose(-1, -2)   # :100
+    vd = rot3(scene.poses[:, :3, :3], viewdirs)                                  # :100
     zf = torch.cat((zf, vd), dim=-1)
     uv = project_uv(scene, xc)
     lat = index_latent(scene, uv).transpose(-1, -2)                              # (NV,B,C)
@@ -349,7 +369,9 @@ def render(scene: Scene, w: MLPWeights, rays, n_samples, n_cand, n_gaussian, whi
 # --------------------------------------------------------------------------------------
 def gen_rays(extr, intr, W, H, z_near, z_far):
     """(4,4),(3,3) -> (H*W, 8) rays [o, d, near, far], row-major pixels, centres at +0.5
-    (cam_geometry.py:5-48)."""
+    (cam_geometry.py:5-48).  Ray generation is NOT on the hot path; like the reference it goes through
+    torch.matmul, whose last bit depends on the host's BLAS kernels, so the golden fixtures store the rays
+    themselves instead of regenerating them."""
     focal = intr[[0, 1], [0, 1]]
     c = intr[[0, 1], [-1, -1]]
     ys, xs = torch.meshgrid(torch.arange(.5, H, 1), torch.arange(.5, W, 1), indexing="ij")
@@ -357,7 +379,7 @@ def gen_rays(extr, intr, W, H, z_near, z_far):
     pc = torch.cat((pc, torch.ones_like(pc[..., :1])), dim=-1)
     dcam = pc / pc.pow(2).sum(dim=-1, keepdim=True).sqrt()
     Rc2w = extr[:3, :3].permute(1, 0)
-    dw = (Rc2w @ dcam.view(-1, 3).permute(1, 0)).permute(1, 0)
-    o = (-1 * Rc2w @ extr[:3, -1:]).view(1, 3).expand(H * W, -1)
+    dw = (Rc2w @ dcam.view(-1, 3).permute(1, 0)).permute(1, 0)                   # cam_geometry.py:37-38
+    o = (-1 * Rc2w @ extr[:3, -1:]).view(1, 3).expand(H * W, -1)                 # :41
     nf = torch.tensor([z_near, z_far], dtype=torch.float32).view(1, 2).expand(H * W, -1)
     return torch.cat((o, dw, nf), dim=-1)

@@ -175,7 +175,7 @@ def main():
                   f"rays with a tie at the cut-off: {ties}, zeros before fill: {(z0 == 0).sum().item()}")
             assert ties == 0
             np.savez_compressed(os.path.join(OUT, f"g3_sampler_K{K}.npz"), W=W, H=H, seed=0, ray_idx=sel.numpy(),
-                                K=K, G=G, n_cand=n_cand, noise_seed=103, in_sha=sha(rs, ncz, ngz, nfz),
+                                K=K, G=G, n_cand=n_cand, noise_seed=103, rays=rs.numpy(), in_sha=sha(ncz, ngz, nfz),
                                 L_sum=aux["L"].sum(-1).numpy(), O_sum=aux["O"].sum(-1).numpy(),
                                 z_unfilled=z0_ref[0].numpy(), z=z_ref[0].numpy())
         # a hand-made fill case: negative gaussian sample, all-empty ray, full ray
@@ -230,7 +230,9 @@ def main():
             gold.update({f"weights_{int(wb)}": w_ref[0].numpy(), f"rgb_{int(wb)}": rgb_ref[0].numpy(),
                          f"depth_{int(wb)}": d_ref[0].numpy()})
         gold["field"] = field.numpy()
-        np.savez_compressed(os.path.join(OUT, "g7_composite.npz"), W=W, H=H, seed=0, **gold)
+        np.savez_compressed(os.path.join(OUT, "g7_composite.npz"), W=W, H=H, seed=0,
+                            scene_sha=sha(sc["latent"], sc["depths"], sc["depths_std"], scene.normals, sc["src_extrinsics"],
+                                          *[v for k, v in sorted(make_mlp_state_dict().items())]), **gold)
 
         # ------------------------------------------------------------------ G8 end-to-end cfg 1
         print("G8 renderer.forward, cfg 1: 64x64 rays, K=64, G=24, 1000 candidates (takes ~1-2 min)")
@@ -243,15 +245,18 @@ def main():
         ren = R(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=False)
         with inject_noise(ncz, ngz, nfz):
             out = ren.forward(nerf, rays[None], want_weights=True)
+            # the sampler output the reference used inside forward (same injected noise -> same z)
+            o_z_ref = ren.fill_up_uniform_samples(
+                ren.sample_depthguided(rays[None], nerf, n_samples=K, n_candidates=n_cand, n_gaussian=G), rays[None])[0]
         sub = slice(0, NRr, 8)      # the oracle re-runs every 8th ray (rays are independent)
         o = O.render(scene, w, rays[sub].contiguous(), K, n_cand, G, False, ncz[sub], ngz[sub], nfz[sub])
         report("e2e rgb", out.fine.rgb[0][sub], o["rgb"])
         report("e2e depth", out.fine.depth[0][sub], o["depth"])
         report("e2e weights", out.fine.weights[0][sub], o["weights"])
         np.savez_compressed(os.path.join(OUT, "g8_render_cfg1.npz"), W=W, H=H, seed=0, K=K, G=G, n_cand=n_cand,
-                            noise_seed=108, in_sha=sha(rays, ncz[:64], ngz[:64], nfz[:64]),
+                            noise_seed=108, rays=rays.numpy(), in_sha=sha(ncz[:64], ngz[:64], nfz[:64]),
                             rgb=out.fine.rgb[0].numpy(), depth=out.fine.depth[0].numpy(),
-                            weights_sum=out.fine.weights[0].sum(-1).numpy(),
+                            z=o_z_ref.numpy(), weights_sum=out.fine.weights[0].sum(-1).numpy(),
                             weights_sub=out.fine.weights[0][::16].numpy())
     print("golden vectors written to", OUT)
 

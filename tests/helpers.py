@@ -42,3 +42,27 @@ def oracle_setup(W, H, seed, bg_std_zero=False):
 def max_norm_rel(a, b):
     a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item()
+
+
+SAT_L = 1e-6   # "erf-saturation" class, see selection_diff
+
+
+def selection_diff(ref_u, got_u, L, zc):
+    """Rays whose depth-guided picks differ between two implementations, and the largest reference likelihood
+    among the candidates that are in one pick set but not in the other.
+
+    A candidate 4-5 sigma away from the surface has L = 0.5*|erf(a)-erf(b)| with both erf values within 1-2 ulp
+    of +-1: L is 0, 3e-8 or 6e-8 depending on the last bit of the erf implementation (Sleef's AVX-512 kernel on
+    the Intel host that generated the fixtures, another Sleef kernel on an AMD host, ocml on the GPU, CUDA's erff
+    for the reference on an A100 -- they all differ).  When a ray has fewer than K-G positive candidates, whether
+    such a candidate counts as "L > 0" (nerf_renderer.py:176) is therefore implementation-defined in the reference
+    itself.  Everything above SAT_L must match exactly.  ref_u / got_u: per-ray ascending unfilled z."""
+    bad = (~torch.isclose(got_u, ref_u, rtol=3e-6, atol=1e-7).all(-1)).nonzero().flatten().tolist()
+    worst = 0.0
+    for r in bad:
+        only = set(ref_u[r].tolist()) ^ set(got_u[r].tolist())
+        for zz in only:
+            i = (zc[r] == zz).nonzero().flatten()
+            if len(i):                       # a candidate depth (not a gaussian / fill sample)
+                worst = max(worst, float(L[r, i[0]]))
+    return bad, worst

@@ -1,0 +1,236 @@
+"""GPU parity: every HIP stage (through the C ABI, via diner_amd.ops) against the golden vectors generated
+from the imported reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances: north_star asks for 1e-4 relative fp32 on the renderer outputs; the fp32 noise floor of the
+reference path itself is ~5e-6.  Index/selection work is compared exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diner_oracle as O
+from tests.helpers import load, oracle_setup, max_norm_rel, sha, selection_diff, SAT_L
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star tolerance on rendered outputs
+TOL_STAGE = 2e-5    # what the individual fp32 stages are held to
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from diner_amd import ops as _ops
+    return _ops
+
+
+def hip_scene(ops, sc):
+    K = sc["src_intrinsics"]
+    return ops.HipScene(sc["latent"].cuda(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(),
+                        sc["src_extrinsics"], K[:, [0, 1], [0, 1]], K[:, :2, -1], sc["image_shape"],
+                        sc["feature_padding"])
+
+
+def hip_mlp(ops, msd):
+    return ops.HipMlp({k: v.cuda() for k, v in msd.items()})
+
+
+def test_posenc(ops):
+    g = load("g1_posenc.npz")
+    for x, y in ((g["x3"], g["y3"]), (g["x1"], g["y1"])):
+        out = ops.posenc(T(x).cuda(), 6, 6.28, True).cpu()
+        err = (out - T(y)).abs().max().item()
+        print(f"posenc d={x.shape[-1]} max-abs err {err:.3e}")
+        assert err < 2e-6
+        assert torch.equal(out[:, :x.shape[-1]], T(x))
+
+
+def test_gathers(ops):
+    g = load("g2_gathers.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]), bg_std_zero=True)
+    hs = hip_scene(ops, sc)
+    uv = T(g["uv"]).cuda()
+    d = ops.index(hs, ops.INDEX_DEPTH, uv).cpu()
+    s = ops.index(hs, ops.INDEX_DEPTH_STD, uv).cpu()
+    n = ops.index(hs, ops.INDEX_NORMAL, uv).cpu()
+    lat = ops.index(hs, ops.INDEX_LATENT, uv).cpu()
+    assert torch.equal(d, T(g["depth"])), "nearest/border depth taps must be bit-exact"
+    assert torch.equal(s, T(g["std"])), "exponentially padded std taps must be bit-exact"
+    assert torch.equal(n, T(g["normal"])), "nearest/zeros normal taps must be bit-exact"
+    rel = max_norm_rel(lat[:, ::16], g["latent_sub"])
+    print(f"latent bilinear max-norm-rel {rel:.3e}")
+    assert rel < 5e-6          # 4-tap blend, association differs from ATen's
+    assert max_norm_rel(lat, O.index_latent(scene, uv.cpu())) < 5e-6
+
+
+def _sampler_case(K):
+    g = load(f"g3_sampler_K{K}.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    gen = torch.Generator().manual_seed(103)
+    sel = torch.randperm(int(g["W"]) * int(g["H"]), generator=gen)[:512].sort().values
+    rs = T(g["rays"])
+    noises = {}
+    for (KK, G) in [(64, 24), (128, 48)]:
+        noises[KK] = (torch.rand(512, 1000, generator=gen), torch.randn(512, G, generator=gen),
+                      torch.rand(512, KK, generator=gen))
+    assert sha(*noises[K]) == str(g["in_sha"]), "seeded noise not reproducible on this host"
+    return g, sc, scene, rs, noises[K]
+
+
+@pytest.mark.parametrize("K", [64, 128])
+def test_sampler_and_fill(ops, K):
+    g, sc, scene, rs, (nc, ng, nf) = _sampler_case(K)
+    G = int(g["G"])
+    hs = hip_scene(ops, sc)
+    z, zu = ops.sample_depthguided(hs, rs.cuda(), K, 1000, G, 0.05, noise=(nc.cuda(), ng.cuda(), nf.cuda()),
+                                   want_unfilled=True)
+    z, zu = z.cpu(), zu.cpu()
+    ref_u = T(g["z_unfilled"]).sort(-1).values
+    got_u = zu.sort(-1).values
+    ref_z = T(g["z"])
+    # depth-guided picks are candidate depths -> bit-exact; gaussian samples go through a reduction whose
+    # association differs (wave tree vs torch's cascade) -> 3e-6 relative
+    zc = O.sample_coarse(rs, 1000, nc)
+    L, _ = O.point_likelihood(scene, rs, zc)
+    bad, worst = selection_diff(ref_u, got_u, L, zc)
+    exact_rows = (got_u == ref_u).all(-1).sum().item()
+    print(f"K={K}: rays bit-exact {exact_rows}/512; rays with a different pick set: {len(bad)} "
+          f"(largest likelihood involved {worst:.2e}); elements bit-exact {(got_u == ref_u).float().mean().item():.5f}")
+    assert worst < SAT_L, "selection differs on a candidate with a well-defined likelihood"
+    assert len(bad) <= 0.02 * 512
+    assert (z[:, 1:] >= z[:, :-1]).all()
+    good = torch.ones(512, dtype=torch.bool)
+    good[bad] = False
+    closez = torch.isclose(z[good], ref_z[good], rtol=3e-6, atol=1e-7)
+    print(f"K={K}: filled z within 3e-6 on the {int(good.sum())} agreeing rays: {closez.float().mean().item():.6f}")
+    assert closez.all()
+
+
+def test_fill_handmade(ops):
+    g = load("g4_fill.npz")
+    z = ops.fill_uniform(T(g["z_in"]).cuda(), T(g["rays"]).cuda(), T(g["noise"]).cuda()).cpu()
+    assert torch.equal(z, T(g["z_out"]))
+
+
+def test_mlp_forward(ops):
+    g = load("g5_mlp.npz")
+    sc, scene, w, msd, rays = oracle_setup(16, 16, 0)
+    zx = torch.randn(4, 300, 567, generator=torch.Generator().manual_seed(105))
+    y = ops.mlp_forward(hip_mlp(ops, msd), zx.cuda()).cpu()
+    rel = max_norm_rel(y, g["y"])
+    print(f"ResnetFC (4,300,567) max-norm-rel vs reference {rel:.3e}")
+    assert rel < TOL_STAGE
+
+
+def test_pixelnerf_forward(ops):
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    out = ops.field_from_points(hs, hm, T(g["pts"]).cuda(), T(g["dirs"]).cuda()).cpu()
+    rel = max_norm_rel(out, g["out"])
+    print(f"PixelNeRF.forward (512 pts) max-norm-rel vs reference {rel:.3e}")
+    assert rel < TOL_STAGE
+
+
+def test_composite_and_render(ops):
+    g = load("g7_composite.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    assert sha(sc["latent"], sc["depths"], sc["depths_std"], scene.normals, sc["src_extrinsics"],
+               *[v for k, v in sorted(msd.items())]) == str(g["scene_sha"]), "seeded scene not reproducible on this host"
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    r7, z7, field = T(g["rays"]).cuda(), T(g["z"]).cuda(), T(g["field"]).cuda()
+    for wb in (0, 1):
+        wts, rgb, depth = ops.composite(field, z7, r7, bool(wb))
+        for name, got in (("weights", wts), ("rgb", rgb), ("depth", depth)):
+            rel = max_norm_rel(got.cpu(), g[f"{name}_{wb}"])
+            print(f"composite white={wb} {name}: {rel:.3e}")
+            assert rel < TOL_STAGE
+        wts, rgb, depth = ops.render(hs, hm, r7, z7, bool(wb), want_weights=True)
+        for name, got in (("weights", wts), ("rgb", rgb), ("depth", depth)):
+            rel = max_norm_rel(got.cpu(), g[f"{name}_{wb}"])
+            print(f"render    white={wb} {name}: {rel:.3e}")
+            assert rel < TOL
+
+
+def test_render_cfg1_end_to_end(ops):
+    """BASELINE.json configs[0]: 64x64 target, 64 samples/ray, 4 source views, against the reference's output.
+
+    Two statements: (1) with the reference's own sample positions the renderer matches on EVERY ray;
+    (2) with the HIP sampler the image matches on every ray whose sample set agrees with the reference's, and
+    the rays that do not agree are the erf-saturation class of test_sampler_and_fill (a fraction of a percent)."""
+    g = load("g8_render_cfg1.npz")
+    W, H, K, G, n_cand = (int(g[k]) for k in ("W", "H", "K", "G", "n_cand"))
+    sc, scene, w, msd, rays = oracle_setup(W, H, int(g["seed"]))
+    gen = torch.Generator().manual_seed(108)
+    nc = torch.rand(W * H, n_cand, generator=gen)
+    ng = torch.randn(W * H, G, generator=gen)
+    nf = torch.rand(W * H, K, generator=gen)
+    assert sha(nc[:64], ng[:64], nf[:64]) == str(g["in_sha"]), "seeded noise not reproducible on this host"
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    rays = T(g["rays"])
+    rc = rays.cuda()
+    ref_rgb, ref_d, ref_z = T(g["rgb"]), T(g["depth"]), T(g["z"])
+
+    def errs(rgb, depth):
+        e_rgb = (rgb.cpu() - ref_rgb).abs().max(-1).values / ref_rgb.abs().max()
+        e_d = (depth.cpu() - ref_d).abs() / ref_d.abs().max()
+        return e_rgb, e_d
+
+    # (1) reference z -> HIP field + compositor
+    wts, rgb, depth = ops.render(hs, hm, rc, ref_z.cuda(), False, want_weights=True)
+    e_rgb, e_d = errs(rgb, depth)
+    print(f"e2e cfg1, reference z : rgb max-norm-rel {e_rgb.max().item():.3e}, depth {e_d.max().item():.3e}")
+    assert e_rgb.max().item() < TOL and e_d.max().item() < TOL
+    np.testing.assert_allclose(wts.cpu().sum(-1).numpy(), g["weights_sum"], atol=2e-5)
+    # (2) HIP sampler -> HIP field + compositor
+    z = ops.sample_depthguided(hs, rc, K, n_cand, G, 0.05, noise=(nc.cuda(), ng.cuda(), nf.cuda()))
+    same = torch.isclose(z.cpu(), ref_z, rtol=3e-6, atol=1e-7).all(-1)
+    wts, rgb, depth = ops.render(hs, hm, rc, z, False, want_weights=True)
+    e_rgb, e_d = errs(rgb, depth)
+    n_diff = int((~same).sum())
+    print(f"e2e cfg1, HIP sampler : {n_diff}/{W * H} rays with a different sample set; on the others rgb "
+          f"{e_rgb[same].max().item():.3e}, depth {e_d[same].max().item():.3e}; on all rays rgb "
+          f"{e_rgb.max().item():.3e}, depth {e_d.max().item():.3e}")
+    assert n_diff <= 0.005 * W * H
+    assert e_rgb[same].max().item() < TOL and e_d[same].max().item() < TOL
+
+
+def test_ray_batch_split_invariance(ops):
+    """diner.py:85 splits rays into batches; results must not depend on the split (bit-exact)."""
+    sc, scene, w, msd, rays = oracle_setup(32, 32, 3)
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    rc = rays.cuda()
+    gen = torch.Generator().manual_seed(5)
+    noise = (torch.rand(1024, 1000, generator=gen).cuda(), torch.randn(1024, 24, generator=gen).cuda(),
+             torch.rand(1024, 64, generator=gen).cuda())
+    z_all = ops.sample_depthguided(hs, rc, 64, 1000, 24, noise=noise)
+    _, rgb_all, d_all = ops.render(hs, hm, rc, z_all, True)
+    parts = []
+    for a, b in ((0, 100), (100, 611), (611, 1024)):
+        zp = ops.sample_depthguided(hs, rc[a:b], 64, 1000, 24, noise=tuple(n[a:b] for n in noise))
+        assert torch.equal(zp, z_all[a:b])
+        parts.append(ops.render(hs, hm, rc[a:b], zp, True)[1])
+    assert torch.equal(torch.cat(parts), rgb_all)
+
+
+def test_philox_sampler_statistics(ops):
+    """Production noise (in-kernel Philox): z sorted, inside [near, far] for fill samples, reproducible per seed."""
+    sc, scene, w, msd, rays = oracle_setup(32, 32, 3)
+    hs = hip_scene(ops, sc)
+    rc = rays.cuda()
+    z1 = ops.sample_depthguided(hs, rc, 128, 1000, 48, seed=11)
+    z2 = ops.sample_depthguided(hs, rc, 128, 1000, 48, seed=11)
+    z3 = ops.sample_depthguided(hs, rc, 128, 1000, 48, seed=12)
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    assert (z1[:, 1:] >= z1[:, :-1]).all() and torch.isfinite(z1).all()
+    # rays that see no surface are a pure stratification of [near, far]
+    L, Oo = O.point_likelihood(scene, rays, O.sample_coarse(rays, 1000, torch.full((1024, 1000), 0.5)))
+    empty = ~(Oo != 0).any(-1)
+    if empty.any():
+        ze = z1.cpu()[empty]
+        edges = torch.linspace(sc["znear"], sc["zfar"], 129)
+        assert (ze >= edges[:-1] - 1e-5).all() and (ze <= edges[1:] + 1e-5).all()
