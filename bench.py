@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py -- rendered rays/s of the MI355X-native DINER renderer (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 4-source-view scene, 400x300 source/target images,
+128 samples/ray (48 gaussian, 1000 depth candidates), fp32, random-init MLP of the trained DINER
+configuration, seeded N(0,1) latent.  A "step" = one full pass of the hot path (depth-guided sampling ->
+projection / gather / encoding / MLP -> compositing) over one 400x300 target frame = 120,000 rays per GPU,
+followed by the gather of the rendered (rgb, depth) tiles to rank 0.  Inputs are resident in HBM before the
+timed region.  With N GPUs every rank renders its own target view (weak scaling: N frames per step).
+
+The JSON line also carries
+  roofline      k_field_pre (per-view MLP, ~90 % of the FLOPs): algorithmic FLOP / HIP-event duration vs the
+                fp32 MFMA peak of MI355X (157.3 TFLOP/s)
+  cpu_baseline  the CPU oracle (torch restatement of the reference, pinned bit-exact against it) timed on
+                the host cores of the same box on a bounded ray sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=400)
+    ap.add_argument("--height", type=int, default=300)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--candidates", type=int, default=1000)
+    ap.add_argument("--cpu-rays", type=int, default=-1, help="rays of the CPU baseline sample (0 disables; -1 auto)")
+    ap.add_argument("--ray-batch", type=int, default=8192, help="rays per launch group (bounds the workspace)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+
+    from diner_amd import ops
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict, look_at_extrinsics
+    from src.util.depth2normal import depth2normal
+    from src.util.cam_geometry import gen_rays
+
+    W, H, K = args.width, args.height, args.samples
+    G = int(15 * K / 40)                           # create_prediction_folder.py:44-47
+    n_cand = args.candidates
+
+    # ---- scene + weights, resident in HBM -----------------------------------------------------------
+    sc = make_scene(W, H, seed=0)
+    normals = depth2normal(sc["depths"], sc["src_intrinsics"])
+    Kin = sc["src_intrinsics"]
+    scene = ops.HipScene(sc["latent"].to(dev), sc["depths"].to(dev), sc["depths_std"].to(dev), normals.to(dev),
+                         sc["src_extrinsics"], Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"],
+                         sc["feature_padding"])
+    msd = make_mlp_state_dict()
+    mlp = ops.HipMlp({k: v.to(dev) for k, v in msd.items()})
+    # every rank renders its own target view of the same scene
+    tgt = look_at_extrinsics((0.03 + 0.04 * rank, -0.02, -1.0))
+    rays = gen_rays(tgt[None].to(dev), sc["target_intrinsics"][None].to(dev), W, H,
+                    torch.tensor([sc["znear"]], device=dev), torch.tensor([sc["zfar"]], device=dev)).view(-1, 8)
+    rays = rays.contiguous()
+    NR = rays.shape[0]
+    out = torch.empty(NR, 4, device=dev)           # packed (rgb, depth) tile of this rank
+    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step(seed):
+        for r0 in range(0, NR, args.ray_batch):
+            r = rays[r0:r0 + args.ray_batch]
+            z = ops.sample_depthguided(scene, r, K, n_cand, G, 0.05, noise=None, seed=seed * 1000003 + r0)
+            _, rgb, depth = ops.render(scene, mlp, r, z, white_bkgd=False, want_weights=False)
+            out[r0:r0 + args.ray_batch, :3] = rgb
+            out[r0:r0 + args.ray_batch, 3] = depth
+        if world > 1:
+            dist.gather(out, gathered, dst=0)       # one RCCL gather of the rendered tiles per frame
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    ops.profile_enable(True)
+    ops.profile_collect()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_collect()
+    ops.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all(), "non-finite render output"
+
+    total_rays = NR * args.steps * world
+    rays_per_s = total_rays / elapsed
+    # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------------------
+    pre_s = prof["pre_ms"] * 1e-3
+    flop_pre = prof["points"] * ops.FLOP_PRE_PER_POINT
+    achieved = flop_pre / pre_s / 1e12 if pre_s > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "k_field_pre", "achieved": round(achieved, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None, "launches": prof["launches"],
+                "avg_launch_ms": round(prof["pre_ms"] / max(prof["launches"], 1), 3),
+                "post_kernel_ms_total": round(prof["post_ms"], 2), "pre_kernel_ms_total": round(prof["pre_ms"], 2)}
+
+    # ---- CPU baseline: the oracle on the host cores of this box (rank 0, N = 1 only) --------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_rays != 0:
+        from oracle import diner_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        n_cpu = args.cpu_rays if args.cpu_rays > 0 else 256
+        oscene = O.Scene(latent=sc["latent"], depths=sc["depths"], depths_std=sc["depths_std"], normals=normals,
+                         poses=sc["src_extrinsics"], focal=Kin[:, [0, 1], [0, 1]], c=Kin[:, :2, -1],
+                         image_shape=sc["image_shape"], feature_padding=sc["feature_padding"])
+        ow = O.MLPWeights.from_state_dict(msd)
+        idx = torch.linspace(0, NR - 1, n_cpu).long()           # spread over the frame
+        rs = rays[idx].cpu().contiguous()
+        g = torch.Generator().manual_seed(0)
+        noise = (torch.rand(n_cpu, n_cand, generator=g), torch.randn(n_cpu, G, generator=g),
+                 torch.rand(n_cpu, K, generator=g))
+
+        def cpu_once(n):
+            t = time.perf_counter()
+            with torch.no_grad():
+                O.render(oscene, ow, rs[:n], K, n_cand, G, False, noise[0][:n], noise[1][:n], noise[2][:n])
+            return time.perf_counter() - t
+
+        cpu_once(min(32, n_cpu))                                 # warm-up (thread pool, MKL)
+        t1 = cpu_once(n_cpu)
+        # scale the sample towards ~10-20 s of CPU work
+        if t1 < 5.0 and args.cpu_rays < 0:
+            n2 = min(NR, int(n_cpu * 12.0 / max(t1, 1e-3)))
+            idx = torch.linspace(0, NR - 1, n2).long()
+            rs = rays[idx].cpu().contiguous()
+            noise = (torch.rand(n2, n_cand, generator=g), torch.randn(n2, G, generator=g), torch.rand(n2, K, generator=g))
+            n_cpu, t1 = n2, cpu_once(n2)
+        cpu = {"value": round(n_cpu / t1, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n_cpu} rays spread over the same {W}x{H} frame, {K} samples/ray, torch CPU oracle "
+                         f"(restatement of the reference, pinned bit-exact), {t1:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "rendered rays/sec (128 samples/ray, 4 src views)", "value": round(rays_per_s, 1),
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: synthetic 4-view scene, {W}x{H} target = {NR} rays per GPU per "
+                                   f"step, {K} samples/ray ({G} gaussian, {n_cand} candidates), fp32 MFMA MLP "
+                                   f"(d_hidden 512, 5 blocks), random-init weights, in-kernel Philox noise",
+                       "rays_per_step_per_gpu": NR, "samples_per_ray": K, "src_views": 4,
+                       "parallelism": f"ray-shard x{world}, RCCL gather of (rgb,depth) tiles"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(rays_per_s / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,9 @@ SIGNATURES = {
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_posenc_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                    C.c_void_p]),
+    "diner_profile_enable": (C.c_int, [C.c_int]),
+    "diner_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong),
+                                        C.POINTER(C.c_longlong)]),
     "diner_index_f32": (C.c_int, [C.POINTER(DinerScene), C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
 }
 

@@ -24,6 +24,7 @@
 //  * the view-mean boundary (resnetfc.py:148-151) splits the network into two persistent kernels;
 //    the hand-over is 8 KB/point of pre-mean activations stored in accumulator layout (coalesced 1 KB
 //    wave stores), 6 % of the gather traffic.
+#include <vector>
 #include "common.hpp"
 
 namespace diner {
@@ -465,6 +466,14 @@ static int num_cus() {
   return g_num_cus;
 }
 
+// ---- optional per-kernel timing (HIP events on the launch stream), used by bench.py for the roofline ----
+struct KernelTimer {
+  bool enabled = false;
+  std::vector<hipEvent_t> ev;      // triples: before pre, between pre and post, after post
+  std::vector<long long> points;
+};
+static KernelTimer g_timer;
+
 static size_t xpre_bytes(long long P, int nv) {
   const long long n_t16 = (P + kPtsPerWave - 1) / kPtsPerWave;
   return (size_t)n_t16 * nv * kTiles * 64 * sizeof(f32x4);
@@ -492,13 +501,28 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     sc = &dummy;
   }
   const int grid_pre = (int)(n_t16 < cus ? n_t16 : cus);
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (g_timer.enabled) {
+    DINER_HIP_OK(hipEventCreate(&e0));
+    DINER_HIP_OK(hipEventCreate(&e1));
+    DINER_HIP_OK(hipEventCreate(&e2));
+    DINER_HIP_OK(hipEventRecord(e0, stream));
+  }
   hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), lds_bytes, stream, *sc, fa);
   DINER_LAUNCH_OK();
+  if (g_timer.enabled) DINER_HIP_OK(hipEventRecord(e1, stream));
   PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw};
   const long long n_tiles = (n_t16 + 3) / 4;
   const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
   hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), lds_bytes, stream, pa);
   DINER_LAUNCH_OK();
+  if (g_timer.enabled) {
+    DINER_HIP_OK(hipEventRecord(e2, stream));
+    g_timer.ev.push_back(e0);
+    g_timer.ev.push_back(e1);
+    g_timer.ev.push_back(e2);
+    g_timer.points.push_back(fa.P);
+  }
   return 0;
 }
 
@@ -567,6 +591,35 @@ extern "C" int diner_mlp_destroy(DinerMlp* m) {
   hipFree(m->impl.b_pre);
   hipFree(m->impl.b_post);
   delete m;
+  return 0;
+}
+
+extern "C" int diner_profile_enable(int enable) {
+  g_timer.enabled = enable != 0;
+  return 0;
+}
+
+// Sums the recorded kernel durations since the last call (waits for the recorded events), then clears them.
+extern "C" int diner_profile_collect(double* pre_ms, double* post_ms, long long* launches, long long* points) {
+  double a = 0.0, b = 0.0;
+  long long pts = 0;
+  const size_t n = g_timer.points.size();
+  for (size_t i = 0; i < n; ++i) {
+    float t0 = 0.f, t1 = 0.f;
+    DINER_HIP_OK(hipEventSynchronize(g_timer.ev[3 * i + 2]));
+    DINER_HIP_OK(hipEventElapsedTime(&t0, g_timer.ev[3 * i], g_timer.ev[3 * i + 1]));
+    DINER_HIP_OK(hipEventElapsedTime(&t1, g_timer.ev[3 * i + 1], g_timer.ev[3 * i + 2]));
+    a += t0;
+    b += t1;
+    pts += g_timer.points[i];
+    for (int k = 0; k < 3; ++k) hipEventDestroy(g_timer.ev[3 * i + k]);
+  }
+  g_timer.ev.clear();
+  g_timer.points.clear();
+  if (pre_ms) *pre_ms = a;
+  if (post_ms) *post_ms = b;
+  if (launches) *launches = (long long)n;
+  if (points) *points = pts;
   return 0;
 }
 

@@ -303,3 +303,20 @@ def index(scene: HipScene, mode, uv):
     with torch.cuda.device(uv.device):
         _lib.check(lib.diner_index_f32(scene.ref, int(mode), _ptr(uv), N, _ptr(out), _stream()))
     return out
+
+
+# FLOPs of the two field kernels per sample point: NV views x (lin_in + 3 x (lin_z, fc_0, fc_1))
+# before the view mean, 2 x (fc_0, fc_1) + lin_out after it.
+FLOP_PRE_PER_POINT = 2 * 4 * (55 * 512 + 9 * 512 * 512)
+FLOP_POST_PER_POINT = 2 * (4 * 512 * 512 + 512 * 4)
+
+
+def profile_enable(flag=True):
+    _lib.check(lib.diner_profile_enable(int(bool(flag))))
+
+
+def profile_collect():
+    """-> dict(pre_ms, post_ms, launches, points): summed HIP-event durations of k_field_pre / k_field_post."""
+    a, b, n, p = C.c_double(), C.c_double(), C.c_longlong(), C.c_longlong()
+    _lib.check(lib.diner_profile_collect(C.byref(a), C.byref(b), C.byref(n), C.byref(p)))
+    return dict(pre_ms=a.value, post_ms=b.value, launches=n.value, points=p.value)

@@ -130,6 +130,13 @@ int diner_posenc_f32(const float* x, long long N, int d_in, int num_freqs, float
  *   1 depth (nearest/border), 2 depth_std (nearest on the 100px exponential padding, zeros), 3 normal. */
 int diner_index_f32(const DinerScene* scene, int mode, const float* uv, long long N, float* out, void* stream);
 
+/* ---- measurement aid (bench.py): per-kernel durations of the two field kernels ------------------
+ * With profiling enabled every field call brackets k_field_pre / k_field_post with HIP events on the
+ * launch stream; diner_profile_collect waits for them, returns the summed durations (ms), the number
+ * of launches of each kernel and the points they processed, and resets the log. */
+int diner_profile_enable(int enable);
+int diner_profile_collect(double* pre_ms, double* post_ms, long long* launches, long long* points);
+
 #ifdef __cplusplus
 }
 #endif
