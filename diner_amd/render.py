@@ -1,0 +1,63 @@
+"""Image harness: the MI355X counterpart of DINER.predict_imgs_from_batch (reference src/models/diner.py:72-97).
+
+The reference renders one target image by splitting its H*W rays into batches of `ray_batch_size` and calling
+`renderer.forward` on each (diner.py:85-92).  Rays are independent, so here the row-major ray list is additionally
+sharded into contiguous ranges across the GPUs of a node (one process per GPU, torch.distributed; backend "nccl" is
+RCCL on ROCm), each rank renders its range with the HIP kernels, and ONE gather of the packed (rgb, depth) tiles
+(16 B/ray) brings the image to rank 0.  There is no other collective on the data path: scene state and MLP weights
+are replicated (every rank runs `encode` itself).
+"""
+import torch
+
+from src.util.cam_geometry import gen_rays
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced partition of range(n): rank r gets [lo, hi)."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def gather_tiles(local, n_total, rank, world, group=None):
+    """Gather per-rank (n_r, C) tiles (contiguous ray ranges, see shard_range) to rank 0 -> (n_total, C) or None.
+
+    Uses equal-size padded buffers so that a single gather collective suffices."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    per = (n_total + world - 1) // world
+    buf = local
+    if local.shape[0] != per:
+        buf = torch.zeros(per, local.shape[1], device=local.device, dtype=local.dtype)
+        buf[:local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf.contiguous(), out, dst=0, group=group)
+    if rank != 0:
+        return None
+    return torch.cat(out, dim=0)[:n_total]
+
+
+@torch.no_grad()
+def predict_image(nerf, renderer, target_extrinsics, target_intrinsics, W, H, znear, zfar, ray_batch_size=8192,
+                  rank=0, world=1, group=None):
+    """Render the (SB) target views described by target_extrinsics (SB,4,4) / target_intrinsics (SB,3,3) of the
+    scene last passed to nerf.encode().  Returns rgb (SB,3,H,W), depth (SB,1,H,W) on rank 0 (None elsewhere).
+    Same ray order (row-major pixels, centres at +0.5) and output layout as diner.py:79-92."""
+    SB = target_extrinsics.shape[0]
+    dev = target_extrinsics.device
+    znear = torch.as_tensor(znear, device=dev, dtype=torch.float32).expand(SB)
+    zfar = torch.as_tensor(zfar, device=dev, dtype=torch.float32).expand(SB)
+    rays = gen_rays(target_extrinsics, target_intrinsics, W, H, znear, zfar).view(SB, H * W, 8)
+    lo, hi = shard_range(H * W, rank, world)
+    tiles = []
+    for r0 in range(lo, hi, ray_batch_size):
+        rb = rays[:, r0:min(hi, r0 + ray_batch_size)].contiguous()
+        out = renderer.forward(model=nerf, rays=rb)
+        tiles.append(torch.cat((out.fine.rgb, out.fine.depth.unsqueeze(-1)), dim=-1))      # (SB, b, 4)
+    local = torch.cat(tiles, dim=1) if tiles else torch.zeros(SB, 0, 4, device=dev)
+    full = gather_tiles(local.permute(1, 0, 2).reshape(hi - lo, SB * 4), H * W, rank, world, group)
+    if full is None:
+        return None, None
+    full = full.view(H, W, SB, 4).permute(2, 3, 0, 1)                                       # (SB,4,H,W)
+    return full[:, :3].contiguous(), full[:, 3:4].contiguous()

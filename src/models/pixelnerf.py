@@ -1,0 +1,95 @@
+"""PixelNeRF -- drop-in for reference src/models/pixelnerf.py (:12-145): same constructor (built through the
+import_obj plugin seam), attributes (`poses`, `focal`, `c`, `image_shape`, `encoder`, `mlp_fine`, `poscode`,
+`depthcode`, `d_in`, `d_latent`, `d_out`) and state-dict keys.
+
+`forward(xyz, viewdirs)` evaluates the radiance field with the fused HIP kernels (projection + positional encoding +
+bilinear feature gather + ResnetFC on fp32 MFMA, diner_amd/csrc/mlp.hip) through diner_field_from_points_f32.
+`encode` is per-image setup and stays in torch ops, as in the reference."""
+import torch
+
+from diner_amd import ops
+from src.models.positional_encoding import PositionalEncoding
+from src.util.depth2normal import depth2normal
+from src.util.import_helper import import_obj
+
+_MEAN = (0.485, 0.456, 0.406)
+_STD = (0.229, 0.224, 0.225)
+
+
+class _Normalize(torch.nn.Module):
+    """torchvision.transforms.Normalize for (..., 3, H, W) tensors (pixelnerf.py:32-33)."""
+
+    def __init__(self, mean, std):
+        super().__init__()
+        self.mean, self.std = tuple(mean), tuple(std)
+
+    def forward(self, x):
+        mean = torch.as_tensor(self.mean, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+        std = torch.as_tensor(self.std, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+        return (x - mean) / std
+
+
+class PixelNeRF(torch.nn.Module):
+    def __init__(self, poscode_conf, encoder_conf, mlp_fine_conf):
+        super().__init__()
+        self.poscode = PositionalEncoding(**poscode_conf.kwargs, d_in=3)
+        self.depthcode = PositionalEncoding(**poscode_conf.kwargs, d_in=1)
+        self.encoder = import_obj(encoder_conf.module)(**encoder_conf.kwargs)
+        self.d_in = self.poscode.d_out + self.depthcode.d_out + 3
+        self.d_latent = self.encoder.latent_size
+        self.d_out = 4
+        self.mlp_fine = import_obj(mlp_fine_conf.module)(**mlp_fine_conf.kwargs, d_latent=self.d_latent,
+                                                         d_in=self.d_in, d_out=self.d_out)
+        self.register_buffer("poses", torch.empty(1, 3, 4), persistent=False)
+        self.register_buffer("image_shape", torch.empty(2), persistent=False)
+        self.register_buffer("focal", torch.empty(1, 2), persistent=False)
+        self.register_buffer("c", torch.empty(1, 2), persistent=False)
+        self.normalize_rgb = _Normalize(_MEAN, _STD)
+        self._scenes = {}
+
+    def encode(self, images, depths, depths_std, extrinsics, intrinsics):
+        """images (SB,NV,3,H,W), depths / depths_std (SB,NV,1,H,W), extrinsics (SB,NV,4,4), intrinsics (SB,NV,3,3):
+        builds the feature maps and stores the source cameras (:35-53).  Call before forward()."""
+        images = self.normalize_rgb(images)
+        normals = depth2normal(depths.flatten(end_dim=1), intrinsics.flatten(end_dim=1)).reshape_as(images)
+        self.encoder(images, depths, depths_std, normals)
+        self.poses = extrinsics
+        self.c = intrinsics[:, :, :2, -1]
+        self.focal = intrinsics[:, :, torch.tensor([0, 1]), torch.tensor([0, 1])]
+        self.image_shape[0] = images.shape[-1]      # width
+        self.image_shape[1] = images.shape[-2]      # height
+        self._scenes = {}
+
+    # ---- HIP state ------------------------------------------------------------------------------------------------
+    def hip_scene(self, sb):
+        """HipScene of object `sb` (channels-last latent copy etc.), rebuilt whenever any source tensor changed."""
+        enc = self.encoder
+        srcs = (enc.latent, enc.depths, enc.depths_std, enc.normals, self.poses, self.focal, self.c, self.image_shape)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in srcs)
+        hit = self._scenes.get(sb)
+        if hit is None or hit[0] != key:
+            scene = ops.HipScene(enc.latent[sb], enc.depths[sb], enc.depths_std[sb], enc.normals[sb], self.poses[sb],
+                                 self.focal[sb], self.c[sb], self.image_shape, enc.feature_padding)
+            hit = (key, scene)
+            self._scenes[sb] = hit
+        return hit[1]
+
+    def hip_mlp(self):
+        return self.mlp_fine.hip_mlp()
+
+    def _check_poscode(self):
+        pc = self.poscode
+        if pc.num_freqs != 6 or abs(pc.freq_factor - 6.28) > 1e-12 or not pc.include_input:
+            raise NotImplementedError("diner_amd: the fused field kernel is built for poscode num_freqs=6, "
+                                      "freq_factor=6.28, include_input=True (every shipped DINER config)")
+
+    def forward(self, xyz, viewdirs):
+        """(r, g, b, sigma) at world-space points: xyz (SB,B,3), viewdirs (SB,B,3) -> (SB,B,4) (:55-145)."""
+        SB, B, _ = xyz.shape
+        assert SB == self.encoder.nobjects
+        if torch.is_grad_enabled() and (xyz.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("diner_amd: the fused HIP radiance field has no backward yet (DESIGN.md, row "
+                                      "f1); run inference under torch.no_grad()")
+        self._check_poscode()
+        mlp = self.hip_mlp()
+        return torch.stack([ops.field_from_points(self.hip_scene(sb), mlp, xyz[sb], viewdirs[sb]) for sb in range(SB)])

@@ -1,0 +1,94 @@
+"""ResnetFC -- drop-in for reference src/models/resnetfc.py (ResnetBlockFC :18-69, ResnetFC :72-159): same
+constructor arguments, parameter names / shapes / initialisation (state-dict compatible with reference
+checkpoints); forward runs the fused MFMA kernels of diner_amd/csrc/mlp.hip through diner_mlp_forward_f32.
+
+The packed-weights handle is cached and keyed on every parameter's (data_ptr, _version), so in-place optimiser
+updates or load_state_dict() invalidate it."""
+import torch
+from torch import nn
+
+from diner_amd import ops
+
+
+class ResnetBlockFC(nn.Module):
+    """fc_1(act(fc_0(act(x)))) + shortcut(x); parameters only -- the arithmetic lives in the HIP kernel."""
+
+    def __init__(self, size_in, size_out=None, size_h=None, beta=0.0):
+        super().__init__()
+        size_out = size_in if size_out is None else size_out
+        size_h = min(size_in, size_out) if size_h is None else size_h
+        self.size_in, self.size_h, self.size_out = size_in, size_h, size_out
+        self.fc_0 = nn.Linear(size_in, size_h)
+        self.fc_1 = nn.Linear(size_h, size_out)
+        nn.init.constant_(self.fc_0.bias, 0.0)
+        nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
+        nn.init.constant_(self.fc_1.bias, 0.0)
+        nn.init.zeros_(self.fc_1.weight)
+        self.activation = nn.Softplus(beta=beta) if beta > 0 else nn.ReLU()
+        if size_in == size_out:
+            self.shortcut = None
+        else:
+            self.shortcut = nn.Linear(size_in, size_out, bias=False)
+            nn.init.kaiming_normal_(self.shortcut.weight, a=0, mode="fan_in")
+
+
+class ResnetFC(nn.Module):
+    def __init__(self, d_in, d_out=4, n_blocks=5, d_latent=0, d_hidden=128, beta=0.0, combine_layer=1000,
+                 combine_type="average"):
+        super().__init__()
+        if d_in > 0:
+            self.lin_in = nn.Linear(d_in, d_hidden)
+            nn.init.constant_(self.lin_in.bias, 0.0)
+            nn.init.kaiming_normal_(self.lin_in.weight, a=0, mode="fan_in")
+        self.lin_out = nn.Linear(d_hidden, d_out)
+        nn.init.constant_(self.lin_out.bias, 0.0)
+        nn.init.kaiming_normal_(self.lin_out.weight, a=0, mode="fan_in")
+        self.n_blocks, self.d_latent, self.d_in, self.d_out, self.d_hidden = n_blocks, d_latent, d_in, d_out, d_hidden
+        self.combine_layer, self.combine_type, self.beta = combine_layer, combine_type, beta
+        self.blocks = nn.ModuleList([ResnetBlockFC(d_hidden, beta=beta) for _ in range(n_blocks)])
+        if d_latent != 0:
+            n_lin_z = min(combine_layer, n_blocks)
+            self.lin_z = nn.ModuleList([nn.Linear(d_latent, d_hidden) for _ in range(n_lin_z)])
+            for i in range(n_lin_z):
+                nn.init.constant_(self.lin_z[i].bias, 0.0)
+                nn.init.kaiming_normal_(self.lin_z[i].weight, a=0, mode="fan_in")
+        self.activation = nn.Softplus(beta=beta) if beta > 0 else nn.ReLU()
+        self._hip = None
+        self._hip_key = None
+
+    # ---- packed weights -----------------------------------------------------------------------------------
+    def _check_supported(self):
+        if self.beta > 0 or self.combine_type != "average":
+            raise NotImplementedError("diner_amd: the fused MLP implements ReLU activations and average view fusion "
+                                      "(the configuration of every shipped DINER config)")
+
+    def hip_mlp(self):
+        """HipMlp handle for the current parameter values (re-packed when any parameter changed)."""
+        self._check_supported()
+        sd = {k: v for k, v in self.state_dict().items()}
+        key = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items()))
+        if self._hip is None or key != self._hip_key:
+            self._hip = ops.HipMlp(sd, combine_layer=self.combine_layer, d_latent=self.d_latent)
+            self._hip_key = key
+        return self._hip
+
+    def forward(self, zx, combine_dim):
+        """zx (SB, NV, B, d_latent + d_in) with combine_dim=1 (the reference's only call, pixelnerf.py:131-134),
+        or (NV, B, d_latent + d_in) with combine_dim=0  ->  (SB, B, d_out) / (B, d_out)."""
+        assert zx.size(-1) == self.d_latent + self.d_in
+        if torch.is_grad_enabled() and (zx.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("diner_amd: the fused HIP MLP has no backward yet (DESIGN.md, row f1); "
+                                      "run inference under torch.no_grad()")
+        mlp = self.hip_mlp()
+        if zx.dim() == 4 and combine_dim in (1, -3):
+            return torch.stack([ops.mlp_forward(mlp, zx[i]) for i in range(zx.shape[0])])
+        if zx.dim() == 3 and combine_dim in (0, -3):
+            return ops.mlp_forward(mlp, zx)
+        raise NotImplementedError(f"diner_amd: ResnetFC.forward supports (SB,NV,B,C)/combine_dim=1 and "
+                                  f"(NV,B,C)/combine_dim=0, got shape {tuple(zx.shape)}, combine_dim={combine_dim}")
+
+    @classmethod
+    def from_conf(cls, conf, d_in, **kwargs):
+        return cls(d_in, n_blocks=conf.get_int("n_blocks", 5), d_hidden=conf.get_int("d_hidden", 128),
+                   beta=conf.get_float("beta", 0.0), combine_layer=conf.get_int("combine_layer", 1000),
+                   combine_type=conf.get_string("combine_type", "average"), **kwargs)
