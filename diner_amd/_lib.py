@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "libdiner_hip.so")
 
 
 class DinerScene(C.Structure):
-    _fields_ = [("latent_cl", C.c_void_p), ("depth", C.c_void_p), ("depth_std", C.c_void_p),
+    _fields_ = [("latent_cl", C.c_void_p), ("latent_proj", C.c_void_p), ("depth", C.c_void_p), ("depth_std", C.c_void_p),
                 ("normals", C.c_void_p), ("poses", C.c_void_p), ("focal", C.c_void_p), ("c", C.c_void_p),
                 ("std_pad_scale", C.c_void_p),
                 ("img_w", C.c_float), ("img_h", C.c_float), ("feature_padding", C.c_float),
@@ -36,6 +36,8 @@ SIGNATURES = {
                                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_fill_uniform_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.c_void_p]),
+    "diner_scene_proj_bytes": (C.c_size_t, [C.POINTER(DinerScene)]),
+    "diner_scene_prepare_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "diner_field_from_rays_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

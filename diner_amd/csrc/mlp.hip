@@ -21,9 +21,15 @@
 //    the host side of the C ABI into the exact ds_read_b128 fragment order (conflict-free, lane-linear).
 //  * the 512-channel latent is gathered straight into B-operand registers from the channels-last map:
 //    each lane reads 16 B (4 channels) per tap, the 4 lanes of a point cover one 64 B segment.
+//  * lin_z hoist: `lin_z[b]` is linear and bilinear / border interpolation weights sum to one, so
+//    lin_z[b](interp(F)) == interp(lin_z[b](F)) (+bias).  The three 512->512 projections of the latent
+//    (30 % of the network's FLOPs, resnetfc.py:153-155) are applied ONCE per feature-map pixel by
+//    k_hoist_linz when a scene is prepared (0.36 TFLOP at 400x300 vs 326 TFLOP per rendered frame); the
+//    per-sample work becomes a gather-add of the projected maps, fused into the B-operand production of
+//    the following fc_0.  Results differ from the reference only by fp32 rounding (parity tests).
 //  * the view-mean boundary (resnetfc.py:148-151) splits the network into two persistent kernels;
 //    the hand-over is 8 KB/point of pre-mean activations stored in accumulator layout (coalesced 1 KB
-//    wave stores), 6 % of the gather traffic.
+//    wave stores).
 #include <vector>
 #include "common.hpp"
 
@@ -38,14 +44,17 @@ constexpr int kDInPad = 64;
 constexpr int kTiles = kHidden / 16;          // 32 accumulator tiles of 16 features
 constexpr int kStageFloats = 8192;            // 32 KB: 128 output features x 64 k
 constexpr int kStagesPerLayer = 32;           // 8 k-chunks x 4 feature groups
-constexpr int kPreStages = 4 + 3 * 3 * kStagesPerLayer;    // lin_in + 3 x (lin_z, fc_0, fc_1) = 292
+constexpr int kHoistStages = 3 * kStagesPerLayer;          // lin_z[0..2]                      =  96
+constexpr int kPreStages = 4 + 3 * 2 * kStagesPerLayer;    // lin_in + 3 x (fc_0, fc_1)        = 196
 constexpr int kPostStages = 2 * 2 * kStagesPerLayer + 1;   // 2 x (fc_0, fc_1) + lin_out      = 129
 constexpr int kPtsPerWave = 16;
 
 struct DinerMlpImpl {
-  float* w_pre;    // kPreStages  x 8192 floats, stage-tile order
-  float* w_post;   // kPostStages x 8192 floats
-  float* b_pre;    // biases: lin_in, then per block b<3: lin_z, fc_0, fc_1  -> 10 x 512
+  float* w_hoist;  // kHoistStages x 8192 floats, stage-tile order: lin_z[0], lin_z[1], lin_z[2]
+  float* w_pre;    // kPreStages   x 8192 floats: lin_in, then per block b<3: fc_0, fc_1
+  float* w_post;   // kPostStages  x 8192 floats: per block b=3,4: fc_0, fc_1, then lin_out
+  float* b_hoist;  // lin_z biases, 3 x 512
+  float* b_pre;    // lin_in, then per block b<3: fc_0, fc_1  -> 7 x 512
   float* b_post;   // per block b=3,4: fc_0, fc_1 -> 4 x 512, then lin_out (4, padded to 16)
 };
 
@@ -172,41 +181,65 @@ __device__ __forceinline__ void layer_from_acc(WeightStream& ws, const f32x4 (&s
 #undef DINER_KC
 }
 
-// bilinear taps of one (point, view) on the channels-last latent map
+// bilinear taps of one (point, view): float offsets into a channels-last (.., 512) map + blend weights
 struct Taps {
-  const float* p[4];
+  size_t off[4];
   float w[4];
 };
 
-__device__ __forceinline__ void taps_load(const Taps& t, int kc, int q, f32x4 (&raw)[16]) {
+__device__ __forceinline__ void taps_load(const float* __restrict__ map, const Taps& t, int kc, int q,
+                                          f32x4 (&raw)[16]) {
 #pragma unroll
   for (int tap = 0; tap < 4; ++tap)
 #pragma unroll
     for (int ml = 0; ml < 4; ++ml)
-      raw[tap * 4 + ml] = *reinterpret_cast<const f32x4*>(t.p[tap] + 64 * kc + 16 * ml + 4 * q);
-}
-__device__ __forceinline__ void taps_blend(const Taps& t, const f32x4 (&raw)[16], float (&bop)[16]) {
-#pragma unroll
-  for (int ml = 0; ml < 4; ++ml) {
-    const f32x4 v = raw[0 + ml] * t.w[0] + raw[4 + ml] * t.w[1] + raw[8 + ml] * t.w[2] + raw[12 + ml] * t.w[3];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bop[4 * ml + r] = v[r];
-  }
+      raw[tap * 4 + ml] = *reinterpret_cast<const f32x4*>(map + t.off[tap] + 64 * kc + 16 * ml + 4 * q);
 }
 
-// x += Wz . latent   (latent gathered on the fly, next k-chunk's taps in flight under the current MFMAs)
-__device__ __forceinline__ void layer_from_latent(WeightStream& ws, const Taps& t, int q, f32x4 (&dst)[kTiles]) {
+// net = fc_0(relu(x + interp(lin_z[b](latent)))) with the gather-add of the hoisted projection fused into the
+// B-operand production: for each 64-feature chunk, blend the 4 taps of the projected map, add into the
+// residual stream x (kept), relu -> B operands.  The next chunk's taps are in flight under the MFMAs.
+__device__ __forceinline__ void layer_fc0_hoisted(WeightStream& ws, const float* __restrict__ tz, const Taps& t, int q,
+                                                  f32x4 (&x)[kTiles], f32x4 (&net)[kTiles]) {
   f32x4 raw[16];
-  taps_load(t, 0, q, raw);
-#define DINER_KC(KC_)                                       \
-  {                                                         \
-    float bop[16];                                          \
-    taps_blend(t, raw, bop);                                \
-    if (KC_ < 7) taps_load(t, KC_ + 1, q, raw);             \
-    stage_mma<0>(ws.acquire(), ws.lane, bop, dst);          \
-    stage_mma<1>(ws.acquire(), ws.lane, bop, dst);          \
-    stage_mma<2>(ws.acquire(), ws.lane, bop, dst);          \
-    stage_mma<3>(ws.acquire(), ws.lane, bop, dst);          \
+  taps_load(tz, t, 0, q, raw);
+#define DINER_KC(KC_)                                                                                         \
+  {                                                                                                           \
+    float bop[16];                                                                                            \
+    _Pragma("unroll") for (int ml = 0; ml < 4; ++ml) {                                                        \
+      const f32x4 v = raw[0 + ml] * t.w[0] + raw[4 + ml] * t.w[1] + raw[8 + ml] * t.w[2] + raw[12 + ml] * t.w[3]; \
+      x[4 * KC_ + ml] += v;                                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) bop[4 * ml + r] = fmaxf(x[4 * KC_ + ml][r], 0.0f);        \
+    }                                                                                                         \
+    if (KC_ < 7) taps_load(tz, t, KC_ + 1, q, raw);                                                           \
+    stage_mma<0>(ws.acquire(), ws.lane, bop, net);                                                            \
+    stage_mma<1>(ws.acquire(), ws.lane, bop, net);                                                            \
+    stage_mma<2>(ws.acquire(), ws.lane, bop, net);                                                            \
+    stage_mma<3>(ws.acquire(), ws.lane, bop, net);                                                            \
+  }
+  DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
+#undef DINER_KC
+}
+
+// dst += W . row   for an explicit 512-float row per lane-column (the hoist kernel): B operands straight from memory
+__device__ __forceinline__ void layer_from_rows(WeightStream& ws, const float* __restrict__ row, int q,
+                                                f32x4 (&dst)[kTiles]) {
+  f32x4 raw[4];
+#pragma unroll
+  for (int ml = 0; ml < 4; ++ml) raw[ml] = *reinterpret_cast<const f32x4*>(row + 16 * ml + 4 * q);
+#define DINER_KC(KC_)                                                                                         \
+  {                                                                                                           \
+    float bop[16];                                                                                            \
+    _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                          \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) bop[4 * ml + r] = raw[ml][r];                             \
+    if (KC_ < 7) {                                                                                            \
+      _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                        \
+        raw[ml] = *reinterpret_cast<const f32x4*>(row + 64 * (KC_ + 1) + 16 * ml + 4 * q);                    \
+    }                                                                                                         \
+    stage_mma<0>(ws.acquire(), ws.lane, bop, dst);                                                            \
+    stage_mma<1>(ws.acquire(), ws.lane, bop, dst);                                                            \
+    stage_mma<2>(ws.acquire(), ws.lane, bop, dst);                                                            \
+    stage_mma<3>(ws.acquire(), ws.lane, bop, dst);                                                            \
   }
   DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
 #undef DINER_KC
@@ -242,8 +275,9 @@ struct FieldArgs {
   const float* z;
   const float* xyz;
   const float* viewdirs;
-  const float* direct_latent;   // (NV*P, 512)  rows used as-is (ResnetFC.forward on an explicit matrix)
-  const float* direct_feat;     // (NV*P, 64)
+  const float* direct_feat;     // (NV*P, 64)   explicit MLP inputs (ResnetFC.forward on a matrix); tz rows = (3, NV*P, 512)
+  const float* tz;              // hoisted projections: (3, NV, Hf, Wf, 512) of the scene, or (3, NV*P, 512) rows
+  size_t tz_stride;             // floats between lin_z[b] and lin_z[b+1] maps
   long long P;
   int K;
   float freq_factor;
@@ -274,9 +308,8 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
                                                         // into a workspace padded to a multiple of 16 points
     Taps taps;
     float feat[16];
-    if (a.direct_latent) {
-      const float* row = a.direct_latent + ((size_t)v * a.P + p) * kLatent;
-      taps.p[0] = taps.p[1] = taps.p[2] = taps.p[3] = row;
+    if (a.direct_feat) {
+      taps.off[0] = taps.off[1] = taps.off[2] = taps.off[3] = ((size_t)v * a.P + p) * kLatent;
       taps.w[0] = 1.0f;
       taps.w[1] = taps.w[2] = taps.w[3] = 0.0f;
       const float* fr = a.direct_feat + ((size_t)v * a.P + p) * kDInPad;
@@ -323,11 +356,11 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
       const float wx = fx - x0f, wy = fy - y0f;
       const int x0 = (int)x0f, y0 = (int)y0f;
       const int x1 = min(x0 + 1, Wf - 1), y1 = min(y0 + 1, Hf - 1);
-      const float* base = sc.latent_cl + (size_t)v * Hf * Wf * kLatent;
-      taps.p[0] = base + ((size_t)y0 * Wf + x0) * kLatent;
-      taps.p[1] = base + ((size_t)y0 * Wf + x1) * kLatent;
-      taps.p[2] = base + ((size_t)y1 * Wf + x0) * kLatent;
-      taps.p[3] = base + ((size_t)y1 * Wf + x1) * kLatent;
+      const size_t base = (size_t)v * Hf * Wf;
+      taps.off[0] = (base + (size_t)y0 * Wf + x0) * kLatent;
+      taps.off[1] = (base + (size_t)y0 * Wf + x1) * kLatent;
+      taps.off[2] = (base + (size_t)y1 * Wf + x0) * kLatent;
+      taps.off[3] = (base + (size_t)y1 * Wf + x1) * kLatent;
       taps.w[0] = (1.0f - wy) * (1.0f - wx);
       taps.w[1] = (1.0f - wy) * wx;
       taps.w[2] = wy * (1.0f - wx);
@@ -343,13 +376,11 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
     stage_mma<3>(ws.acquire(), lane, feat, x);
     // ---- blocks 0..2 (per view)                                                 (:145-157, :61-69)
     for (int b = 0; b < 3; ++b) {
-      const float* bias = a.b_pre + kHidden * (1 + 3 * b);
-      add_bias(x, bias, q);
-      layer_from_latent(ws, taps, q, x);               // x += lin_z[b](latent)
-      set_bias(net, bias + kHidden, q);
-      layer_from_acc(ws, x, net);                      // net = fc_0(relu(x))
-      add_bias(x, bias + 2 * kHidden, q);
-      layer_from_acc(ws, net, x);                      // x += fc_1(relu(net))
+      const float* bias = a.b_pre + kHidden * (1 + 2 * b);
+      set_bias(net, bias, q);
+      layer_fc0_hoisted(ws, a.tz + (size_t)b * a.tz_stride, taps, q, x, net);   // x += lin_z[b](latent); net = fc_0(relu(x))
+      add_bias(x, bias + kHidden, q);
+      layer_from_acc(ws, net, x);                                                // x += fc_1(relu(net))
     }
     // ---- hand the pre-mean activations to the second kernel in accumulator layout
     f32x4* out = reinterpret_cast<f32x4*>(a.xpre) + ((size_t)tile * sc.nv + v) * (kTiles * 64) + lane;
@@ -357,6 +388,46 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
     for (int mo = 0; mo < kTiles; ++mo) out[mo * 64] = x[mo];
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // drain the last (unused) stage prefetch before the LDS is released
+}
+
+struct HoistArgs {
+  const float* src;    // (rows, 512) channels-last latent pixels (or explicit latent rows)
+  float* dst;          // (3, rows, 512): lin_z[b](src) + bias
+  long long rows;
+  const float* w_hoist;
+  const float* b_hoist;
+};
+
+// Projects every feature-map pixel through lin_z[0..2] once per scene (see the header comment).
+__global__ __launch_bounds__(256, 1) void k_hoist_linz(HoistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, pt = lane & 15;
+  const long long n_tiles = (a.rows + 63) / 64;
+  WeightStream ws;
+  ws.base = a.w_hoist;
+  ws.lds = smem;
+  ws.n_stages = kHoistStages;
+  ws.wave = wave;
+  ws.lane = lane;
+  ws.start();
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long row_raw = tile * 64 + wave * 16 + pt;
+    const long long row = row_raw < a.rows ? row_raw : a.rows - 1;
+    const float* src = a.src + (size_t)row * kLatent;
+    for (int b = 0; b < 3; ++b) {
+      f32x4 acc[kTiles];
+      set_bias(acc, a.b_hoist + kHidden * b, q);
+      layer_from_rows(ws, src, q, acc);
+      if (row_raw < a.rows) {
+        f32x4* out = reinterpret_cast<f32x4*>(a.dst + ((size_t)b * a.rows + row) * kLatent) + q;
+#pragma unroll
+        for (int mo = 0; mo < kTiles; ++mo) out[mo * 4] = acc[mo];
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);
 }
 
 struct PostArgs {
@@ -486,6 +557,7 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
   if (!attr_set) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
   fa.w_pre = m->w_pre;
@@ -526,6 +598,21 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
   return 0;
 }
 
+static int launch_hoist(const DinerMlpImpl* m, const float* src, long long rows, float* dst, hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds_bytes = 2 * kStageFloats * sizeof(float);
+  if (!attr_set) {
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  HoistArgs ha{src, dst, rows, m->w_hoist, m->b_hoist};
+  const long long n_tiles = (rows + 63) / 64;
+  const int cus = num_cus();
+  hipLaunchKernelGGL(k_hoist_linz, dim3((unsigned)(n_tiles < cus ? n_tiles : cus)), dim3(256), lds_bytes, stream, ha);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
 }  // namespace diner
 
 using namespace diner;
@@ -546,9 +633,11 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
   hipStream_t stream = (hipStream_t)stream_;
   DinerMlp* m = new DinerMlp();
   memset(&m->impl, 0, sizeof(m->impl));
+  DINER_HIP_OK(hipMalloc(&m->impl.w_hoist, (size_t)kHoistStages * kStageFloats * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&m->impl.w_pre, (size_t)kPreStages * kStageFloats * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&m->impl.w_post, (size_t)kPostStages * kStageFloats * sizeof(float)));
-  DINER_HIP_OK(hipMalloc(&m->impl.b_pre, 10 * kHidden * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&m->impl.b_hoist, 3 * kHidden * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&m->impl.b_pre, 7 * kHidden * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&m->impl.b_post, (4 * kHidden + 16) * sizeof(float)));
   auto pack = [&](const float* W, int rows, int cols, int n_kc, float* dst) {
     hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, W, rows, cols, n_kc, dst);
@@ -561,13 +650,13 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
   wp += 4 * kStageFloats;
   bias(p->lin_in_b, kHidden, kHidden, m->impl.b_pre);
   for (int b = 0; b < 3; ++b) {
-    pack(p->lin_z_w[b], kHidden, kLatent, 8, wp); wp += kStagesPerLayer * kStageFloats;
+    pack(p->lin_z_w[b], kHidden, kLatent, 8, m->impl.w_hoist + (size_t)b * kStagesPerLayer * kStageFloats);
+    bias(p->lin_z_b[b], kHidden, kHidden, m->impl.b_hoist + kHidden * b);
     pack(p->fc0_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
     pack(p->fc1_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
-    float* bb = m->impl.b_pre + kHidden * (1 + 3 * b);
-    bias(p->lin_z_b[b], kHidden, kHidden, bb);
-    bias(p->fc0_b[b], kHidden, kHidden, bb + kHidden);
-    bias(p->fc1_b[b], kHidden, kHidden, bb + 2 * kHidden);
+    float* bb = m->impl.b_pre + kHidden * (1 + 2 * b);
+    bias(p->fc0_b[b], kHidden, kHidden, bb);
+    bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
   }
   wp = m->impl.w_post;
   for (int b = 3; b < 5; ++b) {
@@ -586,8 +675,10 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
 
 extern "C" int diner_mlp_destroy(DinerMlp* m) {
   if (!m) return 0;
+  hipFree(m->impl.w_hoist);
   hipFree(m->impl.w_pre);
   hipFree(m->impl.w_post);
+  hipFree(m->impl.b_hoist);
   hipFree(m->impl.b_pre);
   hipFree(m->impl.b_post);
   delete m;
@@ -630,8 +721,8 @@ extern "C" size_t diner_field_workspace_bytes(long long n_points) {
 
 extern "C" size_t diner_mlp_forward_workspace_bytes(long long B) {
   if (B <= 0) return 0;
-  // as above plus the aligned split of the explicit zx matrix
-  return xpre_bytes(B, kMaxViews) + (size_t)B * kMaxViews * (kLatent + kDInPad) * sizeof(float);
+  // as above plus the aligned split of the explicit zx matrix and the three projected copies of its latent rows
+  return xpre_bytes(B, kMaxViews) + (size_t)B * kMaxViews * (kLatent + kDInPad + 3 * kLatent) * sizeof(float);
 }
 
 static int check_field_scene(const DinerScene* scene, SceneDev* sd) {
@@ -640,7 +731,9 @@ static int check_field_scene(const DinerScene* scene, SceneDev* sd) {
   DINER_CHECK_ARG(scene->nv == kMaxViews, "field: the fused kernel is built for NV=%d source views (got %d)", kMaxViews,
                   scene->nv);
   DINER_CHECK_ARG(scene->C == kLatent, "field: latent size %d != %d", scene->C, kLatent);
-  DINER_CHECK_ARG(scene->latent_cl && scene->depth, "field: latent / depth map missing");
+  DINER_CHECK_ARG(scene->depth, "field: depth map missing");
+  DINER_CHECK_ARG(scene->latent_proj, "field: scene->latent_proj is null -- call diner_scene_prepare_f32 once per "
+                                      "(scene, MLP weights) first");
   DINER_CHECK_ARG(scene->Hf > 0 && scene->Wf > 0 && scene->Hs > 0 && scene->Ws > 0, "field: bad map sizes");
   return 0;
 }
@@ -659,6 +752,8 @@ extern "C" int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp
   fa.z = z;
   fa.K = K;
   fa.P = (long long)NR * K;
+  fa.tz = scene->latent_proj;
+  fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
   return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, (hipStream_t)stream);
 }
 
@@ -676,6 +771,8 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
   fa.viewdirs = viewdirs;
   fa.K = 1;
   fa.P = P;
+  fa.tz = scene->latent_proj;
+  fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
   return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, (hipStream_t)stream);
 }
 
@@ -687,16 +784,34 @@ extern "C" int diner_mlp_forward_f32(const DinerMlp* mlp, const float* zx, long 
   char* ws = (char*)workspace;
   float* lat = (float*)(ws + xpre_bytes(B, kMaxViews));
   float* feat = lat + (size_t)kMaxViews * B * kLatent;
+  float* tz = feat + (size_t)kMaxViews * B * kDInPad;
   const long long rows = (long long)kMaxViews * B;
   hipLaunchKernelGGL(k_split_zx, dim3(2048), dim3(256), 0, stream, zx, rows, lat, feat);
   DINER_LAUNCH_OK();
+  int rc = launch_hoist(&mlp->impl, lat, rows, tz, stream);       // lin_z[0..2] of the explicit latent rows
+  if (rc) return rc;
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));
-  fa.direct_latent = lat;
   fa.direct_feat = feat;
+  fa.tz = tz;
+  fa.tz_stride = (size_t)rows * kLatent;
   fa.K = 1;
   fa.P = B;
   return launch_field(nullptr, &mlp->impl, fa, kMaxViews, out, 1, workspace, stream);
+}
+
+extern "C" size_t diner_scene_proj_bytes(const DinerScene* scene) {
+  if (!scene || scene->nv <= 0 || scene->Hf <= 0 || scene->Wf <= 0) return 0;
+  return (size_t)3 * scene->nv * scene->Hf * scene->Wf * kLatent * sizeof(float);
+}
+
+extern "C" int diner_scene_prepare_f32(const DinerScene* scene, const DinerMlp* mlp, float* latent_proj_out,
+                                       void* stream) {
+  DINER_CHECK_ARG(scene && mlp && latent_proj_out, "scene_prepare: null pointer argument");
+  DINER_CHECK_ARG(scene->latent_cl && scene->C == kLatent && scene->Hf > 0 && scene->Wf > 0 && scene->nv > 0,
+                  "scene_prepare: channels-last latent (NV,Hf,Wf,%d) missing", kLatent);
+  return launch_hoist(&mlp->impl, scene->latent_cl, (long long)scene->nv * scene->Hf * scene->Wf, latent_proj_out,
+                      (hipStream_t)stream);
 }
 
 extern "C" int diner_render_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z, int NR,

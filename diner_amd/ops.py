@@ -116,7 +116,25 @@ class HipScene:
         s.std_pad_scale = self.std_pad_scale.data_ptr()
         s.img_w, s.img_h, s.feature_padding = self.img_w, self.img_h, self.feature_padding
         s.nv, s.C, s.Hf, s.Wf, s.Hs, s.Ws = self.nv, self.C, self.Hf, self.Wf, self.Hs, self.Ws
+        s.latent_proj = None
         self.struct = s
+        self.latent_proj = None
+        self._prepared_for = None
+
+    def prepare(self, mlp, force=False):
+        """Hoist lin_z[0..2] out of the sample loop: project the channels-last latent once (k_hoist_linz).
+        Re-run when the MLP handle changes (the handle itself is rebuilt whenever a parameter changes)."""
+        if self.latent_cl is None:
+            raise RuntimeError("diner_amd: scene has no latent map")
+        if not force and self._prepared_for is mlp and self.latent_proj is not None:
+            return
+        with torch.cuda.device(self.device):
+            if self.latent_proj is None:
+                nbytes = lib.diner_scene_proj_bytes(self.ref)
+                self.latent_proj = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            _lib.check(lib.diner_scene_prepare_f32(self.ref, mlp.handle, _ptr(self.latent_proj), _stream()))
+        self.struct.latent_proj = self.latent_proj.data_ptr()
+        self._prepared_for = mlp
 
     @property
     def ref(self):
@@ -217,6 +235,7 @@ def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z):
     _require_hip(rays, z)
     rays, z = _f32c(rays), _f32c(z)
     NR, K = z.shape
+    scene.prepare(mlp)
     out = torch.empty(NR, K, 4, device=rays.device, dtype=torch.float32)
     rays_per = max(1, MAX_POINTS_PER_LAUNCH // K)
     with torch.cuda.device(rays.device):
@@ -233,6 +252,7 @@ def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs):
     _require_hip(xyz, viewdirs)
     xyz, viewdirs = _f32c(xyz), _f32c(viewdirs)
     P = xyz.shape[0]
+    scene.prepare(mlp)
     out = torch.empty(P, 4, device=xyz.device, dtype=torch.float32)
     step = MAX_POINTS_PER_LAUNCH
     with torch.cuda.device(xyz.device):
@@ -307,7 +327,9 @@ def index(scene: HipScene, mode, uv):
 
 # FLOPs of the two field kernels per sample point: NV views x (lin_in + 3 x (lin_z, fc_0, fc_1))
 # before the view mean, 2 x (fc_0, fc_1) + lin_out after it.
-FLOP_PRE_PER_POINT = 2 * 4 * (55 * 512 + 9 * 512 * 512)
+FLOP_PRE_PER_POINT_REFERENCE = 2 * 4 * (55 * 512 + 9 * 512 * 512)     # as the reference computes it
+FLOP_PRE_PER_POINT = 2 * 4 * (55 * 512 + 6 * 512 * 512)               # executed: lin_z hoisted to once per pixel
+FLOP_HOIST_PER_PIXEL = 2 * 3 * 512 * 512
 FLOP_POST_PER_POINT = 2 * (4 * 512 * 512 + 512 * 4)
 
 

@@ -35,6 +35,8 @@ extern "C" {
  * (pixelnerf.py:47-51; image_encoder.py:232-236, :290-291). */
 typedef struct DinerScene {
   const float* latent_cl;   /* (NV, Hf, Wf, C)  feature map, CHANNELS-LAST (re-laid-out once per encode) */
+  const float* latent_proj; /* (3, NV, Hf, Wf, C) lin_z[b](latent)+bias, written by diner_scene_prepare_f32; the field
+                               entry points gather from these maps (resnetfc.py:153-155 hoisted out of the sample loop) */
   const float* depth;       /* (NV, Hs, Ws)     source depth maps, 0 = background                          */
   const float* depth_std;   /* (NV, Hs, Ws)     depth standard deviation                                    */
   const float* normals;     /* (NV, 3, Hs, Ws)  normal maps (planar, as produced by depth2normal)          */
@@ -91,6 +93,14 @@ int diner_sample_depthguided_f32(const DinerScene* scene, const float* rays, int
 /* Stage-level entry for tests: fill_up_uniform_samples alone (nerf_renderer.py:367-397). */
 int diner_fill_uniform_f32(const float* z_in, const float* rays, int NR, int K, const float* noise_fill,
                            uint64_t seed, float* z_out, void* stream);
+
+/* ---- per-scene preparation: hoist of the three lin_z projections (resnetfc.py:153-155) ---------
+ * lin_z[b] is linear and bilinear/border weights sum to 1, so lin_z[b](interp(latent)) == interp(lin_z[b](latent)):
+ * the projections are applied once per feature-map pixel here instead of once per (sample, view).  Must be called
+ * (and scene->latent_proj set to the output buffer of diner_scene_proj_bytes(scene) bytes) whenever the latent map or
+ * the lin_z parameters change, before any diner_field_* / diner_render_f32 call on that scene. */
+size_t diner_scene_proj_bytes(const DinerScene* scene);
+int diner_scene_prepare_f32(const DinerScene* scene, const DinerMlp* mlp, float* latent_proj_out, void* stream);
 
 /* ---- a5+a6+a7+a8: PixelNeRF.forward at ray samples -------------------------------------------
  * (pixelnerf.py:55-145; positional_encoding.py:33-53; image_encoder.py:97-170; resnetfc.py:129-159)
