@@ -17,8 +17,9 @@
 //    points.  Two 128-register accumulator sets (residual stream x, hidden net) + fragments fit the
 //    512-entry unified VGPR/AGPR file at one wave per SIMD.
 //  * weights (13.8 MB fp32, L2 / Infinity-Cache resident) are streamed by all four waves through a
-//    double-buffered 2 x 32 KB LDS ring with global_load_lds (one barrier per 32 KB stage), packed on
-//    the host side of the C ABI into the exact ds_read_b128 fragment order (conflict-free, lane-linear).
+//    2 x 32 KB LDS ring with global_load_lds (DMA one stage ahead, one barrier per 32 KB stage, A
+//    fragments double-buffered one k-group ahead), packed on the host side of the C ABI into the exact
+//    ds_read_b128 fragment order (conflict-free, lane-linear).
 //  * the 512-channel latent is gathered straight into B-operand registers from the channels-last map:
 //    each lane reads 16 B (4 channels) per tap, the 4 lanes of a point cover one 64 B segment.
 //  * lin_z hoist: `lin_z[b]` is linear and bilinear / border interpolation weights sum to one, so
@@ -92,61 +93,119 @@ __global__ void k_copy_pad(const float* __restrict__ src, int n, int n_pad, floa
 // ------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) float lds_float;
 
-// Issue the LDS-DMA of one 32 KB stage: 32 pieces of 1 KB, wave w moves pieces w, w+4, ...
+// Issue the LDS-DMA of one 32 KB stage: 32 pieces of 1 KB (one wave-wide global_load_lds_dwordx4 each); wave w
+// moves the contiguous pieces 8w..8w+7.  The instruction's immediate offset applies to the global AND the LDS
+// address, so one address / M0 pair covers four pieces (0, 1, 2, 3 KB) -- two pairs per wave per stage.
 __device__ __forceinline__ void stage_prefetch(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
+  const float* g0 = gsrc + wave * 2048 + lane * 4;
+  float* l0 = lds_dst + wave * 2048;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int piece = wave + 4 * j;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
+  for (int h = 0; h < 2; ++h) {
+    const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(g0 + h * 1024);
+    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(l0 + h * 1024);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
   }
 }
 
-// The weight stream of a persistent workgroup: a fixed cyclic sequence of stages.
+// The weight stream of a persistent workgroup: a fixed cyclic sequence of 32 KB stages flowing through a
+// double-buffered LDS ring.  While stage s is consumed, the DMA of stage s+1 (issued right after the barrier that
+// opened stage s) has a whole stage (>= 4096 matrix-pipe cycles) to land.
+constexpr int kRing = 2;
+
 struct WeightStream {
   const float* base;   // packed stages in global memory
-  float* lds;          // 2 x kStageFloats
+  float* lds;          // kRing x kStageFloats
   int n_stages;
-  int cur;             // index (in the cyclic sequence) of the stage about to be consumed
-  int parity;
+  int issue;           // index (in the cyclic sequence) of the next stage to DMA
+  int slot;            // ring slot of the stage about to be consumed
   int wave, lane;
+
   __device__ __forceinline__ void start() {
-    cur = 0;
-    parity = 0;
     stage_prefetch(base, lds, wave, lane);
+    issue = n_stages > 1 ? 1 : 0;
+    slot = 0;
   }
-  // make stage `cur` readable in lds[parity], then start the DMA of the following stage into the other
-  // buffer (free: every wave finished reading it before it reached this barrier)
-  __device__ __forceinline__ const float* acquire() {
-    __builtin_amdgcn_s_waitcnt(0x0f70 | 0);  // vmcnt(0): my pieces of stage `cur` have landed (expcnt/lgkmcnt untouched)
+  // Begin consuming the stage in `slot`: one barrier per stage publishes it (every wave has waited for its own DMA
+  // pieces) and retires the previous stage, whose slot then receives the DMA of the next one.
+  __device__ __forceinline__ const f32x4* begin() {
+    __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): everything outstanding is a whole stage old
     __syncthreads();
-    int nxt = cur + 1;
-    if (nxt == n_stages) nxt = 0;
-    stage_prefetch(base + (size_t)nxt * kStageFloats, lds + (parity ^ 1) * kStageFloats, wave, lane);
-    const float* ready = lds + parity * kStageFloats;
-    cur = nxt;
-    parity ^= 1;
-    return ready;
+    stage_prefetch(base + (size_t)issue * kStageFloats, lds + (slot ^ 1) * kStageFloats, wave, lane);
+    issue = (issue + 1 == n_stages) ? 0 : issue + 1;
+    const f32x4* cur = reinterpret_cast<const f32x4*>(lds + slot * kStageFloats) + lane;
+    slot ^= 1;
+    return cur;
   }
+  __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 };
 
-// one 32 KB stage = 128 output features (accumulators acc[8 mg .. 8 mg+7]) x 64 k (B operands bop[0..15])
-template <int MG>
-__device__ __forceinline__ void stage_mma(const float* __restrict__ st, int lane, const float (&bop)[16],
-                                          f32x4 (&acc)[kTiles]) {
-  const f32x4* st4 = reinterpret_cast<const f32x4*>(st) + lane;
+// one 32 KB stage = 128 output features (accumulators acc[8 mg .. 8 mg+7]) x 64 k (B operands bop[0..15]).
+// The stage is walked in 16 steps of 8 MFMAs: step (ml, mp) multiplies the two A fragments (mo = 2 mp, 2 mp + 1)
+// of k-group ml into their two accumulators, alternating between them so that back-to-back MFMAs never hit the
+// same accumulator (40-cycle dependent latency vs 32-cycle issue).  The two ds_read_b128 of step s+2 are issued
+// in front of the MFMAs of step s: LDS traffic is spread evenly (2 reads per 8 MFMAs = 256 matrix-pipe cycles)
+// instead of bursts of 8 reads that starve the pipe, and only 24 VGPRs hold fragments.
+#ifndef DINER_PIN_SCHEDULE
+#define DINER_PIN_SCHEDULE 1
+#endif
+#if DINER_PIN_SCHEDULE
+#define DINER_STEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DINER_STEP_FENCE()
+#endif
+
+template <int MG, int STEP>
+__device__ __forceinline__ void stage_step_load(const f32x4* __restrict__ cur, f32x4 (&f)[2]) {
+  constexpr int ml = STEP >> 2, mp = STEP & 3;
+  f[0] = cur[((2 * mp) * 4 + ml) * 64];
+  f[1] = cur[((2 * mp + 1) * 4 + ml) * 64];
+}
+template <int MG, int STEP>
+__device__ __forceinline__ void stage_step_mma(const f32x4 (&f)[2], const float (&bop)[16], f32x4 (&acc)[kTiles]) {
+  constexpr int ml = STEP >> 2, mp = STEP & 3;
 #pragma unroll
-  for (int ml = 0; ml < 4; ++ml) {
-    f32x4 a[8];
-#pragma unroll
-    for (int mo = 0; mo < 8; ++mo) a[mo] = st4[(mo * 4 + ml) * 64];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int mo = 0; mo < 8; ++mo)
-        acc[8 * MG + mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo][r], bop[4 * ml + r], acc[8 * MG + mo], 0, 0, 0);
-    }
+  for (int r = 0; r < 4; ++r) {
+    acc[8 * MG + 2 * mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[0][r], bop[4 * ml + r], acc[8 * MG + 2 * mp], 0, 0, 0);
+    acc[8 * MG + 2 * mp + 1] =
+        __builtin_amdgcn_mfma_f32_16x16x4f32(f[1][r], bop[4 * ml + r], acc[8 * MG + 2 * mp + 1], 0, 0, 0);
   }
+}
+
+template <int MG>
+__device__ __forceinline__ void stage_compute(const f32x4* __restrict__ cur, const float (&bop)[16],
+                                              f32x4 (&acc)[kTiles]) {
+  f32x4 fa[2], fb[2], fc[2];
+  stage_step_load<MG, 0>(cur, fa);
+  stage_step_load<MG, 1>(cur, fb);
+#define DINER_STEP3(S0)                                                      \
+  stage_step_load<MG, (S0) + 2>(cur, fc);                                    \
+  stage_step_mma<MG, (S0)>(fa, bop, acc);                                    \
+  DINER_STEP_FENCE();                                                        \
+  stage_step_load<MG, (S0) + 3>(cur, fa);                                    \
+  stage_step_mma<MG, (S0) + 1>(fb, bop, acc);                                \
+  DINER_STEP_FENCE();                                                        \
+  stage_step_load<MG, (S0) + 4>(cur, fb);                                    \
+  stage_step_mma<MG, (S0) + 2>(fc, bop, acc);                                \
+  DINER_STEP_FENCE();
+  DINER_STEP3(0) DINER_STEP3(3) DINER_STEP3(6) DINER_STEP3(9)
+#undef DINER_STEP3
+  // steps 12..15: fa holds step 12, fb step 13
+  stage_step_load<MG, 14>(cur, fc);
+  stage_step_mma<MG, 12>(fa, bop, acc);
+  DINER_STEP_FENCE();
+  stage_step_load<MG, 15>(cur, fa);
+  stage_step_mma<MG, 13>(fb, bop, acc);
+  DINER_STEP_FENCE();
+  stage_step_mma<MG, 14>(fc, bop, acc);
+  stage_step_mma<MG, 15>(fa, bop, acc);
+}
+
+template <int MG>
+__device__ __forceinline__ void stage_mma(WeightStream& ws, const float (&bop)[16], f32x4 (&acc)[kTiles]) {
+  stage_compute<MG>(ws.begin(), bop, acc);
 }
 
 template <int KC>
@@ -172,10 +231,10 @@ __device__ __forceinline__ void layer_from_acc(WeightStream& ws, const f32x4 (&s
   {                                                         \
     float bop[16];                                          \
     bops_relu<KC_>(src, bop);                               \
-    stage_mma<0>(ws.acquire(), ws.lane, bop, dst);          \
-    stage_mma<1>(ws.acquire(), ws.lane, bop, dst);          \
-    stage_mma<2>(ws.acquire(), ws.lane, bop, dst);          \
-    stage_mma<3>(ws.acquire(), ws.lane, bop, dst);          \
+    stage_mma<0>(ws, bop, dst);                             \
+    stage_mma<1>(ws, bop, dst);                             \
+    stage_mma<2>(ws, bop, dst);                             \
+    stage_mma<3>(ws, bop, dst);                             \
   }
   DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
 #undef DINER_KC
@@ -211,11 +270,14 @@ __device__ __forceinline__ void layer_fc0_hoisted(WeightStream& ws, const float*
       x[4 * KC_ + ml] += v;                                                                                   \
       _Pragma("unroll") for (int r = 0; r < 4; ++r) bop[4 * ml + r] = fmaxf(x[4 * KC_ + ml][r], 0.0f);        \
     }                                                                                                         \
-    if (KC_ < 7) taps_load(tz, t, KC_ + 1, q, raw);                                                           \
-    stage_mma<0>(ws.acquire(), ws.lane, bop, net);                                                            \
-    stage_mma<1>(ws.acquire(), ws.lane, bop, net);                                                            \
-    stage_mma<2>(ws.acquire(), ws.lane, bop, net);                                                            \
-    stage_mma<3>(ws.acquire(), ws.lane, bop, net);                                                            \
+    {                                                                                                         \
+      const f32x4* cur = ws.begin();  /* taps of the next chunk go out right AFTER the barrier: a whole */    \
+      if (KC_ < 7) taps_load(tz, t, KC_ + 1, q, raw);   /* stage passes before the next vmcnt(0)        */    \
+      stage_compute<0>(cur, bop, net);                                                                        \
+    }                                                                                                         \
+    stage_mma<1>(ws, bop, net);                                                                               \
+    stage_mma<2>(ws, bop, net);                                                                               \
+    stage_mma<3>(ws, bop, net);                                                                               \
   }
   DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
 #undef DINER_KC
@@ -232,14 +294,17 @@ __device__ __forceinline__ void layer_from_rows(WeightStream& ws, const float* _
     float bop[16];                                                                                            \
     _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                          \
       _Pragma("unroll") for (int r = 0; r < 4; ++r) bop[4 * ml + r] = raw[ml][r];                             \
-    if (KC_ < 7) {                                                                                            \
-      _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                        \
-        raw[ml] = *reinterpret_cast<const f32x4*>(row + 64 * (KC_ + 1) + 16 * ml + 4 * q);                    \
+    {                                                                                                         \
+      const f32x4* cur = ws.begin();                                                                          \
+      if (KC_ < 7) {                                                                                          \
+        _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                      \
+          raw[ml] = *reinterpret_cast<const f32x4*>(row + 64 * (KC_ + 1) + 16 * ml + 4 * q);                  \
+      }                                                                                                       \
+      stage_compute<0>(cur, bop, dst);                                                                        \
     }                                                                                                         \
-    stage_mma<0>(ws.acquire(), ws.lane, bop, dst);                                                            \
-    stage_mma<1>(ws.acquire(), ws.lane, bop, dst);                                                            \
-    stage_mma<2>(ws.acquire(), ws.lane, bop, dst);                                                            \
-    stage_mma<3>(ws.acquire(), ws.lane, bop, dst);                                                            \
+    stage_mma<1>(ws, bop, dst);                                                                               \
+    stage_mma<2>(ws, bop, dst);                                                                               \
+    stage_mma<3>(ws, bop, dst);                                                                               \
   }
   DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
 #undef DINER_KC
@@ -266,7 +331,7 @@ __device__ __forceinline__ float input_feature(int f, const float* xc, const flo
   }
   const float freq = __fmul_rn(6.28f, (float)(1 << (j >> 1)));                  // positional_encoding.py:18
   const float phase = (j & 1) ? 1.57079637050628662109375f : 0.0f;               // fp32(pi/2), :30
-  return sinf(__fmaf_rn(arg, freq, phase));                                       // addcmul is fused, :46
+  return sin_posenc(__fmaf_rn(arg, freq, phase));                                 // addcmul is fused, :46
 }
 
 struct FieldArgs {
@@ -370,10 +435,10 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
     f32x4 x[kTiles], net[kTiles];
     // ---- lin_in: x = W_in f + b_in                                             (resnetfc.py:141)
     set_bias(x, a.b_pre, q);
-    stage_mma<0>(ws.acquire(), lane, feat, x);
-    stage_mma<1>(ws.acquire(), lane, feat, x);
-    stage_mma<2>(ws.acquire(), lane, feat, x);
-    stage_mma<3>(ws.acquire(), lane, feat, x);
+    stage_mma<0>(ws, feat, x);
+    stage_mma<1>(ws, feat, x);
+    stage_mma<2>(ws, feat, x);
+    stage_mma<3>(ws, feat, x);
     // ---- blocks 0..2 (per view)                                                 (:145-157, :61-69)
     for (int b = 0; b < 3; ++b) {
       const float* bias = a.b_pre + kHidden * (1 + 2 * b);
@@ -387,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
 #pragma unroll
     for (int mo = 0; mo < kTiles; ++mo) out[mo * 64] = x[mo];
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);   // drain the last (unused) stage prefetch before the LDS is released
+  ws.drain();   // the last (unused) stage DMAs must land before the LDS is released
 }
 
 struct HoistArgs {
@@ -427,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void k_hoist_linz(HoistArgs a) {
       }
     }
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);
+  ws.drain();
 }
 
 struct PostArgs {
@@ -481,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
     }
     // ---- lin_out (one stage: 16 padded output rows x 512)                       (resnetfc.py:158)
     {
-      const f32x4* st4 = reinterpret_cast<const f32x4*>(ws.acquire()) + lane;
+      const f32x4* st4 = ws.begin();
       f32x4 o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -506,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
       }
     }
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);
+  ws.drain();
 }
 
 // split an explicit (NV, B, 512+55) ResnetFC input into aligned latent rows and 64-padded feature rows
@@ -553,7 +618,7 @@ static size_t xpre_bytes(long long P, int nv) {
 static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa, int nv, float* out, int raw,
                         void* workspace, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds_bytes = 2 * kStageFloats * sizeof(float);
+  const size_t lds_bytes = kRing * kStageFloats * sizeof(float);
   if (!attr_set) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -600,7 +665,7 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
 
 static int launch_hoist(const DinerMlpImpl* m, const float* src, long long rows, float* dst, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds_bytes = 2 * kStageFloats * sizeof(float);
+  const size_t lds_bytes = kRing * kStageFloats * sizeof(float);
   if (!attr_set) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;

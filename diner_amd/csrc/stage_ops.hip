@@ -25,7 +25,8 @@ __global__ void k_posenc(const float* __restrict__ x, long long N, int D, int F,
       const int j = o / D, d = o - j * D;
       const float freq = __fmul_rn(factor, (float)(1 << (j >> 1)));          // positional_encoding.py:18
       const float phase = (j & 1) ? 1.57079637050628662109375f : 0.0f;        // fp32(pi/2) :30
-      v = sinf(__fmaf_rn(x[n * D + d], freq, phase));                          // addcmul (fused on the CPU) then sin :46
+      const float arg = __fmaf_rn(x[n * D + d], freq, phase);                  // addcmul (fused on the CPU) :46
+      v = fabsf(arg) < 8192.0f ? sin_posenc(arg) : sinf(arg);
     }
     out[idx] = v;
   }
