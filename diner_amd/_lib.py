@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiner_hip.so")
+LIB_PATH = os.environ.get("DINER_AMD_LIB") or os.path.join(_HERE, "libdiner_hip.so")   # override: timing experiments
 
 
 class DinerScene(C.Structure):

@@ -36,6 +36,24 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def build_variant(name, defines, verbose=False):
+    """Timing-experiment builds (tools/ablate.sh): libdiner_hip_<name>.so with extra -D flags."""
+    obj_dir = os.path.join(ROOT, "build", "obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        op = os.path.join(obj_dir, src + ".o")
+        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", op]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(op)
+    lib = os.path.join(HERE, f"libdiner_hip_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     deps = [os.path.join(CSRC, "common.hpp"), os.path.join(ROOT, "include", "diner_hip.h")]

@@ -93,35 +93,48 @@ __global__ void k_copy_pad(const float* __restrict__ src, int n, int n_pad, floa
 // ------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) float lds_float;
 
-// Issue the LDS-DMA of one 32 KB stage: 32 pieces of 1 KB (one wave-wide global_load_lds_dwordx4 each); wave w
-// moves the contiguous pieces 8w..8w+7.  The instruction's immediate offset applies to the global AND the LDS
-// address, so one address / M0 pair covers four pieces (0, 1, 2, 3 KB) -- two pairs per wave per stage.
+// LDS-DMA of one 32 KB stage = 32 pieces of 1 KB (one wave-wide global_load_lds_dwordx4 each); wave w moves the
+// contiguous pieces 8w..8w+7.  The instruction's immediate offset applies to the global AND the LDS address, so one
+// address / M0 pair covers four pieces.  Piece j of a wave is issued from step j of the stage (see stage_compute):
+// the DMA is spread over the first half of the stage instead of an 8-instruction burst after the barrier.
+// Timing-experiment switches (tools/ablate.sh): DINER_ABL_NO_DMA / _NO_BARRIER / _NO_LDS remove one ingredient of the
+// stage loop to price it.  Results are WRONG when any is set; the shipped library is built with none.
+template <int J>
+__device__ __forceinline__ void stage_dma_piece(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
+#ifdef DINER_ABL_NO_DMA
+  return;
+#endif
+  constexpr int h = J >> 2, o = (J & 3) * 1024;
+  const __attribute__((address_space(1))) void* g =
+      (const __attribute__((address_space(1))) void*)(gsrc + wave * 2048 + lane * 4 + h * 1024);
+  __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(lds_dst + wave * 2048 + h * 1024);
+  __builtin_amdgcn_global_load_lds(g, l, 16, o, 0);
+}
 __device__ __forceinline__ void stage_prefetch(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
-  const float* g0 = gsrc + wave * 2048 + lane * 4;
-  float* l0 = lds_dst + wave * 2048;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(g0 + h * 1024);
-    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(l0 + h * 1024);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
-  }
+  stage_dma_piece<0>(gsrc, lds_dst, wave, lane);
+  stage_dma_piece<1>(gsrc, lds_dst, wave, lane);
+  stage_dma_piece<2>(gsrc, lds_dst, wave, lane);
+  stage_dma_piece<3>(gsrc, lds_dst, wave, lane);
+  stage_dma_piece<4>(gsrc, lds_dst, wave, lane);
+  stage_dma_piece<5>(gsrc, lds_dst, wave, lane);
+  stage_dma_piece<6>(gsrc, lds_dst, wave, lane);
+  stage_dma_piece<7>(gsrc, lds_dst, wave, lane);
 }
 
 // The weight stream of a persistent workgroup: a fixed cyclic sequence of 32 KB stages flowing through a
-// double-buffered LDS ring.  While stage s is consumed, the DMA of stage s+1 (issued right after the barrier that
-// opened stage s) has a whole stage (>= 4096 matrix-pipe cycles) to land.
+// double-buffered LDS ring.  While stage s is consumed, the DMA of stage s+1 is issued (pieces spread over the
+// first 8 steps of stage s) and has the rest of the stage (> 2000 matrix-pipe cycles) to land.
 constexpr int kRing = 2;
 
 struct WeightStream {
   const float* base;   // packed stages in global memory
   float* lds;          // kRing x kStageFloats
   int n_stages;
-  int issue;           // index (in the cyclic sequence) of the next stage to DMA
+  int issue;           // index (in the cyclic sequence) of the stage whose DMA is issued during the current stage
   int slot;            // ring slot of the stage about to be consumed
   int wave, lane;
+  const float* dma_src;   // set by begin(): source / destination of the DMA pieces of this stage
+  float* dma_dst;
 
   __device__ __forceinline__ void start() {
     stage_prefetch(base, lds, wave, lane);
@@ -131,13 +144,20 @@ struct WeightStream {
   // Begin consuming the stage in `slot`: one barrier per stage publishes it (every wave has waited for its own DMA
   // pieces) and retires the previous stage, whose slot then receives the DMA of the next one.
   __device__ __forceinline__ const f32x4* begin() {
-    __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): everything outstanding is a whole stage old
+#ifndef DINER_ABL_NO_BARRIER
+    __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): everything outstanding is at least half a stage old
     __syncthreads();
-    stage_prefetch(base + (size_t)issue * kStageFloats, lds + (slot ^ 1) * kStageFloats, wave, lane);
+#endif
+    dma_src = base + (size_t)issue * kStageFloats;
+    dma_dst = lds + (slot ^ 1) * kStageFloats;
     issue = (issue + 1 == n_stages) ? 0 : issue + 1;
     const f32x4* cur = reinterpret_cast<const f32x4*>(lds + slot * kStageFloats) + lane;
     slot ^= 1;
     return cur;
+  }
+  template <int STEP>
+  __device__ __forceinline__ void dma_step() {
+    if constexpr (STEP < 8) stage_dma_piece<STEP>(dma_src, dma_dst, wave, lane);
   }
   __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 };
@@ -145,9 +165,12 @@ struct WeightStream {
 // one 32 KB stage = 128 output features (accumulators acc[8 mg .. 8 mg+7]) x 64 k (B operands bop[0..15]).
 // The stage is walked in 16 steps of 8 MFMAs: step (ml, mp) multiplies the two A fragments (mo = 2 mp, 2 mp + 1)
 // of k-group ml into their two accumulators, alternating between them so that back-to-back MFMAs never hit the
-// same accumulator (40-cycle dependent latency vs 32-cycle issue).  The two ds_read_b128 of step s+2 are issued
-// in front of the MFMAs of step s: LDS traffic is spread evenly (2 reads per 8 MFMAs = 256 matrix-pipe cycles)
-// instead of bursts of 8 reads that starve the pipe, and only 24 VGPRs hold fragments.
+// same accumulator (40-cycle dependent latency vs 32-cycle issue).  Everything that is not an MFMA is spread over
+// the steps so that the in-order wave never leaves the matrix pipe idle for long:
+//   * the two ds_read_b128 of step s+2 are issued in front of the MFMAs of step s (24 VGPRs of fragments);
+//   * one 1 KB LDS-DMA piece of the NEXT stage goes out in each of steps 0..7;
+//   * a per-step hook does 1/16 of the VALU work that prepares the B operands of the next 64-feature chunk.
+// sched_barrier pins MFMA / LDS / VMEM order between steps; VALU and SALU may still float.
 #ifndef DINER_PIN_SCHEDULE
 #define DINER_PIN_SCHEDULE 1
 #endif
@@ -157,55 +180,96 @@ struct WeightStream {
 #define DINER_STEP_FENCE()
 #endif
 
-template <int MG, int STEP>
-__device__ __forceinline__ void stage_step_load(const f32x4* __restrict__ cur, f32x4 (&f)[2]) {
+struct NoHook {
+  template <int STEP, int PIECE>
+  __device__ __forceinline__ void run() {}
+};
+
+#define DINER_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, ACC, 0, 0, 0)
+
+// One step = 8 MFMAs on two accumulators, with every other kind of instruction placed in the gaps BETWEEN
+// individual MFMAs (an in-order wave can hide about five single-issue instructions under one 32-cycle MFMA; a clump of
+// a dozen at a step boundary leaves the matrix pipe idle): two ds_read_b128 for step s+2, one LDS-DMA piece of the
+// next stage, and four pieces of the B-operand preparation hook.
+template <int MG, int STEP, class Hook>
+__device__ __forceinline__ void stage_step(WeightStream& ws, const f32x4* __restrict__ cur, const f32x4 (&f)[2],
+                                           f32x4 (&fnext)[2], const float (&bop)[16], f32x4 (&acc)[kTiles],
+                                           Hook& hook) {
   constexpr int ml = STEP >> 2, mp = STEP & 3;
-  f[0] = cur[((2 * mp) * 4 + ml) * 64];
-  f[1] = cur[((2 * mp + 1) * 4 + ml) * 64];
-}
-template <int MG, int STEP>
-__device__ __forceinline__ void stage_step_mma(const f32x4 (&f)[2], const float (&bop)[16], f32x4 (&acc)[kTiles]) {
-  constexpr int ml = STEP >> 2, mp = STEP & 3;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    acc[8 * MG + 2 * mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[0][r], bop[4 * ml + r], acc[8 * MG + 2 * mp], 0, 0, 0);
-    acc[8 * MG + 2 * mp + 1] =
-        __builtin_amdgcn_mfma_f32_16x16x4f32(f[1][r], bop[4 * ml + r], acc[8 * MG + 2 * mp + 1], 0, 0, 0);
-  }
+  constexpr int a0 = 8 * MG + 2 * mp, a1 = a0 + 1;
+  constexpr int S2 = STEP + 2 < 16 ? STEP + 2 : 15;
+  constexpr int ml2 = S2 >> 2, mp2 = S2 & 3;
+  DINER_MFMA(acc[a0], f[0][0], bop[4 * ml + 0]);
+#ifndef DINER_ABL_NO_LDS
+  if constexpr (STEP + 2 < 16) fnext[0] = cur[((2 * mp2) * 4 + ml2) * 64];
+#endif
+  DINER_MFMA(acc[a1], f[1][0], bop[4 * ml + 0]);
+  hook.template run<STEP, 0>();
+  DINER_MFMA(acc[a0], f[0][1], bop[4 * ml + 1]);
+#ifndef DINER_ABL_NO_LDS
+  if constexpr (STEP + 2 < 16) fnext[1] = cur[((2 * mp2 + 1) * 4 + ml2) * 64];
+#endif
+  DINER_MFMA(acc[a1], f[1][1], bop[4 * ml + 1]);
+  hook.template run<STEP, 1>();
+  DINER_MFMA(acc[a0], f[0][2], bop[4 * ml + 2]);
+  ws.template dma_step<STEP>();
+  DINER_MFMA(acc[a1], f[1][2], bop[4 * ml + 2]);
+  hook.template run<STEP, 2>();
+  DINER_MFMA(acc[a0], f[0][3], bop[4 * ml + 3]);
+  hook.template run<STEP, 3>();
+  DINER_MFMA(acc[a1], f[1][3], bop[4 * ml + 3]);
+#if DINER_PIN_SCHEDULE
+  // the order the scheduler must realise inside this step: MFMAs with at most a few other instructions between them
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (hook piece 0)
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // VMEM (LDS-DMA piece / tap load)
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
+  DINER_STEP_FENCE();
 }
 
-template <int MG>
-__device__ __forceinline__ void stage_compute(const f32x4* __restrict__ cur, const float (&bop)[16],
-                                              f32x4 (&acc)[kTiles]) {
+template <int MG, class Hook>
+__device__ __forceinline__ void stage_compute(WeightStream& ws, const f32x4* __restrict__ cur, const float (&bop)[16],
+                                              f32x4 (&acc)[kTiles], Hook& hook) {
   f32x4 fa[2], fb[2], fc[2];
-  stage_step_load<MG, 0>(cur, fa);
-  stage_step_load<MG, 1>(cur, fb);
-#define DINER_STEP3(S0)                                                      \
-  stage_step_load<MG, (S0) + 2>(cur, fc);                                    \
-  stage_step_mma<MG, (S0)>(fa, bop, acc);                                    \
-  DINER_STEP_FENCE();                                                        \
-  stage_step_load<MG, (S0) + 3>(cur, fa);                                    \
-  stage_step_mma<MG, (S0) + 1>(fb, bop, acc);                                \
-  DINER_STEP_FENCE();                                                        \
-  stage_step_load<MG, (S0) + 4>(cur, fb);                                    \
-  stage_step_mma<MG, (S0) + 2>(fc, bop, acc);                                \
-  DINER_STEP_FENCE();
-  DINER_STEP3(0) DINER_STEP3(3) DINER_STEP3(6) DINER_STEP3(9)
-#undef DINER_STEP3
-  // steps 12..15: fa holds step 12, fb step 13
-  stage_step_load<MG, 14>(cur, fc);
-  stage_step_mma<MG, 12>(fa, bop, acc);
-  DINER_STEP_FENCE();
-  stage_step_load<MG, 15>(cur, fa);
-  stage_step_mma<MG, 13>(fb, bop, acc);
-  DINER_STEP_FENCE();
-  stage_step_mma<MG, 14>(fc, bop, acc);
-  stage_step_mma<MG, 15>(fa, bop, acc);
+#ifdef DINER_ABL_NO_LDS
+  asm volatile("" : "=v"(fa[0]), "=v"(fa[1]), "=v"(fb[0]), "=v"(fb[1]), "=v"(fc[0]), "=v"(fc[1]));
+#else
+  fa[0] = cur[(0 * 4 + 0) * 64];
+  fa[1] = cur[(1 * 4 + 0) * 64];
+  fb[0] = cur[(2 * 4 + 0) * 64];
+  fb[1] = cur[(3 * 4 + 0) * 64];
+#endif
+#define DINER_STEP(S_, FUSE, FLOAD) stage_step<MG, (S_)>(ws, cur, FUSE, FLOAD, bop, acc, hook);
+  DINER_STEP(0, fa, fc)  DINER_STEP(1, fb, fa)  DINER_STEP(2, fc, fb)
+  DINER_STEP(3, fa, fc)  DINER_STEP(4, fb, fa)  DINER_STEP(5, fc, fb)
+  DINER_STEP(6, fa, fc)  DINER_STEP(7, fb, fa)  DINER_STEP(8, fc, fb)
+  DINER_STEP(9, fa, fc)  DINER_STEP(10, fb, fa) DINER_STEP(11, fc, fb)
+  DINER_STEP(12, fa, fc) DINER_STEP(13, fb, fa) DINER_STEP(14, fc, fb)
+  DINER_STEP(15, fa, fc)
+#undef DINER_STEP
 }
 
 template <int MG>
 __device__ __forceinline__ void stage_mma(WeightStream& ws, const float (&bop)[16], f32x4 (&acc)[kTiles]) {
-  stage_compute<MG>(ws.begin(), bop, acc);
+  NoHook h;
+  stage_compute<MG>(ws, ws.begin(), bop, acc, h);
+}
+template <int MG, class Hook>
+__device__ __forceinline__ void stage_mma_hook(WeightStream& ws, const float (&bop)[16], f32x4 (&acc)[kTiles],
+                                               Hook& hook) {
+  stage_compute<MG>(ws, ws.begin(), bop, acc, hook);
 }
 
 template <int KC>
@@ -225,18 +289,36 @@ __device__ __forceinline__ void set_bias(f32x4 (&acc)[kTiles], const float* __re
   for (int mo = 0; mo < kTiles; ++mo) acc[mo] = *reinterpret_cast<const f32x4*>(bias + 16 * mo + 4 * q);
 }
 
-// dst (+)= W . relu(src)  : a full 512x512 layer, 32 stages
-__device__ __forceinline__ void layer_from_acc(WeightStream& ws, const f32x4 (&src)[kTiles], f32x4 (&dst)[kTiles]) {
-#define DINER_KC(KC_)                                       \
-  {                                                         \
-    float bop[16];                                          \
-    bops_relu<KC_>(src, bop);                               \
-    stage_mma<0>(ws, bop, dst);                             \
-    stage_mma<1>(ws, bop, dst);                             \
-    stage_mma<2>(ws, bop, dst);                             \
-    stage_mma<3>(ws, bop, dst);                             \
+// hook: B operands of chunk KCN = relu(src[4 KCN ..]) -- one element per step of the preceding stage
+template <int KCN>
+struct ReluNext {
+  const f32x4 (&src)[kTiles];
+  float (&bop)[16];
+  template <int STEP, int PIECE>
+  __device__ __forceinline__ void run() {
+    if constexpr (PIECE == 0) bop[STEP] = fmaxf(src[4 * KCN + (STEP >> 2)][STEP & 3], 0.0f);
   }
-  DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
+};
+
+// dst (+)= W . relu(src)  : a full 512x512 layer, 32 stages.  The B operands of chunk kc+1 are produced inside the
+// last stage of chunk kc.
+__device__ __forceinline__ void layer_from_acc(WeightStream& ws, const f32x4 (&src)[kTiles], f32x4 (&dst)[kTiles]) {
+  float bopA[16], bopB[16];
+  bops_relu<0>(src, bopA);
+#define DINER_KC(KC_, CUR, NXT)                                       \
+  {                                                                   \
+    stage_mma<0>(ws, CUR, dst);                                       \
+    stage_mma<1>(ws, CUR, dst);                                       \
+    stage_mma<2>(ws, CUR, dst);                                       \
+    if constexpr ((KC_) < 7) {                                        \
+      ReluNext<((KC_) < 7 ? (KC_) + 1 : 7)> hk{src, NXT};             \
+      stage_mma_hook<3>(ws, CUR, dst, hk);                            \
+    } else {                                                          \
+      stage_mma<3>(ws, CUR, dst);                                     \
+    }                                                                 \
+  }
+  DINER_KC(0, bopA, bopB) DINER_KC(1, bopB, bopA) DINER_KC(2, bopA, bopB) DINER_KC(3, bopB, bopA)
+  DINER_KC(4, bopA, bopB) DINER_KC(5, bopB, bopA) DINER_KC(6, bopA, bopB) DINER_KC(7, bopB, bopA)
 #undef DINER_KC
 }
 
@@ -255,58 +337,120 @@ __device__ __forceinline__ void taps_load(const float* __restrict__ map, const T
       raw[tap * 4 + ml] = *reinterpret_cast<const f32x4*>(map + t.off[tap] + 64 * kc + 16 * ml + 4 * q);
 }
 
+// hook: chunk KCN of the hoisted layer: blend the 4 taps of the projected map (step 4 ml), add into the residual
+// stream (4 ml + 1), relu -> B operands (4 ml + 2, 4 ml + 3)
+template <int KCN>
+struct HoistNext {
+  const f32x4 (&raw)[16];
+  const Taps& t;
+  f32x4 (&x)[kTiles];
+  float (&bop)[16];
+  f32x4 v;
+  // one vector component (PIECE) per MFMA gap: blend in step 4 ml, add into x in 4 ml + 1, relu in 4 ml + 2 / + 3
+  template <int STEP, int PIECE>
+  __device__ __forceinline__ void run() {
+    constexpr int ml = STEP >> 2, j = STEP & 3, c = PIECE;
+    if constexpr (j == 0)
+      v[c] = raw[0 + ml][c] * t.w[0] + raw[4 + ml][c] * t.w[1] + raw[8 + ml][c] * t.w[2] + raw[12 + ml][c] * t.w[3];
+    if constexpr (j == 1) x[4 * KCN + ml][c] += v[c];
+    if constexpr (j == 2 && c < 2) bop[4 * ml + c] = fmaxf(x[4 * KCN + ml][c], 0.0f);
+    if constexpr (j == 3 && c < 2) bop[4 * ml + 2 + c] = fmaxf(x[4 * KCN + ml][2 + c], 0.0f);
+  }
+};
+// hook that only issues the tap loads of the following chunk right after the barrier of a stage (step 0)
+template <int KCN>
+struct TapsIssue {
+  const float* __restrict__ tz;
+  const Taps& t;
+  int q;
+  f32x4 (&raw)[16];
+  // 16 float4 loads: one per step of the stage, in its first gap
+  template <int STEP, int PIECE>
+  __device__ __forceinline__ void run() {
+    if constexpr (PIECE == 0) {
+      constexpr int tap = STEP >> 2, ml = STEP & 3;
+      raw[tap * 4 + ml] = *reinterpret_cast<const f32x4*>(tz + t.off[tap] + 64 * KCN + 16 * ml + 4 * q);
+    }
+  }
+};
+
 // net = fc_0(relu(x + interp(lin_z[b](latent)))) with the gather-add of the hoisted projection fused into the
-// B-operand production: for each 64-feature chunk, blend the 4 taps of the projected map, add into the
-// residual stream x (kept), relu -> B operands.  The next chunk's taps are in flight under the MFMAs.
+// B-operand production.  Chunk kc+1's taps are requested in stage 0 of chunk kc (right after its barrier) and are
+// blended / added / relu'd step by step inside stage 3 of chunk kc.
 __device__ __forceinline__ void layer_fc0_hoisted(WeightStream& ws, const float* __restrict__ tz, const Taps& t, int q,
                                                   f32x4 (&x)[kTiles], f32x4 (&net)[kTiles]) {
   f32x4 raw[16];
+  float bopA[16], bopB[16];
   taps_load(tz, t, 0, q, raw);
-#define DINER_KC(KC_)                                                                                         \
-  {                                                                                                           \
-    float bop[16];                                                                                            \
-    _Pragma("unroll") for (int ml = 0; ml < 4; ++ml) {                                                        \
-      const f32x4 v = raw[0 + ml] * t.w[0] + raw[4 + ml] * t.w[1] + raw[8 + ml] * t.w[2] + raw[12 + ml] * t.w[3]; \
-      x[4 * KC_ + ml] += v;                                                                                   \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) bop[4 * ml + r] = fmaxf(x[4 * KC_ + ml][r], 0.0f);        \
-    }                                                                                                         \
-    {                                                                                                         \
-      const f32x4* cur = ws.begin();  /* taps of the next chunk go out right AFTER the barrier: a whole */    \
-      if (KC_ < 7) taps_load(tz, t, KC_ + 1, q, raw);   /* stage passes before the next vmcnt(0)        */    \
-      stage_compute<0>(cur, bop, net);                                                                        \
-    }                                                                                                         \
-    stage_mma<1>(ws, bop, net);                                                                               \
-    stage_mma<2>(ws, bop, net);                                                                               \
-    stage_mma<3>(ws, bop, net);                                                                               \
+  {
+    HoistNext<0> h0{raw, t, x, bopA};
+#define DINER_H0(S_) h0.template run<S_, 0>(); h0.template run<S_, 1>(); h0.template run<S_, 2>(); h0.template run<S_, 3>();
+    DINER_H0(0) DINER_H0(1) DINER_H0(2) DINER_H0(3) DINER_H0(4) DINER_H0(5) DINER_H0(6) DINER_H0(7)
+    DINER_H0(8) DINER_H0(9) DINER_H0(10) DINER_H0(11) DINER_H0(12) DINER_H0(13) DINER_H0(14) DINER_H0(15)
+#undef DINER_H0
   }
-  DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
+#define DINER_KC(KC_, CUR, NXT)                                                    \
+  {                                                                                \
+    if constexpr ((KC_) < 7) {                                                     \
+      TapsIssue<((KC_) < 7 ? (KC_) + 1 : 7)> ti{tz, t, q, raw};                    \
+      stage_mma_hook<0>(ws, CUR, net, ti);                                         \
+    } else {                                                                       \
+      stage_mma<0>(ws, CUR, net);                                                  \
+    }                                                                              \
+    stage_mma<1>(ws, CUR, net);                                                    \
+    stage_mma<2>(ws, CUR, net);                                                    \
+    if constexpr ((KC_) < 7) {                                                     \
+      HoistNext<((KC_) < 7 ? (KC_) + 1 : 7)> hk{raw, t, x, NXT};                   \
+      stage_mma_hook<3>(ws, CUR, net, hk);                                         \
+    } else {                                                                       \
+      stage_mma<3>(ws, CUR, net);                                                  \
+    }                                                                              \
+  }
+  DINER_KC(0, bopA, bopB) DINER_KC(1, bopB, bopA) DINER_KC(2, bopA, bopB) DINER_KC(3, bopB, bopA)
+  DINER_KC(4, bopA, bopB) DINER_KC(5, bopB, bopA) DINER_KC(6, bopA, bopB) DINER_KC(7, bopB, bopA)
 #undef DINER_KC
 }
+
+// hook: explicit rows (hoist kernel): load the next 64 inputs of the row in step 0, copy them to B operands in step 8+
+template <int KCN>
+struct RowsNext {
+  const float* __restrict__ row;
+  int q;
+  f32x4 (&raw)[4];
+  float (&bop)[16];
+  template <int STEP, int PIECE>
+  __device__ __forceinline__ void run() {
+    if constexpr (STEP < 4 && PIECE == 0)
+      raw[STEP] = *reinterpret_cast<const f32x4*>(row + 64 * KCN + 16 * STEP + 4 * q);
+  }
+};
 
 // dst += W . row   for an explicit 512-float row per lane-column (the hoist kernel): B operands straight from memory
 __device__ __forceinline__ void layer_from_rows(WeightStream& ws, const float* __restrict__ row, int q,
                                                 f32x4 (&dst)[kTiles]) {
   f32x4 raw[4];
+  float bopA[16], bopB[16];
 #pragma unroll
   for (int ml = 0; ml < 4; ++ml) raw[ml] = *reinterpret_cast<const f32x4*>(row + 16 * ml + 4 * q);
-#define DINER_KC(KC_)                                                                                         \
-  {                                                                                                           \
-    float bop[16];                                                                                            \
-    _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                          \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) bop[4 * ml + r] = raw[ml][r];                             \
-    {                                                                                                         \
-      const f32x4* cur = ws.begin();                                                                          \
-      if (KC_ < 7) {                                                                                          \
-        _Pragma("unroll") for (int ml = 0; ml < 4; ++ml)                                                      \
-          raw[ml] = *reinterpret_cast<const f32x4*>(row + 64 * (KC_ + 1) + 16 * ml + 4 * q);                  \
-      }                                                                                                       \
-      stage_compute<0>(cur, bop, dst);                                                                        \
-    }                                                                                                         \
-    stage_mma<1>(ws, bop, dst);                                                                               \
-    stage_mma<2>(ws, bop, dst);                                                                               \
-    stage_mma<3>(ws, bop, dst);                                                                               \
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bopA[i] = raw[i >> 2][i & 3];
+#define DINER_KC(KC_, CUR, NXT)                                                    \
+  {                                                                                \
+    if constexpr ((KC_) < 7) {                                                     \
+      RowsNext<((KC_) < 7 ? (KC_) + 1 : 7)> rn{row, q, raw, NXT};                  \
+      stage_mma_hook<0>(ws, CUR, dst, rn);                                         \
+    } else {                                                                       \
+      stage_mma<0>(ws, CUR, dst);                                                  \
+    }                                                                              \
+    stage_mma<1>(ws, CUR, dst);                                                    \
+    stage_mma<2>(ws, CUR, dst);                                                    \
+    stage_mma<3>(ws, CUR, dst);                                                    \
+    if constexpr ((KC_) < 7) {                                                     \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) NXT[i] = raw[i >> 2][i & 3];  \
+    }                                                                              \
   }
-  DINER_KC(0) DINER_KC(1) DINER_KC(2) DINER_KC(3) DINER_KC(4) DINER_KC(5) DINER_KC(6) DINER_KC(7)
+  DINER_KC(0, bopA, bopB) DINER_KC(1, bopB, bopA) DINER_KC(2, bopA, bopB) DINER_KC(3, bopB, bopA)
+  DINER_KC(4, bopA, bopB) DINER_KC(5, bopB, bopA) DINER_KC(6, bopA, bopB) DINER_KC(7, bopB, bopA)
 #undef DINER_KC
 }
 
@@ -547,6 +691,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
     // ---- lin_out (one stage: 16 padded output rows x 512)                       (resnetfc.py:158)
     {
       const f32x4* st4 = ws.begin();
+      stage_prefetch(ws.dma_src, ws.dma_dst, wave, lane);      // DMA of the stage after lin_out (no step loop here)
       f32x4 o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
