@@ -51,6 +51,8 @@ SIGNATURES = {
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_posenc_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                    C.c_void_p]),
+    "diner_set_precision": (C.c_int, [C.c_int]),
+    "diner_get_precision": (C.c_int, []),
     "diner_profile_enable": (C.c_int, [C.c_int]),
     "diner_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                         C.POINTER(C.c_longlong)]),

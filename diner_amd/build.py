@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libdiner_hip.so")
-SOURCES = ["api.cpp", "sampler.hip", "composite.hip", "stage_ops.hip", "mlp.hip"]
+SOURCES = ["api.cpp", "sampler.hip", "composite.hip", "stage_ops.hip", "mlp.hip", "mlp_h3.hip"]
 # -ffp-contract=off: every fp32 op of the geometry path rounds where the reference's torch ops round;
 # fused multiply-adds are written explicitly (fmaf / MFMA) where they are wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value",
@@ -56,7 +56,8 @@ def build_variant(name, defines, verbose=False):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    deps = [os.path.join(CSRC, "common.hpp"), os.path.join(ROOT, "include", "diner_hip.h")]
+    deps = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "field_common.hpp"),
+            os.path.join(ROOT, "include", "diner_hip.h")]
     hipcc = _hipcc()
     objs = []
     for src in SOURCES:

@@ -32,23 +32,9 @@
 //    the hand-over is 8 KB/point of pre-mean activations stored in accumulator layout (coalesced 1 KB
 //    wave stores).
 #include <vector>
-#include "common.hpp"
+#include "field_common.hpp"
 
 namespace diner {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kHidden = 512;
-constexpr int kLatent = 512;
-constexpr int kDIn = 55;
-constexpr int kDInPad = 64;
-constexpr int kTiles = kHidden / 16;          // 32 accumulator tiles of 16 features
-constexpr int kStageFloats = 8192;            // 32 KB: 128 output features x 64 k
-constexpr int kStagesPerLayer = 32;           // 8 k-chunks x 4 feature groups
-constexpr int kHoistStages = 3 * kStagesPerLayer;          // lin_z[0..2]                      =  96
-constexpr int kPreStages = 4 + 3 * 2 * kStagesPerLayer;    // lin_in + 3 x (fc_0, fc_1)        = 196
-constexpr int kPostStages = 2 * 2 * kStagesPerLayer + 1;   // 2 x (fc_0, fc_1) + lin_out      = 129
-constexpr int kPtsPerWave = 16;
 
 struct DinerMlpImpl {
   float* w_hoist;  // kHoistStages x 8192 floats, stage-tile order: lin_z[0], lin_z[1], lin_z[2]
@@ -57,7 +43,20 @@ struct DinerMlpImpl {
   float* b_hoist;  // lin_z biases, 3 x 512
   float* b_pre;    // lin_in, then per block b<3: fc_0, fc_1  -> 7 x 512
   float* b_post;   // per block b=3,4: fc_0, fc_1 -> 4 x 512, then lin_out (4, padded to 16)
+  // split-precision (f16x3) copies, see mlp_h3.hip: same stage structure, fp16 hi/lo fragments, x16 pre-scaled
+  float* h3_w_pre;
+  float* h3_w_post;
+  float* h3_b_pre;
+  float* h3_b_post;
 };
+
+// mlp_h3.hip
+int h3_pack(const DinerMlpParams* p, hipStream_t stream, float** w_pre, float** w_post, float** b_pre, float** b_post);
+int h3_set_attributes(size_t lds_bytes);
+void h3_launch_pre(const SceneDev& sc, const FieldArgs& fa, int grid, size_t lds_bytes, hipStream_t stream);
+void h3_launch_post(const PostArgs& pa, int grid, size_t lds_bytes, hipStream_t stream);
+
+static int g_precision = 0;   // 0: exact fp32 MFMA (default), 1: f16x3 split products
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing (runs once per parameter version, on the device)
@@ -97,71 +96,6 @@ typedef __attribute__((address_space(3))) float lds_float;
 // contiguous pieces 8w..8w+7.  The instruction's immediate offset applies to the global AND the LDS address, so one
 // address / M0 pair covers four pieces.  Piece j of a wave is issued from step j of the stage (see stage_compute):
 // the DMA is spread over the first half of the stage instead of an 8-instruction burst after the barrier.
-// Timing-experiment switches (tools/ablate.sh): DINER_ABL_NO_DMA / _NO_BARRIER / _NO_LDS remove one ingredient of the
-// stage loop to price it.  Results are WRONG when any is set; the shipped library is built with none.
-template <int J>
-__device__ __forceinline__ void stage_dma_piece(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
-#ifdef DINER_ABL_NO_DMA
-  return;
-#endif
-  constexpr int h = J >> 2, o = (J & 3) * 1024;
-  const __attribute__((address_space(1))) void* g =
-      (const __attribute__((address_space(1))) void*)(gsrc + wave * 2048 + lane * 4 + h * 1024);
-  __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(lds_dst + wave * 2048 + h * 1024);
-  __builtin_amdgcn_global_load_lds(g, l, 16, o, 0);
-}
-__device__ __forceinline__ void stage_prefetch(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
-  stage_dma_piece<0>(gsrc, lds_dst, wave, lane);
-  stage_dma_piece<1>(gsrc, lds_dst, wave, lane);
-  stage_dma_piece<2>(gsrc, lds_dst, wave, lane);
-  stage_dma_piece<3>(gsrc, lds_dst, wave, lane);
-  stage_dma_piece<4>(gsrc, lds_dst, wave, lane);
-  stage_dma_piece<5>(gsrc, lds_dst, wave, lane);
-  stage_dma_piece<6>(gsrc, lds_dst, wave, lane);
-  stage_dma_piece<7>(gsrc, lds_dst, wave, lane);
-}
-
-// The weight stream of a persistent workgroup: a fixed cyclic sequence of 32 KB stages flowing through a
-// double-buffered LDS ring.  While stage s is consumed, the DMA of stage s+1 is issued (pieces spread over the
-// first 8 steps of stage s) and has the rest of the stage (> 2000 matrix-pipe cycles) to land.
-constexpr int kRing = 2;
-
-struct WeightStream {
-  const float* base;   // packed stages in global memory
-  float* lds;          // kRing x kStageFloats
-  int n_stages;
-  int issue;           // index (in the cyclic sequence) of the stage whose DMA is issued during the current stage
-  int slot;            // ring slot of the stage about to be consumed
-  int wave, lane;
-  const float* dma_src;   // set by begin(): source / destination of the DMA pieces of this stage
-  float* dma_dst;
-
-  __device__ __forceinline__ void start() {
-    stage_prefetch(base, lds, wave, lane);
-    issue = n_stages > 1 ? 1 : 0;
-    slot = 0;
-  }
-  // Begin consuming the stage in `slot`: one barrier per stage publishes it (every wave has waited for its own DMA
-  // pieces) and retires the previous stage, whose slot then receives the DMA of the next one.
-  __device__ __forceinline__ const f32x4* begin() {
-#ifndef DINER_ABL_NO_BARRIER
-    __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): everything outstanding is at least half a stage old
-    __syncthreads();
-#endif
-    dma_src = base + (size_t)issue * kStageFloats;
-    dma_dst = lds + (slot ^ 1) * kStageFloats;
-    issue = (issue + 1 == n_stages) ? 0 : issue + 1;
-    const f32x4* cur = reinterpret_cast<const f32x4*>(lds + slot * kStageFloats) + lane;
-    slot ^= 1;
-    return cur;
-  }
-  template <int STEP>
-  __device__ __forceinline__ void dma_step() {
-    if constexpr (STEP < 8) stage_dma_piece<STEP>(dma_src, dma_dst, wave, lane);
-  }
-  __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
-};
-
 // one 32 KB stage = 128 output features (accumulators acc[8 mg .. 8 mg+7]) x 64 k (B operands bop[0..15]).
 // The stage is walked in 16 steps of 8 MFMAs: step (ml, mp) multiplies the two A fragments (mo = 2 mp, 2 mp + 1)
 // of k-group ml into their two accumulators, alternating between them so that back-to-back MFMAs never hit the
@@ -322,21 +256,6 @@ __device__ __forceinline__ void layer_from_acc(WeightStream& ws, const f32x4 (&s
 #undef DINER_KC
 }
 
-// bilinear taps of one (point, view): float offsets into a channels-last (.., 512) map + blend weights
-struct Taps {
-  size_t off[4];
-  float w[4];
-};
-
-__device__ __forceinline__ void taps_load(const float* __restrict__ map, const Taps& t, int kc, int q,
-                                          f32x4 (&raw)[16]) {
-#pragma unroll
-  for (int tap = 0; tap < 4; ++tap)
-#pragma unroll
-    for (int ml = 0; ml < 4; ++ml)
-      raw[tap * 4 + ml] = *reinterpret_cast<const f32x4*>(map + t.off[tap] + 64 * kc + 16 * ml + 4 * q);
-}
-
 // hook: chunk KCN of the hoisted layer: blend the 4 taps of the projected map (step 4 ml), add into the residual
 // stream (4 ml + 1), relu -> B operands (4 ml + 2, 4 ml + 3)
 template <int KCN>
@@ -454,47 +373,6 @@ __device__ __forceinline__ void layer_from_rows(WeightStream& ws, const float* _
 #undef DINER_KC
 }
 
-// MLP input feature f of [x_c(3), 36 sin/cos of x_c, R d (3), dd, 12 sin/cos of dd]  (pixelnerf.py:96-128)
-__device__ __forceinline__ float input_feature(int f, const float* xc, const float* vd, float dd) {
-  float arg;
-  int j;
-  if (f < 3) return f == 0 ? xc[0] : (f == 1 ? xc[1] : xc[2]);
-  if (f < 39) {
-    j = (f - 3) / 3;
-    const int d = (f - 3) - 3 * j;
-    arg = d == 0 ? xc[0] : (d == 1 ? xc[1] : xc[2]);
-  } else if (f < 42) {
-    return f == 39 ? vd[0] : (f == 40 ? vd[1] : vd[2]);
-  } else if (f == 42) {
-    return dd;
-  } else if (f < kDIn) {
-    j = f - 43;
-    arg = dd;
-  } else {
-    return 0.0f;
-  }
-  const float freq = __fmul_rn(6.28f, (float)(1 << (j >> 1)));                  // positional_encoding.py:18
-  const float phase = (j & 1) ? 1.57079637050628662109375f : 0.0f;               // fp32(pi/2), :30
-  return sin_posenc(__fmaf_rn(arg, freq, phase));                                 // addcmul is fused, :46
-}
-
-struct FieldArgs {
-  // point source: (rays, z) with K samples per ray, or explicit xyz / viewdirs, or a pre-split zx matrix
-  const float* rays;
-  const float* z;
-  const float* xyz;
-  const float* viewdirs;
-  const float* direct_feat;     // (NV*P, 64)   explicit MLP inputs (ResnetFC.forward on a matrix); tz rows = (3, NV*P, 512)
-  const float* tz;              // hoisted projections: (3, NV, Hf, Wf, 512) of the scene, or (3, NV*P, 512) rows
-  size_t tz_stride;             // floats between lin_z[b] and lin_z[b+1] maps
-  long long P;
-  int K;
-  float freq_factor;
-  const float* w_pre;
-  const float* b_pre;
-  float* xpre;                  // (P/16 tiles, NV, 32, 64) f32x4
-};
-
 __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -517,64 +395,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
                                                         // into a workspace padded to a multiple of 16 points
     Taps taps;
     float feat[16];
-    if (a.direct_feat) {
-      taps.off[0] = taps.off[1] = taps.off[2] = taps.off[3] = ((size_t)v * a.P + p) * kLatent;
-      taps.w[0] = 1.0f;
-      taps.w[1] = taps.w[2] = taps.w[3] = 0.0f;
-      const float* fr = a.direct_feat + ((size_t)v * a.P + p) * kDInPad;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(fr + 16 * m + 4 * q);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) feat[4 * m + r] = t4[r];
-      }
-    } else {
-      float px, py, pz, dx, dy, dz;
-      if (a.xyz) {
-        px = a.xyz[p * 3 + 0]; py = a.xyz[p * 3 + 1]; pz = a.xyz[p * 3 + 2];
-        dx = a.viewdirs[p * 3 + 0]; dy = a.viewdirs[p * 3 + 1]; dz = a.viewdirs[p * 3 + 2];
-      } else {
-        const long long ray = p / a.K;
-        const float* r = a.rays + ray * 8;
-        const float zz = a.z[p];
-        dx = r[3]; dy = r[4]; dz = r[5];
-        px = __fadd_rn(r[0], __fmul_rn(zz, dx));                                 // nerf_renderer.py:304
-        py = __fadd_rn(r[1], __fmul_rn(zz, dy));
-        pz = __fadd_rn(r[2], __fmul_rn(zz, dz));
-      }
-      float xc[3], vd[3];
-      world_to_cam(sc.R[v], sc.t[v], px, py, pz, xc[0], xc[1], xc[2]);           // pixelnerf.py:91-93
-      vd[0] = rot_row(sc.R[v] + 0, dx, dy, dz);                                  // :100
-      vd[1] = rot_row(sc.R[v] + 3, dx, dy, dz);
-      vd[2] = rot_row(sc.R[v] + 6, dx, dy, dz);
-      const float u = project_axis(xc[0], xc[2], sc.focal[v][0], sc.c[v][0], sc.img_w);   // :105-108
-      const float w = project_axis(xc[1], xc[2], sc.focal[v][1], sc.c[v][1], sc.img_h);
-      // nearest depth tap -> distance-to-depth code (:114-116)
-      const int ix = nearest_border(u, sc.Ws), iy = nearest_border(w, sc.Hs);
-      const float dd = __fsub_rn(sc.depth[(size_t)v * sc.Hs * sc.Ws + (size_t)iy * sc.Ws + ix], xc[2]);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) feat[4 * m + r] = input_feature(16 * m + 4 * q + r, xc, vd, dd);
-      // bilinear / border taps on the padded feature map (image_encoder.py:112-123)
-      const int Wf = sc.Wf, Hf = sc.Hf;
-      const float su = __fmul_rn(u, __fdiv_rn(__fsub_rn((float)Wf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Wf));
-      const float sv = __fmul_rn(w, __fdiv_rn(__fsub_rn((float)Hf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Hf));
-      const float fx = clip_border(unnormalize(su, Wf), Wf), fy = clip_border(unnormalize(sv, Hf), Hf);
-      const float x0f = floorf(fx), y0f = floorf(fy);
-      const float wx = fx - x0f, wy = fy - y0f;
-      const int x0 = (int)x0f, y0 = (int)y0f;
-      const int x1 = min(x0 + 1, Wf - 1), y1 = min(y0 + 1, Hf - 1);
-      const size_t base = (size_t)v * Hf * Wf;
-      taps.off[0] = (base + (size_t)y0 * Wf + x0) * kLatent;
-      taps.off[1] = (base + (size_t)y0 * Wf + x1) * kLatent;
-      taps.off[2] = (base + (size_t)y1 * Wf + x0) * kLatent;
-      taps.off[3] = (base + (size_t)y1 * Wf + x1) * kLatent;
-      taps.w[0] = (1.0f - wy) * (1.0f - wx);
-      taps.w[1] = (1.0f - wy) * wx;
-      taps.w[2] = wy * (1.0f - wx);
-      taps.w[3] = wy * wx;
-    }
+    field_frontend(sc, a, v, q, p, taps, feat);
 
     f32x4 x[kTiles], net[kTiles];
     // ---- lin_in: x = W_in f + b_in                                             (resnetfc.py:141)
@@ -638,16 +459,6 @@ __global__ __launch_bounds__(256, 1) void k_hoist_linz(HoistArgs a) {
   }
   ws.drain();
 }
-
-struct PostArgs {
-  const float* xpre;
-  const float* w_post;
-  const float* b_post;
-  float* out;          // (P, 4)
-  long long P;
-  int nv;
-  int raw;             // 1: ResnetFC.forward output; 0: sigmoid(rgb), relu(sigma) (pixelnerf.py:139-143)
-};
 
 __global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -768,10 +579,13 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int rc = h3_set_attributes(lds_bytes);
+    if (rc) return rc;
     attr_set = true;
   }
-  fa.w_pre = m->w_pre;
-  fa.b_pre = m->b_pre;
+  const bool use_h3 = g_precision == 1 && !fa.direct_feat;
+  fa.w_pre = use_h3 ? m->h3_w_pre : m->w_pre;
+  fa.b_pre = use_h3 ? m->h3_b_pre : m->b_pre;
   fa.xpre = (float*)workspace;
   fa.freq_factor = 6.28f;
   const long long n_t16 = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
@@ -790,13 +604,16 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     DINER_HIP_OK(hipEventCreate(&e2));
     DINER_HIP_OK(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), lds_bytes, stream, *sc, fa);
+  if (use_h3) h3_launch_pre(*sc, fa, grid_pre, lds_bytes, stream);
+  else hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), lds_bytes, stream, *sc, fa);
   DINER_LAUNCH_OK();
   if (g_timer.enabled) DINER_HIP_OK(hipEventRecord(e1, stream));
-  PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw};
+  PostArgs pa{(const float*)workspace, use_h3 ? m->h3_w_post : m->w_post, use_h3 ? m->h3_b_post : m->b_post, out, fa.P,
+              nv, raw};
   const long long n_tiles = (n_t16 + 3) / 4;
   const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
-  hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), lds_bytes, stream, pa);
+  if (use_h3) h3_launch_post(pa, grid_post, lds_bytes, stream);
+  else hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), lds_bytes, stream, pa);
   DINER_LAUNCH_OK();
   if (g_timer.enabled) {
     DINER_HIP_OK(hipEventRecord(e2, stream));
@@ -876,6 +693,10 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
     bias(p->fc0_b[b], kHidden, kHidden, bb);
     bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
   }
+  {
+    int rc = h3_pack(p, stream, &m->impl.h3_w_pre, &m->impl.h3_w_post, &m->impl.h3_b_pre, &m->impl.h3_b_post);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_pack_lin_out, dim3(32), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, wp);
   bias(p->lin_out_b, 4, 16, m->impl.b_post + 4 * kHidden);
   DINER_LAUNCH_OK();
@@ -891,9 +712,20 @@ extern "C" int diner_mlp_destroy(DinerMlp* m) {
   hipFree(m->impl.b_hoist);
   hipFree(m->impl.b_pre);
   hipFree(m->impl.b_post);
+  hipFree(m->impl.h3_w_pre);
+  hipFree(m->impl.h3_w_post);
+  hipFree(m->impl.h3_b_pre);
+  hipFree(m->impl.h3_b_post);
   delete m;
   return 0;
 }
+
+extern "C" int diner_set_precision(int mode) {
+  DINER_CHECK_ARG(mode == 0 || mode == 1, "set_precision: mode must be 0 (fp32) or 1 (f16x3), got %d", mode);
+  g_precision = mode;
+  return 0;
+}
+extern "C" int diner_get_precision(void) { return g_precision; }
 
 extern "C" int diner_profile_enable(int enable) {
   g_timer.enabled = enable != 0;

@@ -342,3 +342,19 @@ def profile_collect():
     a, b, n, p = C.c_double(), C.c_double(), C.c_longlong(), C.c_longlong()
     _lib.check(lib.diner_profile_collect(C.byref(a), C.byref(b), C.byref(n), C.byref(p)))
     return dict(pre_ms=a.value, post_ms=b.value, launches=n.value, points=p.value)
+
+
+PRECISION_FP32, PRECISION_F16X3 = 0, 1
+
+
+def set_precision(mode):
+    """0: exact fp32 MFMA (default); 1: f16x3 split products (see include/diner_hip.h)."""
+    _lib.check(lib.diner_set_precision(int(mode)))
+
+
+def get_precision():
+    return int(lib.diner_get_precision())
+
+
+if os.environ.get("DINER_AMD_PRECISION", "").lower() in ("f16x3", "1"):
+    set_precision(PRECISION_F16X3)
