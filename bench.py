@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0      # same guide, dense fp16/bf16 matrix peak (AMD's 5 PF figure is 2:1 sparse)
 
 
 def parse():
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--candidates", type=int, default=1000)
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays of the CPU baseline sample (0 disables; -1 auto)")
     ap.add_argument("--ray-batch", type=int, default=8192, help="rays per launch group (bounds the workspace)")
+    ap.add_argument("--precision", choices=["f16x3", "fp32"], default=None,
+                    help="MLP GEMM arithmetic (default: the library default, f16x3 split products)")
     return ap.parse_args()
 
 
@@ -69,6 +72,9 @@ def main():
     from src.util.depth2normal import depth2normal
     from src.util.cam_geometry import gen_rays
 
+    if args.precision:
+        ops.set_precision(ops.PRECISION_F16X3 if args.precision == "f16x3" else ops.PRECISION_FP32)
+    h3 = ops.get_precision() == ops.PRECISION_F16X3
     W, H, K = args.width, args.height, args.samples
     G = int(15 * K / 40)                           # create_prediction_folder.py:44-47
     n_cand = args.candidates
@@ -132,23 +138,31 @@ def main():
     rays_per_s = total_rays / elapsed
     # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------------------
     pre_s = prof["pre_ms"] * 1e-3
-    flop_pre = prof["points"] * ops.FLOP_PRE_PER_POINT                 # FLOPs the kernel executes (lin_z hoisted)
+    # FLOPs the dominant kernel executes per point: lin_z hoisted; with f16x3 every fp32 product is three fp16 MFMA products
+    mfma_per_product = 3 if h3 else 1
+    flop_pre = prof["points"] * ops.FLOP_PRE_PER_POINT * mfma_per_product
+    peak = PEAK_F16_MFMA_TFLOPS if h3 else PEAK_FP32_MFMA_TFLOPS
     achieved = flop_pre / pre_s / 1e12 if pre_s > 0 else 0.0
+    fp32_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT / pre_s / 1e12 if pre_s > 0 else 0.0
     ref_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT_REFERENCE / pre_s / 1e12 if pre_s > 0 else 0.0
     # HBM traffic per launch: bytes/point measured with rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, committed profile)
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            traffic = round(json.load(f)["k_field_pre_hbm_bytes_per_point"] * prof["points"] / max(prof["launches"], 1))
+            key = "k_field_pre_h3_hbm_bytes_per_point" if h3 else "k_field_pre_hbm_bytes_per_point"
+            traffic = round(json.load(f)[key] * prof["points"] / max(prof["launches"], 1))
     except Exception:
         pass
-    roofline = {"bound": "mfma", "kernel": "k_field_pre", "achieved": round(achieved, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+    roofline = {"bound": "mfma", "kernel": "k_field_pre_h3" if h3 else "k_field_pre",
+                "mfma_dtype": "f16 (3 MFMA products per fp32 product, fp32 accumulate)" if h3 else "f32",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_latest.json)",
                 "launches": prof["launches"],
-                "flop_per_point_executed": ops.FLOP_PRE_PER_POINT,
+                "flop_per_point_executed_fp32_products": ops.FLOP_PRE_PER_POINT,
                 "flop_per_point_reference": ops.FLOP_PRE_PER_POINT_REFERENCE,
+                "achieved_fp32_equivalent": round(fp32_equiv, 2),
                 "achieved_reference_flops": round(ref_equiv, 2),
+                "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
                 "avg_launch_ms": round(prof["pre_ms"] / max(prof["launches"], 1), 3),
                 "post_kernel_ms_total": round(prof["post_ms"], 2), "pre_kernel_ms_total": round(prof["pre_ms"], 2)}
 
@@ -197,10 +211,12 @@ def main():
             "metric": "rendered rays/sec (128 samples/ray, 4 src views)", "value": round(rays_per_s, 1),
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32 via f16x3 split MFMA products, fp32 accumulate" if h3 else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: synthetic 4-view scene, {W}x{H} target = {NR} rays per GPU per "
-                                   f"step, {K} samples/ray ({G} gaussian, {n_cand} candidates), fp32 MFMA MLP "
-                                   f"(d_hidden 512, 5 blocks), random-init weights, in-kernel Philox noise",
+                                   f"step, {K} samples/ray ({G} gaussian, {n_cand} candidates), MLP d_hidden 512 / 5 blocks "
+                                   f"({'f16x3 split-product' if h3 else 'exact fp32'} MFMA GEMMs), random-init weights, "
+                                   f"in-kernel Philox noise",
                        "rays_per_step_per_gpu": NR, "samples_per_ray": K, "src_views": 4,
                        "parallelism": f"ray-shard x{world}, RCCL gather of (rgb,depth) tiles"},
             "roofline": roofline,

@@ -173,6 +173,9 @@ class HipMlp:
             self._arrays[name] = arr
             setattr(p, name, C.cast(arr, C.POINTER(C.c_void_p)))
         self.device = keep["lin_in_w"].device
+        # f16x3 runs the network at 16x scale in fp16 hi/lo parts: weights must stay far inside the fp16 range
+        wmax = max(float(t.abs().max()) for t in list(keep.values()) + [t for l in lists.values() for t in l])
+        self.h3_ok = bool(np.isfinite(wmax) and wmax < 1024.0)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(lib.diner_mlp_create(C.byref(p), _stream(), C.byref(h)))
@@ -226,6 +229,20 @@ def fill_uniform(z_in, rays, noise_fill=None, seed=0):
     return out
 
 
+_requested_precision = [None]
+
+
+def _apply_precision(mlp):
+    """The library switch is process-wide; honour the requested mode unless this MLP's weights are outside the range
+    the fp16 split supports (then the exact fp32 kernels are used for it)."""
+    want = _requested_precision[0]
+    if want is None:
+        return
+    eff = want if (want == 0 or mlp.h3_ok) else 0
+    if lib.diner_get_precision() != eff:
+        _lib.check(lib.diner_set_precision(eff))
+
+
 def _workspace(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
@@ -236,6 +253,7 @@ def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z):
     rays, z = _f32c(rays), _f32c(z)
     NR, K = z.shape
     scene.prepare(mlp)
+    _apply_precision(mlp)
     out = torch.empty(NR, K, 4, device=rays.device, dtype=torch.float32)
     rays_per = max(1, MAX_POINTS_PER_LAUNCH // K)
     with torch.cuda.device(rays.device):
@@ -253,6 +271,7 @@ def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs):
     xyz, viewdirs = _f32c(xyz), _f32c(viewdirs)
     P = xyz.shape[0]
     scene.prepare(mlp)
+    _apply_precision(mlp)
     out = torch.empty(P, 4, device=xyz.device, dtype=torch.float32)
     step = MAX_POINTS_PER_LAUNCH
     with torch.cuda.device(xyz.device):
@@ -348,13 +367,21 @@ PRECISION_FP32, PRECISION_F16X3 = 0, 1
 
 
 def set_precision(mode):
-    """0: exact fp32 MFMA (default); 1: f16x3 split products (see include/diner_hip.h)."""
+    """0: exact fp32 MFMA; 1: f16x3 split products (see include/diner_hip.h).  Default: 1 (DINER_AMD_PRECISION)."""
     _lib.check(lib.diner_set_precision(int(mode)))
+    _requested_precision[0] = int(mode)
 
 
 def get_precision():
     return int(lib.diner_get_precision())
 
 
-if os.environ.get("DINER_AMD_PRECISION", "").lower() in ("f16x3", "1"):
+# Default arithmetic of the MLP GEMMs: f16x3 split products (fp32-class accuracy, measured 3e-6 end to end against the
+# reference, about twice the fp32 MFMA throughput).  DINER_AMD_PRECISION=fp32 selects the exact-fp32 MFMA kernels.
+_want = os.environ.get("DINER_AMD_PRECISION", "f16x3").lower()
+if _want in ("f16x3", "1", "split"):
     set_precision(PRECISION_F16X3)
+elif _want in ("fp32", "f32", "0", "exact"):
+    set_precision(PRECISION_FP32)
+else:
+    raise ValueError(f"DINER_AMD_PRECISION={_want!r}: expected 'f16x3' or 'fp32'")

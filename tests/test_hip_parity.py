@@ -28,6 +28,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=["f16x3", "fp32"])
+def precision(request, ops):
+    """Both arithmetic modes of the MLP GEMMs are held to the same tolerances."""
+    prev = ops.get_precision()
+    ops.set_precision(ops.PRECISION_F16X3 if request.param == "f16x3" else ops.PRECISION_FP32)
+    yield request.param
+    ops.set_precision(prev)
+
+
 def hip_scene(ops, sc):
     K = sc["src_intrinsics"]
     return ops.HipScene(sc["latent"].cuda(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(),
@@ -126,17 +135,17 @@ def test_mlp_forward(ops):
     assert rel < TOL_STAGE
 
 
-def test_pixelnerf_forward(ops):
+def test_pixelnerf_forward(ops, precision):
     g = load("g6_pixelnerf.npz")
     sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
     hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
     out = ops.field_from_points(hs, hm, T(g["pts"]).cuda(), T(g["dirs"]).cuda()).cpu()
     rel = max_norm_rel(out, g["out"])
-    print(f"PixelNeRF.forward (512 pts) max-norm-rel vs reference {rel:.3e}")
+    print(f"PixelNeRF.forward (512 pts) [{precision}] max-norm-rel vs reference {rel:.3e}")
     assert rel < TOL_STAGE
 
 
-def test_composite_and_render(ops):
+def test_composite_and_render(ops, precision):
     g = load("g7_composite.npz")
     sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
     assert sha(sc["latent"], sc["depths"], sc["depths_std"], scene.normals, sc["src_extrinsics"],
@@ -156,7 +165,7 @@ def test_composite_and_render(ops):
             assert rel < TOL
 
 
-def test_render_cfg1_end_to_end(ops):
+def test_render_cfg1_end_to_end(ops, precision):
     """BASELINE.json configs[0]: 64x64 target, 64 samples/ray, 4 source views, against the reference's output.
 
     Two statements: (1) with the reference's own sample positions the renderer matches on EVERY ray;
@@ -183,7 +192,7 @@ def test_render_cfg1_end_to_end(ops):
     # (1) reference z -> HIP field + compositor
     wts, rgb, depth = ops.render(hs, hm, rc, ref_z.cuda(), False, want_weights=True)
     e_rgb, e_d = errs(rgb, depth)
-    print(f"e2e cfg1, reference z : rgb max-norm-rel {e_rgb.max().item():.3e}, depth {e_d.max().item():.3e}")
+    print(f"e2e cfg1 [{precision}], reference z : rgb max-norm-rel {e_rgb.max().item():.3e}, depth {e_d.max().item():.3e}")
     assert e_rgb.max().item() < TOL and e_d.max().item() < TOL
     np.testing.assert_allclose(wts.cpu().sum(-1).numpy(), g["weights_sum"], atol=2e-5)
     # (2) HIP sampler -> HIP field + compositor
@@ -199,7 +208,7 @@ def test_render_cfg1_end_to_end(ops):
     assert e_rgb[same].max().item() < TOL and e_d[same].max().item() < TOL
 
 
-def test_ray_batch_split_invariance(ops):
+def test_ray_batch_split_invariance(ops, precision):
     """diner.py:85 splits rays into batches; results must not depend on the split (bit-exact)."""
     sc, scene, w, msd, rays = oracle_setup(32, 32, 3)
     hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
@@ -236,7 +245,7 @@ def test_philox_sampler_statistics(ops):
         assert (ze >= edges[:-1] - 1e-5).all() and (ze <= edges[1:] + 1e-5).all()
 
 
-def test_k192_against_oracle(ops):
+def test_k192_against_oracle(ops, precision):
     """BASELINE configs[4] samples 192 points per ray (72 gaussian): no reference fixture at that size, so compare with
     the CPU oracle (pinned bit-exact against the reference on the other sizes) on a few hundred rays."""
     sc, scene, w, msd, rays = oracle_setup(40, 32, 5)
