@@ -84,6 +84,54 @@ struct WeightStream {
   __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 };
 
+// Deeper ring for kernels whose stages are short compared with the L2 / Infinity-Cache latency (the f16x3 kernels: a
+// stage lasts ~1 us): RING slots, the DMA of stage k + RING - 1 is issued during stage k.  At the start of stage k only
+// the pieces of stage k must have landed; the 8 (RING - 2) younger DMA instructions of this wave (stages k+1 ..) stay
+// in flight, hence a COUNTED vmcnt (any other younger VMEM instruction only makes the wait more conservative) and a RAW
+// s_barrier (__syncthreads() would drain the LDS-DMA queue).
+template <int RING>
+struct WeightStreamDeep {
+  static constexpr int D = RING - 1;
+  const float* base;
+  float* lds;
+  int n_stages;
+  int issue;
+  int slot;
+  int wave, lane;
+  const float* dma_src;
+  float* dma_dst;
+
+  __device__ __forceinline__ void start() {
+    issue = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      stage_prefetch(base + (size_t)issue * kStageFloats, lds + d * kStageFloats, wave, lane);
+      issue = (issue + 1 == n_stages) ? 0 : issue + 1;
+    }
+    slot = 0;
+  }
+  __device__ __forceinline__ const f32x4* begin() {
+#ifndef DINER_ABL_NO_BARRIER
+    constexpr int keep = 8 * (D - 1);
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (keep & 15) | ((keep >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+#endif
+    int sd = slot + D;
+    if (sd >= RING) sd -= RING;
+    dma_src = base + (size_t)issue * kStageFloats;
+    dma_dst = lds + sd * kStageFloats;
+    issue = (issue + 1 == n_stages) ? 0 : issue + 1;
+    const f32x4* cur = reinterpret_cast<const f32x4*>(lds + slot * kStageFloats) + lane;
+    slot = (slot + 1 == RING) ? 0 : slot + 1;
+    return cur;
+  }
+  template <int STEP>
+  __device__ __forceinline__ void dma_step() {
+    if constexpr (STEP < 8) stage_dma_piece<STEP>(dma_src, dma_dst, wave, lane);
+  }
+  __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+};
+
 // bilinear taps of one (point, view): float offsets into a channels-last (.., 512) map + blend weights
 struct Taps {
   size_t off[4];

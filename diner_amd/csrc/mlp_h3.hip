@@ -17,6 +17,11 @@ namespace h3 {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+#ifndef DINER_H3_RING
+#define DINER_H3_RING 4
+#endif
+typedef WeightStreamDeep<DINER_H3_RING> WStream;     // 4 x 32 KB ring: DMA three stages (~3 us) ahead
+
 constexpr float kScale = 16.0f, kInvScale = 1.0f / 16.0f;
 
 // B operands of one 64-feature chunk: two k32 blocks, hi and lo parts (8 fp16 per lane each)
@@ -49,13 +54,19 @@ template <int STEP, int W>
 __device__ __forceinline__ h8 frag_addr(const h8* __restrict__ cur) {
   constexpr int tb = STEP >> 2, mp = STEP & 3;
   constexpr int mo = 2 * mp + (W >> 1), hl = W & 1;
+#ifdef DINER_ABL_NO_LDS
+  h8 r;
+  asm volatile("" : "=v"(r));
+  return r;
+#else
   return cur[((mo * 2 + tb) * 2 + hl) * 64];
+#endif
 }
 
 // One step = 6 MFMAs on two accumulators (2 row tiles x {hi*hi, lo*hi, hi*lo}); the four fragment reads of step
 // s+2, one LDS-DMA piece of the next stage and the hook's VALU go into the gaps.
 template <int MG, int STEP, class Hook>
-__device__ __forceinline__ void stage_step(WeightStream& ws, const h8* __restrict__ cur, const Frag& f, Frag& fnext,
+__device__ __forceinline__ void stage_step(WStream& ws, const h8* __restrict__ cur, const Frag& f, Frag& fnext,
                                            const BOp& bop, f32x4 (&acc)[kTiles], Hook& hook) {
   constexpr int tb = STEP >> 2, mp = STEP & 3;
   constexpr int a0 = 8 * MG + 2 * mp, a1 = a0 + 1;
@@ -98,7 +109,7 @@ __device__ __forceinline__ void stage_step(WeightStream& ws, const h8* __restric
 }
 
 template <int MG, class Hook>
-__device__ __forceinline__ void stage_compute(WeightStream& ws, const h8* __restrict__ cur, const BOp& bop,
+__device__ __forceinline__ void stage_compute(WStream& ws, const h8* __restrict__ cur, const BOp& bop,
                                               f32x4 (&acc)[kTiles], Hook& hook) {
   Frag fa, fb, fc;
   fa.v[0] = frag_addr<0, 0>(cur); fa.v[1] = frag_addr<0, 1>(cur); fa.v[2] = frag_addr<0, 2>(cur); fa.v[3] = frag_addr<0, 3>(cur);
@@ -110,12 +121,12 @@ __device__ __forceinline__ void stage_compute(WeightStream& ws, const h8* __rest
 }
 
 template <int MG>
-__device__ __forceinline__ void stage_mma(WeightStream& ws, const BOp& bop, f32x4 (&acc)[kTiles]) {
+__device__ __forceinline__ void stage_mma(WStream& ws, const BOp& bop, f32x4 (&acc)[kTiles]) {
   NoHook h;
   stage_compute<MG>(ws, reinterpret_cast<const h8*>(ws.begin()), bop, acc, h);
 }
 template <int MG, class Hook>
-__device__ __forceinline__ void stage_mma_hook(WeightStream& ws, const BOp& bop, f32x4 (&acc)[kTiles], Hook& hook) {
+__device__ __forceinline__ void stage_mma_hook(WStream& ws, const BOp& bop, f32x4 (&acc)[kTiles], Hook& hook) {
   stage_compute<MG>(ws, reinterpret_cast<const h8*>(ws.begin()), bop, acc, hook);
 }
 
@@ -151,7 +162,7 @@ struct ReluNext {
   }
 };
 
-__device__ __forceinline__ void layer_from_acc(WeightStream& ws, const f32x4 (&src)[kTiles], f32x4 (&dst)[kTiles]) {
+__device__ __forceinline__ void layer_from_acc(WStream& ws, const f32x4 (&src)[kTiles], f32x4 (&dst)[kTiles]) {
   BOp bopA, bopB;
   bops_relu<0>(src, bopA);
 #define DINER_KC(KC_, CUR, NXT)                                       \
@@ -210,7 +221,7 @@ struct TapsIssue {
   }
 };
 
-__device__ __forceinline__ void layer_fc0_hoisted(WeightStream& ws, const float* __restrict__ tz, const Taps& t, int q,
+__device__ __forceinline__ void layer_fc0_hoisted(WStream& ws, const float* __restrict__ tz, const Taps& t, int q,
                                                   f32x4 (&x)[kTiles], f32x4 (&net)[kTiles]) {
   f32x4 raw[16];
   BOp bopA, bopB;
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3(SceneDev sc, FieldArgs 
   const int q = lane >> 4, pt = lane & 15;
   const int v = wave;
   const long long n_tiles = (a.P + kPtsPerWave - 1) / kPtsPerWave;
-  WeightStream ws;
+  WStream ws;
   ws.base = a.w_pre;           // fp16 hi/lo stage tiles (same 32 KB stage size)
   ws.lds = smem;
   ws.n_stages = kPreStages;
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3(PostArgs a) {
   const int q = lane >> 4, pt = lane & 15;
   const long long n_t16 = (a.P + kPtsPerWave - 1) / kPtsPerWave;
   const long long n_tiles = (n_t16 + 3) / 4;
-  WeightStream ws;
+  WStream ws;
   ws.base = a.w_post;
   ws.lds = smem;
   ws.n_stages = kPostStages;
@@ -437,16 +448,18 @@ int h3_pack(const DinerMlpParams* p, hipStream_t stream, float** w_pre, float** 
   return 0;
 }
 
-int h3_set_attributes(size_t lds_bytes) {
+static constexpr size_t kH3LdsBytes = (size_t)DINER_H3_RING * kStageFloats * sizeof(float);
+int h3_set_attributes(size_t) {
+  const size_t lds_bytes = kH3LdsBytes;
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3::k_field_pre_h3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3::k_field_post_h3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   return 0;
 }
-void h3_launch_pre(const SceneDev& sc, const FieldArgs& fa, int grid, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(h3::k_field_pre_h3, dim3(grid), dim3(256), lds_bytes, stream, sc, fa);
+void h3_launch_pre(const SceneDev& sc, const FieldArgs& fa, int grid, size_t, hipStream_t stream) {
+  hipLaunchKernelGGL(h3::k_field_pre_h3, dim3(grid), dim3(256), kH3LdsBytes, stream, sc, fa);
 }
-void h3_launch_post(const PostArgs& pa, int grid, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(h3::k_field_post_h3, dim3(grid), dim3(256), lds_bytes, stream, pa);
+void h3_launch_post(const PostArgs& pa, int grid, size_t, hipStream_t stream) {
+  hipLaunchKernelGGL(h3::k_field_post_h3, dim3(grid), dim3(256), kH3LdsBytes, stream, pa);
 }
 
 }  // namespace diner
