@@ -18,9 +18,9 @@ namespace h3 {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 #ifndef DINER_H3_RING
-#define DINER_H3_RING 4
+#define DINER_H3_RING 3
 #endif
-typedef WeightStreamDeep<DINER_H3_RING> WStream;     // 4 x 32 KB ring: DMA three stages (~3 us) ahead
+typedef WeightStreamDeep<DINER_H3_RING> WStream;     // 3 x 32 KB ring: DMA two stages (~2 us) ahead (4 and 5 slots measured no better)
 
 constexpr float kScale = 16.0f, kInvScale = 1.0f / 16.0f;
 
@@ -50,6 +50,10 @@ struct NoHook {
 struct Frag {
   h8 v[4];   // hi(mo0), lo(mo0), hi(mo1), lo(mo1)
 };
+#ifndef DINER_H3_AHEAD
+#define DINER_H3_AHEAD 2
+#endif
+constexpr int kAhead = DINER_H3_AHEAD;   // fragment reads are issued this many steps (6 MFMAs each) before their use
 template <int STEP, int W>
 __device__ __forceinline__ h8 frag_addr(const h8* __restrict__ cur) {
   constexpr int tb = STEP >> 2, mp = STEP & 3;
@@ -70,18 +74,18 @@ __device__ __forceinline__ void stage_step(WStream& ws, const h8* __restrict__ c
                                            const BOp& bop, f32x4 (&acc)[kTiles], Hook& hook) {
   constexpr int tb = STEP >> 2, mp = STEP & 3;
   constexpr int a0 = 8 * MG + 2 * mp, a1 = a0 + 1;
-  constexpr int S2 = STEP + 2 < 8 ? STEP + 2 : 7;
+  constexpr int S2 = STEP + kAhead < 8 ? STEP + kAhead : 7;
   DINER_H3_MFMA(acc[a0], f.v[0], bop.hi[tb]);
-  if constexpr (STEP + 2 < 8) fnext.v[0] = frag_addr<S2, 0>(cur);
+  if constexpr (STEP + kAhead < 8) fnext.v[0] = frag_addr<S2, 0>(cur);
   hook.template run<STEP, 0>();
   DINER_H3_MFMA(acc[a1], f.v[2], bop.hi[tb]);
-  if constexpr (STEP + 2 < 8) fnext.v[1] = frag_addr<S2, 1>(cur);
+  if constexpr (STEP + kAhead < 8) fnext.v[1] = frag_addr<S2, 1>(cur);
   hook.template run<STEP, 1>();
   DINER_H3_MFMA(acc[a0], f.v[1], bop.hi[tb]);
-  if constexpr (STEP + 2 < 8) fnext.v[2] = frag_addr<S2, 2>(cur);
+  if constexpr (STEP + kAhead < 8) fnext.v[2] = frag_addr<S2, 2>(cur);
   hook.template run<STEP, 2>();
   DINER_H3_MFMA(acc[a1], f.v[3], bop.hi[tb]);
-  if constexpr (STEP + 2 < 8) fnext.v[3] = frag_addr<S2, 3>(cur);
+  if constexpr (STEP + kAhead < 8) fnext.v[3] = frag_addr<S2, 3>(cur);
   hook.template run<STEP, 3>();
   DINER_H3_MFMA(acc[a0], f.v[0], bop.lo[tb]);
   ws.template dma_step<STEP>();
@@ -111,12 +115,15 @@ __device__ __forceinline__ void stage_step(WStream& ws, const h8* __restrict__ c
 template <int MG, class Hook>
 __device__ __forceinline__ void stage_compute(WStream& ws, const h8* __restrict__ cur, const BOp& bop,
                                               f32x4 (&acc)[kTiles], Hook& hook) {
-  Frag fa, fb, fc;
-  fa.v[0] = frag_addr<0, 0>(cur); fa.v[1] = frag_addr<0, 1>(cur); fa.v[2] = frag_addr<0, 2>(cur); fa.v[3] = frag_addr<0, 3>(cur);
-  fb.v[0] = frag_addr<1, 0>(cur); fb.v[1] = frag_addr<1, 1>(cur); fb.v[2] = frag_addr<1, 2>(cur); fb.v[3] = frag_addr<1, 3>(cur);
-#define DINER_STEP(S_, FUSE, FLOAD) stage_step<MG, (S_)>(ws, cur, FUSE, FLOAD, bop, acc, hook);
-  DINER_STEP(0, fa, fc) DINER_STEP(1, fb, fa) DINER_STEP(2, fc, fb) DINER_STEP(3, fa, fc)
-  DINER_STEP(4, fb, fa) DINER_STEP(5, fc, fb) DINER_STEP(6, fa, fc) DINER_STEP(7, fb, fa)
+  // kAhead + 1 rotating fragment buffers: step s uses buffer s % (kAhead+1) and fills the buffer of step s + kAhead
+  Frag fr[kAhead + 1];
+#define DINER_FL(S_) fr[S_].v[0] = frag_addr<S_, 0>(cur); fr[S_].v[1] = frag_addr<S_, 1>(cur); \
+                     fr[S_].v[2] = frag_addr<S_, 2>(cur); fr[S_].v[3] = frag_addr<S_, 3>(cur);
+  DINER_FL(0) DINER_FL(1)
+  if constexpr (kAhead > 2) { DINER_FL(2) }
+#undef DINER_FL
+#define DINER_STEP(S_) stage_step<MG, (S_)>(ws, cur, fr[(S_) % (kAhead + 1)], fr[((S_) + kAhead) % (kAhead + 1)], bop, acc, hook);
+  DINER_STEP(0) DINER_STEP(1) DINER_STEP(2) DINER_STEP(3) DINER_STEP(4) DINER_STEP(5) DINER_STEP(6) DINER_STEP(7)
 #undef DINER_STEP
 }
 
