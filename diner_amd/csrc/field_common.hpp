@@ -132,6 +132,34 @@ struct WeightStreamDeep {
   __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 };
 
+// View mean at the hand-over between the two field kernels (resnetfc.py:148-151): the 4 waves of a workgroup hold the 4
+// source views of the same 16 points, so the mean is an in-LDS exchange -- four rounds of 8 accumulator tiles through a
+// 32 KB buffer behind the weight ring.  Wave w sums tiles 2w, 2w+1 of each round over the views ((v0+v1)+v2)+v3, scales
+// and stores 2 KB per point in accumulator layout.  Raw barriers + lgkmcnt only: the ring's LDS-DMA stays in flight.
+constexpr int kExchFloats = 4 * 8 * 64 * 4;     // 32 KB
+__device__ __forceinline__ void view_mean_store(float* exch, const f32x4 (&x)[kTiles], float scale, f32x4* __restrict__ out_tile,
+                                                int wave, int lane) {
+  f32x4* e = reinterpret_cast<f32x4*>(exch);
+#define DINER_ROUND(R_)                                                                              \
+  {                                                                                                  \
+    __builtin_amdgcn_s_waitcnt(0xc07f);       /* lgkmcnt(0): my reads of the previous round are done */ \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) e[(wave * 8 + j) * 64 + lane] = x[8 * (R_) + j];   \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                                              \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                               \
+      const int j = 2 * wave + jj;                                                                   \
+      f32x4 s = e[(0 * 8 + j) * 64 + lane];                                                          \
+      s += e[(1 * 8 + j) * 64 + lane];                                                               \
+      s += e[(2 * 8 + j) * 64 + lane];                                                               \
+      s += e[(3 * 8 + j) * 64 + lane];                                                               \
+      out_tile[(8 * (R_) + j) * 64 + lane] = s * scale;                                              \
+    }                                                                                                \
+  }
+  DINER_ROUND(0) DINER_ROUND(1) DINER_ROUND(2) DINER_ROUND(3)
+#undef DINER_ROUND
+}
+
 // bilinear taps of one (point, view): float offsets into a channels-last (.., 512) map + blend weights
 struct Taps {
   size_t off[4];

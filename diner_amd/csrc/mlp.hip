@@ -412,10 +412,9 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
       add_bias(x, bias + kHidden, q);
       layer_from_acc(ws, net, x);                                                // x += fc_1(relu(net))
     }
-    // ---- hand the pre-mean activations to the second kernel in accumulator layout
-    f32x4* out = reinterpret_cast<f32x4*>(a.xpre) + ((size_t)tile * sc.nv + v) * (kTiles * 64) + lane;
-#pragma unroll
-    for (int mo = 0; mo < kTiles; ++mo) out[mo * 64] = x[mo];
+    // ---- mean over the 4 views (= the 4 waves) and hand-over to the second kernel in accumulator layout
+    view_mean_store(smem + kRing * kStageFloats, x, 0.25f, reinterpret_cast<f32x4*>(a.xpre) + (size_t)tile * (kTiles * 64),
+                    wave, lane);
   }
   ws.drain();   // the last (unused) stage DMAs must land before the LDS is released
 }
@@ -481,15 +480,11 @@ __global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
     const bool live = t16 < n_t16;
     if (!live) t16 = n_t16 - 1;
     f32x4 x[kTiles], net[kTiles];
-    // ---- mean over the source views (resnetfc.py:148-151)
+    // ---- view-averaged activations written by k_field_pre (resnetfc.py:148-151)
     {
-      const f32x4* in = reinterpret_cast<const f32x4*>(a.xpre) + (size_t)t16 * a.nv * (kTiles * 64) + lane;
+      const f32x4* in = reinterpret_cast<const f32x4*>(a.xpre) + (size_t)t16 * (kTiles * 64) + lane;
 #pragma unroll
-      for (int mo = 0; mo < kTiles; ++mo) {
-        f32x4 s = in[mo * 64];
-        for (int vv = 1; vv < a.nv; ++vv) s += in[(size_t)vv * (kTiles * 64) + mo * 64];
-        x[mo] = s / (float)a.nv;
-      }
+      for (int mo = 0; mo < kTiles; ++mo) x[mo] = in[mo * 64];
     }
     // ---- blocks 3, 4
     for (int b = 0; b < 2; ++b) {
@@ -566,15 +561,15 @@ struct KernelTimer {
 };
 static KernelTimer g_timer;
 
-static size_t xpre_bytes(long long P, int nv) {
+static size_t xpre_bytes(long long P, int /*nv*/) {
   const long long n_t16 = (P + kPtsPerWave - 1) / kPtsPerWave;
-  return (size_t)n_t16 * nv * kTiles * 64 * sizeof(f32x4);
+  return (size_t)n_t16 * kTiles * 64 * sizeof(f32x4);        // view-averaged hand-over: 2 KB per point
 }
 
 static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa, int nv, float* out, int raw,
                         void* workspace, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds_bytes = kRing * kStageFloats * sizeof(float);
+  const size_t lds_bytes = (kRing * kStageFloats + kExchFloats) * sizeof(float);
   if (!attr_set) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -627,7 +622,7 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
 
 static int launch_hoist(const DinerMlpImpl* m, const float* src, long long rows, float* dst, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds_bytes = kRing * kStageFloats * sizeof(float);
+  const size_t lds_bytes = (kRing * kStageFloats + kExchFloats) * sizeof(float);
   if (!attr_set) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
@@ -758,7 +753,7 @@ extern "C" int diner_profile_collect(double* pre_ms, double* post_ms, long long*
 
 extern "C" size_t diner_field_workspace_bytes(long long n_points) {
   if (n_points <= 0) return 0;
-  return xpre_bytes(n_points, kMaxViews);     // pre-mean activations in accumulator layout (8 KB / point)
+  return xpre_bytes(n_points, kMaxViews);     // view-averaged pre-mean activations in accumulator layout (2 KB / point)
 }
 
 extern "C" size_t diner_mlp_forward_workspace_bytes(long long B) {

@@ -303,9 +303,9 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3(SceneDev sc, FieldArgs 
       add_bias(x, bias + kHidden, q);
       layer_from_acc(ws, net, x);
     }
-    f32x4* out = reinterpret_cast<f32x4*>(a.xpre) + ((size_t)tile * sc.nv + v) * (kTiles * 64) + lane;
-#pragma unroll
-    for (int mo = 0; mo < kTiles; ++mo) out[mo * 64] = x[mo] * kInvScale;     // hand-over at scale 1
+    // view mean + hand-over at scale 1 (0.25 / 16 folded into one exact power-of-two factor)
+    view_mean_store(smem + DINER_H3_RING * kStageFloats, x, 0.25f * kInvScale,
+                    reinterpret_cast<f32x4*>(a.xpre) + (size_t)tile * (kTiles * 64), wave, lane);
   }
   ws.drain();
 }
@@ -330,13 +330,9 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3(PostArgs a) {
     if (!live) t16 = n_t16 - 1;
     f32x4 x[kTiles], net[kTiles];
     {
-      const f32x4* in = reinterpret_cast<const f32x4*>(a.xpre) + (size_t)t16 * a.nv * (kTiles * 64) + lane;
+      const f32x4* in = reinterpret_cast<const f32x4*>(a.xpre) + (size_t)t16 * (kTiles * 64) + lane;
 #pragma unroll
-      for (int mo = 0; mo < kTiles; ++mo) {
-        f32x4 s = in[mo * 64];
-        for (int vv = 1; vv < a.nv; ++vv) s += in[(size_t)vv * (kTiles * 64) + mo * 64];
-        x[mo] = (s / (float)a.nv) * kScale;
-      }
+      for (int mo = 0; mo < kTiles; ++mo) x[mo] = in[mo * 64] * kScale;
     }
     for (int b = 0; b < 2; ++b) {
       const float* bias = a.b_post + 2 * kHidden * b;
@@ -455,7 +451,7 @@ int h3_pack(const DinerMlpParams* p, hipStream_t stream, float** w_pre, float** 
   return 0;
 }
 
-static constexpr size_t kH3LdsBytes = (size_t)DINER_H3_RING * kStageFloats * sizeof(float);
+static constexpr size_t kH3LdsBytes = ((size_t)DINER_H3_RING * kStageFloats + kExchFloats) * sizeof(float);
 int h3_set_attributes(size_t) {
   const size_t lds_bytes = kH3LdsBytes;
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3::k_field_pre_h3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

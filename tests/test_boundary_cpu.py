@@ -55,8 +55,8 @@ def test_argument_validation_without_gpu():
     assert rc == -2 and b"unsupported" in lib.diner_last_error()
     with pytest.raises(RuntimeError, match="unsupported"):
         _lib.check(rc)
-    assert lib.diner_field_workspace_bytes(16) == 16 * 4 * 512 * 4
-    assert lib.diner_field_workspace_bytes(17) == 32 * 4 * 512 * 4      # whole 16-point tiles
+    assert lib.diner_field_workspace_bytes(16) == 16 * 512 * 4
+    assert lib.diner_field_workspace_bytes(17) == 32 * 512 * 4          # whole 16-point tiles
 
 
 def test_state_dict_contract():
