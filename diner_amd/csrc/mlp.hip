@@ -48,6 +48,7 @@ struct DinerMlpImpl {
   float* h3_w_post;
   float* h3_b_pre;
   float* h3_b_post;
+  float* h3n_w;    // n-split packing of the per-view layers (mlp_h3n.hip), fp16 hi/lo, x16
 };
 
 // mlp_h3.hip
@@ -56,7 +57,12 @@ int h3_set_attributes(size_t lds_bytes);
 void h3_launch_pre(const SceneDev& sc, const FieldArgs& fa, int grid, size_t lds_bytes, hipStream_t stream);
 void h3_launch_post(const PostArgs& pa, int grid, size_t lds_bytes, hipStream_t stream);
 
-static int g_precision = 0;   // 0: exact fp32 MFMA (default), 1: f16x3 split products
+// mlp_h3n.hip
+int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out);
+int h3n_set_attributes();
+void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, hipStream_t stream);
+
+static int g_precision = 0;   // 0: exact fp32 MFMA, 1: f16x3 split products, 2: f16x3 with the n-split per-view kernel
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing (runs once per parameter version, on the device)
@@ -576,9 +582,12 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int rc = h3_set_attributes(lds_bytes);
     if (rc) return rc;
+    rc = h3n_set_attributes();
+    if (rc) return rc;
     attr_set = true;
   }
-  const bool use_h3 = g_precision == 1 && !fa.direct_feat;
+  const bool use_h3 = g_precision >= 1 && !fa.direct_feat;
+  const bool use_h3n = g_precision == 2 && !fa.direct_feat;
   fa.w_pre = use_h3 ? m->h3_w_pre : m->w_pre;
   fa.b_pre = use_h3 ? m->h3_b_pre : m->b_pre;
   fa.xpre = (float*)workspace;
@@ -599,7 +608,8 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     DINER_HIP_OK(hipEventCreate(&e2));
     DINER_HIP_OK(hipEventRecord(e0, stream));
   }
-  if (use_h3) h3_launch_pre(*sc, fa, grid_pre, lds_bytes, stream);
+  if (use_h3n) h3n_launch_pre(*sc, fa, m->h3n_w, m->h3_b_pre, grid_pre, stream);
+  else if (use_h3) h3_launch_pre(*sc, fa, grid_pre, lds_bytes, stream);
   else hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), lds_bytes, stream, *sc, fa);
   DINER_LAUNCH_OK();
   if (g_timer.enabled) DINER_HIP_OK(hipEventRecord(e1, stream));
@@ -691,6 +701,8 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
   {
     int rc = h3_pack(p, stream, &m->impl.h3_w_pre, &m->impl.h3_w_post, &m->impl.h3_b_pre, &m->impl.h3_b_post);
     if (rc) return rc;
+    rc = h3n_pack(p, stream, &m->impl.h3n_w);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(k_pack_lin_out, dim3(32), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, wp);
   bias(p->lin_out_b, 4, 16, m->impl.b_post + 4 * kHidden);
@@ -711,12 +723,13 @@ extern "C" int diner_mlp_destroy(DinerMlp* m) {
   hipFree(m->impl.h3_w_post);
   hipFree(m->impl.h3_b_pre);
   hipFree(m->impl.h3_b_post);
+  hipFree(m->impl.h3n_w);
   delete m;
   return 0;
 }
 
 extern "C" int diner_set_precision(int mode) {
-  DINER_CHECK_ARG(mode == 0 || mode == 1, "set_precision: mode must be 0 (fp32) or 1 (f16x3), got %d", mode);
+  DINER_CHECK_ARG(mode >= 0 && mode <= 2, "set_precision: mode must be 0 (fp32), 1 (f16x3) or 2 (f16x3 n-split), got %d", mode);
   g_precision = mode;
   return 0;
 }

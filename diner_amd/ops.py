@@ -363,7 +363,7 @@ def profile_collect():
     return dict(pre_ms=a.value, post_ms=b.value, launches=n.value, points=p.value)
 
 
-PRECISION_FP32, PRECISION_F16X3 = 0, 1
+PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X3_NSPLIT = 0, 1, 2
 
 
 def set_precision(mode):
@@ -381,6 +381,8 @@ def get_precision():
 _want = os.environ.get("DINER_AMD_PRECISION", "f16x3").lower()
 if _want in ("f16x3", "1", "split"):
     set_precision(PRECISION_F16X3)
+elif _want in ("f16x3n", "2", "nsplit"):
+    set_precision(PRECISION_F16X3_NSPLIT)
 elif _want in ("fp32", "f32", "0", "exact"):
     set_precision(PRECISION_FP32)
 else:

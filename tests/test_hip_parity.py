@@ -28,11 +28,12 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=["f16x3", "fp32"])
+@pytest.fixture(params=["f16x3", "f16x3n", "fp32"])
 def precision(request, ops):
-    """Both arithmetic modes of the MLP GEMMs are held to the same tolerances."""
+    """All arithmetic modes / kernel variants of the MLP GEMMs are held to the same tolerances."""
     prev = ops.get_precision()
-    ops.set_precision(ops.PRECISION_F16X3 if request.param == "f16x3" else ops.PRECISION_FP32)
+    ops.set_precision({"f16x3": ops.PRECISION_F16X3, "f16x3n": ops.PRECISION_F16X3_NSPLIT,
+                       "fp32": ops.PRECISION_FP32}[request.param])
     yield request.param
     ops.set_precision(prev)
 
