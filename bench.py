@@ -44,8 +44,8 @@ def parse():
     ap.add_argument("--candidates", type=int, default=1000)
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays of the CPU baseline sample (0 disables; -1 auto)")
     ap.add_argument("--ray-batch", type=int, default=8192, help="rays per launch group (bounds the workspace)")
-    ap.add_argument("--precision", choices=["f16x3", "fp32"], default=None,
-                    help="MLP GEMM arithmetic (default: the library default, f16x3 split products)")
+    ap.add_argument("--precision", choices=["f16x3n", "f16x3", "fp32"], default=None,
+                    help="MLP GEMM arithmetic / kernel variant (default: the library default, see diner_amd/ops.py)")
     return ap.parse_args()
 
 
@@ -73,8 +73,11 @@ def main():
     from src.util.cam_geometry import gen_rays
 
     if args.precision:
-        ops.set_precision(ops.PRECISION_F16X3 if args.precision == "f16x3" else ops.PRECISION_FP32)
-    h3 = ops.get_precision() == ops.PRECISION_F16X3
+        ops.set_precision({"f16x3": ops.PRECISION_F16X3, "f16x3n": ops.PRECISION_F16X3_NSPLIT,
+                           "fp32": ops.PRECISION_FP32}[args.precision])
+    h3 = ops.get_precision() in (ops.PRECISION_F16X3, ops.PRECISION_F16X3_NSPLIT)
+    pre_kernel = {ops.PRECISION_FP32: "k_field_pre", ops.PRECISION_F16X3: "k_field_pre_h3",
+                  ops.PRECISION_F16X3_NSPLIT: "k_field_pre_h3n"}[ops.get_precision()]
     W, H, K = args.width, args.height, args.samples
     G = int(15 * K / 40)                           # create_prediction_folder.py:44-47
     n_cand = args.candidates
@@ -149,11 +152,11 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            key = "k_field_pre_h3_hbm_bytes_per_point" if h3 else "k_field_pre_hbm_bytes_per_point"
+            key = pre_kernel + "_hbm_bytes_per_point"
             traffic = round(json.load(f)[key] * prof["points"] / max(prof["launches"], 1))
     except Exception:
         pass
-    roofline = {"bound": "mfma", "kernel": "k_field_pre_h3" if h3 else "k_field_pre",
+    roofline = {"bound": "mfma", "kernel": pre_kernel,
                 "mfma_dtype": "f16 (3 MFMA products per fp32 product, fp32 accumulate)" if h3 else "f32",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_latest.json)",

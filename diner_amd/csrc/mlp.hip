@@ -587,7 +587,8 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     attr_set = true;
   }
   const bool use_h3 = g_precision >= 1 && !fa.direct_feat;
-  const bool use_h3n = g_precision == 2 && !fa.direct_feat;
+  // the n-split kernel addresses one projected map with 32-bit byte offsets
+  const bool use_h3n = g_precision == 2 && !fa.direct_feat && fa.tz_stride * sizeof(float) < ((size_t)1 << 32);
   fa.w_pre = use_h3 ? m->h3_w_pre : m->w_pre;
   fa.b_pre = use_h3 ? m->h3_b_pre : m->b_pre;
   fa.xpre = (float*)workspace;

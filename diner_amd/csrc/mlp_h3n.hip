@@ -10,6 +10,7 @@
 //     1/16 scale folded in): every wave converts its 128-feature slice, two barriers per layer instead of 32;
 //   * LDS traffic per MFMA drops 8x, the view mean is a register sum over the four column groups.
 // Arithmetic, scaling and results are those of mlp_h3.hip (same products, same accumulation order over k).
+#include <utility>
 #include <vector>
 #include "field_common.hpp"
 
@@ -41,40 +42,97 @@ __device__ __forceinline__ const h8* wfrag(const _Float16* layer, int KT, int wa
   return reinterpret_cast<const h8*>(layer) + ((((size_t)wave * KT + t) * 8 + mo) * 2 + hl) * 64 + lane;
 }
 
-// acc[mo][g] += W[slice rows][all k] . B[k][cols g]   (B from the LDS exchange buffer, A straight from global)
-template <int KT>
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Side work interleaved with a GEMM, one slice per quarter-step (see gemm): default nothing.
+struct NoSide {
+  template <int H, int G>
+  __device__ __forceinline__ void run() {}
+  __device__ __forceinline__ void finish() {}
+};
+
+#ifndef DINER_HN_RING
+#define DINER_HN_RING 3
+#endif
+
+// acc[mo][g] += W[slice rows][all k] . B[k][cols g]   (B from the LDS exchange buffer, A straight from global).
+// Fully unrolled over 2 KT half-steps (k32 block t, row-tile half) of four quarter-steps (column group g): 12 MFMAs
+// each (4 row tiles x {hi*hi, lo*hi, hi*lo}), an accumulator revisited 4 MFMAs apart.
+//   * A fragments (8 x 1 KB per half-step, wave-private) are requested R-1 half-steps ahead, two per quarter-step,
+//     into a ring of R register buffers (an L2 hit takes longer than one half-step's 768 MFMA cycles);
+//   * B fragments (hi, lo of one column group, shared) live in one buffer: group g of the next k32 block is re-read
+//     right after its last use in the second half (576 MFMA cycles before the next use);
+//   * the side task gets a slot per quarter-step, so its VALU / VMEM work is spread between the MFMAs.
+template <int KT, int R, class Side>
 __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, const h8* __restrict__ B, int wave, int lane,
-                                     f32x4 (&acc)[kSlice][kGroups]) {
-  h8 a_cur[16], a_nxt[16];
+                                     f32x4 (&acc)[kSlice][kGroups], Side& side) {
+  constexpr int NH = 2 * KT;
+  h8 a[R][8];                            // half-step ring (static indices after unrolling)
+  h8 bb[kGroups][2];                     // B of the current k32 block: [g][hl]
+  // scalar base (advanced 8 KB per half-step and kept opaque so the addresses are not all materialised up front)
+  // + per-lane 32-bit offset + immediate: no address registers per load
+  typedef const __attribute__((address_space(1))) char* gptr;      // stays a global (not flat) access through the asm
+  gptr abase = (gptr)(reinterpret_cast<const char*>(layer) + (size_t)wave * KT * 16384 + 4096);
+  const unsigned avoff = lane * 16;
+  auto load_a2 = [&](h8 (&dst)[8], int pair) {      // fragments 2 pair, 2 pair + 1 of the half-step at abase
+#ifdef DINER_HN_NO_A          // ablation: price the weight stream
+    asm volatile("" : "+v"(dst[2 * pair]), "+v"(dst[2 * pair + 1]));
+#else
+    asm volatile("" : "+s"(abase));
 #pragma unroll
-  for (int i = 0; i < 16; ++i) a_cur[i] = *wfrag(layer, KT, wave, 0, i >> 1, i & 1, lane);
-#pragma unroll 1
-  for (int t = 0; t < KT; ++t) {
-    const int tn = t + 1 < KT ? t + 1 : t;
+    for (int i = 2 * pair; i < 2 * pair + 2; ++i)
+      dst[i] = *(const __attribute__((address_space(1))) h8*)(abase + avoff + (i * 1024 - 4096));
+    if (pair == 3) abase += 8192;
+#endif
+  };
+  auto load_b = [&](int t, int g) {
+#ifdef DINER_HN_NO_B          // ablation: price the LDS operand reads
+    asm volatile("" : "+v"(bb[g][0]), "+v"(bb[g][1]));
+#else
+    bb[g][0] = B[((t * kGroups + g) * 2 + 0) * 64 + lane];
+    bb[g][1] = B[((t * kGroups + g) * 2 + 1) * 64 + lane];
+#endif
+  };
+#if defined(DINER_HN_NO_A) || defined(DINER_HN_NO_B)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a_nxt[i] = *wfrag(layer, KT, wave, tn, i >> 1, i & 1, lane);
-    h8 bh[kGroups], bl[kGroups];
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
-      bh[g] = B[((t * kGroups + g) * 2 + 0) * 64 + lane];
-      bl[g] = B[((t * kGroups + g) * 2 + 1) * 64 + lane];
-    }
-    // three product kinds, accumulators revisited 32 MFMAs apart
+    for (int i = 0; i < 8; ++i) a[r][i] = *(reinterpret_cast<const h8*>(layer) + (r * 8 + i) * 64 + lane);
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g)
+  for (int g = 0; g < kGroups; ++g) bb[g][0] = bb[g][1] = B[g * 64 + lane];
+#endif
+  static_for<(R - 1 < NH ? R - 1 : NH)>([&](auto H) {
 #pragma unroll
-      for (int mo = 0; mo < kSlice; ++mo) DINER_HN_MFMA(acc[mo][g], a_cur[2 * mo], bh[g]);
+    for (int pr = 0; pr < 4; ++pr) load_a2(a[decltype(H)::value], pr);
+  });
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g)
+  for (int g = 0; g < kGroups; ++g) load_b(0, g);
+  static_for<NH * kGroups>([&](auto Q) {
+    constexpr int qi = decltype(Q)::value;
+    constexpr int h = qi >> 2, g = qi & 3;
+    constexpr int t = h >> 1, half = h & 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (h + R - 1 < NH) load_a2(a[(h + R - 1) % R], g);
+    if constexpr (half == 1 && g > 0 && t + 1 < KT) load_b(t + 1, g - 1);       // previous quarter's group is free
+    if constexpr (half == 0 && g == 0 && t > 0) load_b(t, kGroups - 1);         // ... and the last one of block t-1
+    side.template run<h, g>();
+    h8 (&ac)[8] = a[h % R];
 #pragma unroll
-      for (int mo = 0; mo < kSlice; ++mo) DINER_HN_MFMA(acc[mo][g], a_cur[2 * mo + 1], bh[g]);
+    for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][0]);
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g)
+    for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m + 1], bb[g][0]);
 #pragma unroll
-      for (int mo = 0; mo < kSlice; ++mo) DINER_HN_MFMA(acc[mo][g], a_cur[2 * mo], bl[g]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a_cur[i] = a_nxt[i];
-  }
+    for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][1]);
+  });
+  side.finish();
 }
 
 __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float scale, h8& h, h8& l) {
@@ -89,6 +147,9 @@ __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float
 
 // publish relu(acc)/16 of this wave's 128-feature slice as B operands (k32 blocks 4w .. 4w+3) for all 4 column groups
 __device__ __forceinline__ void publish(h8* __restrict__ B, int wave, int lane, const f32x4 (&acc)[kSlice][kGroups]) {
+#ifdef DINER_HN_NO_PUBLISH
+  return;
+#endif
 #pragma unroll
   for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
@@ -118,24 +179,91 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
   }
 }
 
-// xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups
-__device__ __forceinline__ void gather_add(const float* __restrict__ tz, const TapRec (&tp)[kGroups], int wave, int q,
-                                           f32x4 (&xs)[kSlice][kGroups]) {
-  const f32x4* m4 = reinterpret_cast<const f32x4*>(tz) + 32 * wave + q;       // float4 index of feature 128 w + 4 q
+#ifndef DINER_HN_GDEPTH
+#define DINER_HN_GDEPTH 2
+#endif
+
+// xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
+// (g, mo) of 4 taps each.  As a GEMM side task one unit's taps are requested per half-step and blended / added GD
+// half-steps later (the additions commute with the GEMM's accumulation into the same registers).
+template <int GD>
+struct GatherSide {
+  const float* __restrict__ tz;
+  const TapRec* __restrict__ taps_lds;     // [g 4][col 16]
+  int wave, q, pt;
+  f32x4 (&xs)[kSlice][kGroups];
+  f32x4 r[GD][4];
+#ifdef DINER_HN_W_AT_ISSUE
+  f32x4 wr[GD];
+#endif
+  template <int U>
+  __device__ __forceinline__ void issue() {
+    constexpr int g = U >> 3, mo = U & 7;
+    const TapRec tp = taps_lds[g * 16 + pt];
+    const char* base = reinterpret_cast<const char*>(tz);          // scalar base + 32-bit lane offset + immediate
+    const unsigned lane_off = (32 * wave + q) * 16;
 #pragma unroll
-  for (int g = 0; g < kGroups; ++g) {
-    f32x4 raw[kSlice][4];
-#pragma unroll
-    for (int mo = 0; mo < kSlice; ++mo)
-#pragma unroll
-      for (int tap = 0; tap < 4; ++tap) raw[mo][tap] = m4[(size_t)tp[g].off[tap] * 128 + 4 * mo];
-#pragma unroll
-    for (int mo = 0; mo < kSlice; ++mo) {
-      const f32x4 v = raw[mo][0] * tp[g].w[0] + raw[mo][1] * tp[g].w[1] + raw[mo][2] * tp[g].w[2] + raw[mo][3] * tp[g].w[3];
-      xs[mo][g] += v * kScale;
-    }
+    for (int k = 0; k < 4; ++k)
+      r[U % GD][k] = *reinterpret_cast<const f32x4*>(base + (tp.off[k] * 2048u + lane_off) + mo * 64);
+#ifdef DINER_HN_W_AT_ISSUE
+    wr[U % GD] = *reinterpret_cast<const f32x4*>(tp.w);
+#endif
   }
-}
+  template <int U>
+  __device__ __forceinline__ void blend() {
+    constexpr int g = U >> 3, mo = U & 7;
+#ifdef DINER_HN_W_AT_ISSUE
+    const f32x4 w = wr[U % GD];
+#else
+#ifdef DINER_HN_NOPUN
+    const float* wp = taps_lds[g * 16 + pt].w;
+    const f32x4 w = {wp[0], wp[1], wp[2], wp[3]};
+#else
+    const f32x4 w = *reinterpret_cast<const f32x4*>(taps_lds[g * 16 + pt].w);
+#endif
+#endif
+#ifdef DINER_HN_FIXL
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(const_cast<f32x4&>(w)));
+#endif
+    // Keep w an opaque register value.  Without this the hipcc 7.2 build of this kernel returns wrong sums whenever
+    // the blend reads its weights from LDS inside the GEMM (standalone it is fine; -amdgpu-waitcnt-forcezero, an
+    // extra s_waitcnt or this empty asm all cure it; LDS / VMEM return order checked in tools/ubench/{lds,vm}_order).
+    asm volatile("" : "+v"(const_cast<f32x4&>(w)));
+#ifdef DINER_HN_FIXV
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(const_cast<f32x4&>(w)));
+#endif
+    const f32x4 (&t)[4] = r[U % GD];
+    const f32x4 v = (t[0] * w[0] + t[1] * w[1] + t[2] * w[2] + t[3] * w[3]) * kScale;
+#ifndef DINER_HN_NO_PIN
+    asm volatile("" : "+a"(xs[mo][g]));      // keep the accumulator file assignment: read, add, write back
+#endif
+    xs[mo][g] += v;
+#ifndef DINER_HN_NO_PIN
+    asm volatile("" : "+a"(xs[mo][g]));
+#endif
+  }
+  // half-step H: quarter 0 requests unit H's taps (ring slot H % GD), quarter 2 blends unit H - GD + 1
+  template <int H, int G>
+  __device__ __forceinline__ void run() {
+#ifndef DINER_HN_NO_GATHER
+    if constexpr (G == 0 && H < 32) issue<H>();
+    if constexpr (G == 2 && H - GD + 1 >= 0 && H - GD + 1 < 32) blend<(H - GD + 1 >= 0 ? H - GD + 1 : 0)>();
+#endif
+  }
+  __device__ __forceinline__ void finish() {
+#ifndef DINER_HN_NO_GATHER
+    static_for<GD - 1>([&](auto I) { blend<33 - GD + decltype(I)::value>(); });
+#endif
+  }
+  // stand-alone (no GEMM to hide under): block 0
+  __device__ __forceinline__ void all() {
+    static_for<32>([&](auto H) {
+      run<decltype(H)::value, 0>();
+      run<decltype(H)::value, 2>();
+    });
+    finish();
+  }
+};
 
 __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -150,12 +278,28 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   const _Float16* w_blk = a.w + (size_t)4 * 2 * 8192;           // then 6 layers of 4 * 16 * 16 KB
   constexpr size_t kLayerHalfs = (size_t)4 * 16 * 8192;
 
+#ifdef DINER_HN_NO_FRONT
+  float smem_keep[16]; size_t keep_off[4]; float keep_w[4];
+#endif
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     long long p = tile * kPtsPerWave + pt;
     if (p >= fa.P) p = fa.P - 1;
+#ifdef DINER_HN_NO_FRONT      // ablation: price the projection / encoding front end (first tile's inputs reused)
+    static_assert(true, "");
+    Taps taps;
+    float feat[16];
+    if (tile == blockIdx.x) {
+      field_frontend(sc, fa, wave, q, p, taps, feat);
+      for (int i = 0; i < 16; ++i) smem_keep[i] = feat[i];
+      for (int i = 0; i < 4; ++i) { keep_off[i] = taps.off[i]; keep_w[i] = taps.w[i]; }
+    }
+    for (int i = 0; i < 16; ++i) feat[i] = smem_keep[i];
+    for (int i = 0; i < 4; ++i) { taps.off[i] = keep_off[i]; taps.w[i] = keep_w[i]; }
+#else
     Taps taps;
     float feat[16];
     field_frontend(sc, fa, /*view=*/wave, q, p, taps, feat);
+#endif
     __syncthreads();                              // previous tile's readers of B / taps are done
     {   // publish lin_in B operands (scale 1) for column group `wave` and this column's taps
 #pragma unroll
@@ -182,26 +326,46 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       }
     }
     __syncthreads();
-    TapRec tp[kGroups];
-#pragma unroll
-    for (int g = 0; g < kGroups; ++g) tp[g] = taps_lds[g * 16 + pt];
-
     f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
     set_bias(xs, a.b, wave, q);
-    gemm<2>(w_in, B, wave, lane, xs);
+    {
+      NoSide none;
+      gemm<2, 2>(w_in, B, wave, lane, xs, none);
+      GatherSide<8> g0{fa.tz, taps_lds, wave, q, pt, xs};  // lin_z[0]: nothing long enough to hide under yet
+      g0.all();
+    }
     for (int b = 0; b < 3; ++b) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
-      gather_add(fa.tz + (size_t)b * fa.tz_stride, tp, wave, q, xs);
       __syncthreads();                            // everybody finished reading the previous B
       publish(B, wave, lane, xs);
       __syncthreads();
       set_bias(ns, bias, wave, q);
-      gemm<16>(w_blk + (size_t)(2 * b) * kLayerHalfs, B, wave, lane, ns);
+      {
+        NoSide none;
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b) * kLayerHalfs, B, wave, lane, ns, none);
+      }
       __syncthreads();
       publish(B, wave, lane, ns);
       __syncthreads();
       add_bias(xs, bias + kHidden, wave, q);
-      gemm<16>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, B, wave, lane, xs);
+#ifdef DINER_HN_STANDALONE_GATHER
+      {
+        NoSide none;
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, B, wave, lane, xs, none);
+        if (b < 2) {
+          GatherSide<8> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
+          gs.all();
+        }
+      }
+      continue;
+#endif
+      if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
+        GatherSide<DINER_HN_GDEPTH> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, B, wave, lane, xs, gs);
+      } else {
+        NoSide none;
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, B, wave, lane, xs, none);
+      }
     }
     // view mean = mean over the four column groups; hand-over at scale 1 in accumulator layout (row tile 8 w + mo)
     f32x4* out = reinterpret_cast<f32x4*>(fa.xpre) + (size_t)tile * (kTiles * 64) + lane;

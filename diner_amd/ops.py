@@ -367,7 +367,8 @@ PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X3_NSPLIT = 0, 1, 2
 
 
 def set_precision(mode):
-    """0: exact fp32 MFMA; 1: f16x3 split products (see include/diner_hip.h).  Default: 1 (DINER_AMD_PRECISION)."""
+    """0: exact fp32 MFMA; 1: f16x3 split products, weights streamed through LDS; 2: f16x3, feature-sliced waves
+    (see include/diner_hip.h).  Default: 2 (env DINER_AMD_PRECISION = fp32 | f16x3 | f16x3n)."""
     _lib.check(lib.diner_set_precision(int(mode)))
     _requested_precision[0] = int(mode)
 
@@ -378,7 +379,7 @@ def get_precision():
 
 # Default arithmetic of the MLP GEMMs: f16x3 split products (fp32-class accuracy, measured 3e-6 end to end against the
 # reference, about twice the fp32 MFMA throughput).  DINER_AMD_PRECISION=fp32 selects the exact-fp32 MFMA kernels.
-_want = os.environ.get("DINER_AMD_PRECISION", "f16x3").lower()
+_want = os.environ.get("DINER_AMD_PRECISION", "f16x3n").lower()
 if _want in ("f16x3", "1", "split"):
     set_precision(PRECISION_F16X3)
 elif _want in ("f16x3n", "2", "nsplit"):
@@ -386,4 +387,4 @@ elif _want in ("f16x3n", "2", "nsplit"):
 elif _want in ("fp32", "f32", "0", "exact"):
     set_precision(PRECISION_FP32)
 else:
-    raise ValueError(f"DINER_AMD_PRECISION={_want!r}: expected 'f16x3' or 'fp32'")
+    raise ValueError(f"DINER_AMD_PRECISION={_want!r}: expected 'f16x3n', 'f16x3' or 'fp32'")
