@@ -125,3 +125,29 @@ def test_shard_range_partition():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= (n + world - 1) // world
+
+
+def test_no_spill_code_inside_nsplit_gemms(tmp_path):
+    """Codegen guard for the default per-view kernel (k_field_pre_h3n): no scratch (register spill) traffic between its
+    first and last MFMA.  Builds of this kernel that spilled accumulators inside the GEMM loops returned wrong sums on
+    the GPU for every tile after a workgroup's first one ('n-split kernel'); the resident version must stay
+    spill-free there, so a compiler or source change that reintroduces such spills fails here, on the CPU box."""
+    import re
+    import shutil
+    import subprocess
+    from diner_amd import build as B
+    hipcc = B._hipcc()
+    if not (hipcc and (shutil.which(hipcc) or os.path.exists(hipcc))):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "mlp_h3n.s"
+    subprocess.check_call([hipcc] + B.FLAGS + ["-x", "hip", "-S", "--cuda-device-only",
+                                                os.path.join(B.CSRC, "mlp_h3n.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    m = re.search(r"^(\w*k_field_pre_h3n\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
+    assert m, "kernel not found in the assembly"
+    body = m.group(2).split("\n")
+    idx = [i for i, l in enumerate(body) if "v_mfma" in l]
+    assert len(idx) > 4000
+    spills = [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
+    assert not spills, f"{len(spills)} scratch accesses inside the GEMM span, e.g. {spills[:3]}"

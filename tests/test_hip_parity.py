@@ -264,3 +264,18 @@ def test_k192_against_oracle(ops, precision):
     print(f"K=192: sampler agrees on {int(same.sum())}/{NRr} rays; render on the oracle's z: rgb {e_rgb:.2e} depth {e_d:.2e}")
     assert int((~same).sum()) <= 3
     assert e_rgb < TOL and e_d < TOL and max_norm_rel(wts.cpu(), ref["weights"]) < TOL
+
+
+def test_replicated_points_are_bit_identical(ops, precision):
+    """Several tiles per workgroup: the 512 fixture points repeated 12 times (384 tiles over 256 workgroups, so the
+    second half of the replicas is every workgroup's second tile).  Identical inputs must give bit-identical outputs
+    whatever tile slot, workgroup or pipeline phase they land in, and replica 0 must still match the reference."""
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    R = 12
+    pts, dirs = T(g["pts"]).repeat(R, 1).cuda(), T(g["dirs"]).repeat(R, 1).cuda()
+    out = ops.field_from_points(hs, hm, pts, dirs).cpu().view(R, -1, 4)
+    assert max_norm_rel(out[0], g["out"]) < TOL_STAGE
+    for r in range(1, R):
+        assert torch.equal(out[r], out[0]), f"replica {r} differs from replica 0 [{precision}]"
