@@ -140,11 +140,16 @@ int diner_posenc_f32(const float* x, long long N, int d_in, int num_freqs, float
  *   1 depth (nearest/border), 2 depth_std (nearest on the 100px exponential padding, zeros), 3 normal. */
 int diner_index_f32(const DinerScene* scene, int mode, const float* uv, long long N, float* out, void* stream);
 
-/* ---- arithmetic of the MLP GEMMs (process-wide switch) -----------------------------------------
- * 0 (default): exact fp32 MFMA (v_mfma_f32_16x16x4_f32), results within fp32 round-off of the reference.
+/* ---- arithmetic / kernel variant of the MLP GEMMs (process-wide switch) ------------------------
+ * 0 (library default): exact fp32 MFMA (v_mfma_f32_16x16x4_f32), results within fp32 round-off of the reference.
  * 1: "f16x3" split products -- each fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on
  *    v_mfma_f32_16x16x32_f16 with fp32 accumulation and power-of-two pre-scaling (diner_amd/csrc/mlp_h3.hip);
- *    ~2^-21 relative error per product.  diner_mlp_forward_f32 (explicit matrices) always uses mode 0. */
+ *    ~2^-21 relative error per product.  Weights are streamed through LDS and shared by the four waves.
+ * 2: the same arithmetic (bit-identical sums) with the per-view part computed by the feature-sliced kernel of
+ *    diner_amd/csrc/mlp_h3n.hip: every wave owns 128 output features of all 64 columns, weights go global ->
+ *    registers, activations are exchanged through LDS as fp16 hi/lo operands.  The Python host selects this mode
+ *    by default (diner_amd/ops.py).  Falls back to mode 1 when one projected map exceeds 4 GB.
+ * diner_mlp_forward_f32 (explicit matrices) always uses mode 0.  Returns <0 for an unknown mode. */
 int diner_set_precision(int mode);
 int diner_get_precision(void);
 
