@@ -61,6 +61,7 @@ void h3_launch_post(const PostArgs& pa, int grid, size_t lds_bytes, hipStream_t 
 int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out);
 int h3n_set_attributes();
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, hipStream_t stream);
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, hipStream_t stream);
 
 static int g_precision = 0;   // 0: exact fp32 MFMA, 1: f16x3 split products, 2: f16x3 with the n-split per-view kernel
 
@@ -618,7 +619,8 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
               nv, raw};
   const long long n_tiles = (n_t16 + 3) / 4;
   const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
-  if (use_h3) h3_launch_post(pa, grid_post, lds_bytes, stream);
+  if (use_h3n) h3n_launch_post(pa, m->h3n_w, m->h3_w_post, grid_post, stream);
+  else if (use_h3) h3_launch_post(pa, grid_post, lds_bytes, stream);
   else hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), lds_bytes, stream, pa);
   DINER_LAUNCH_OK();
   if (g_timer.enabled) {

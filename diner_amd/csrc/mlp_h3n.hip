@@ -24,6 +24,24 @@ constexpr int kGroups = 4;                // column groups = source views
 constexpr int kBHalfs = 16 * kGroups * 2 * 64 * 8;      // B buffer: [t 16][g 4][hl 2][lane 64] h8 = 128 KB
 constexpr size_t kLdsBytes = (size_t)kBHalfs * 2 + 4 * 16 * 32;   // + taps exchange (4 groups x 16 columns x 32 B)
 
+// LDS operand buffer addressing: a per-lane byte address kept in one register + immediate offsets (the ds offset
+// field holds 16 bits, so the 128 KB buffer is reached from two bases 64 KB apart).  The bases are made opaque at
+// each use site: otherwise the compiler materialises one address register per fragment, hoists them out of the
+// tile loop and spills them.
+typedef __attribute__((address_space(3))) char* lds_ptr;
+struct LdsB {
+  lds_ptr lo, hi;          // lane's 16 B slot in fragment 0 of k32 blocks 0 and 8
+  __device__ __forceinline__ static LdsB make(h8* base, int lane) {
+    lds_ptr p = (lds_ptr)(reinterpret_cast<char*>(base)) + lane * 16;
+    return {p, p + 65536};
+  }
+  __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(lo), "+v"(hi)); }
+  __device__ __forceinline__ __attribute__((address_space(3))) h8* at(int t, int g, int hl) const {      // fragment (t, g, hl)
+    const int frag = ((t & 7) * kGroups + g) * 2 + hl;
+    return (__attribute__((address_space(3))) h8*)((t < 8 ? lo : hi) + frag * 1024);
+  }
+};
+
 #define DINER_HN_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
 
 struct TapRec {            // per column: 4 tap offsets (float4 units into a projected map) + 4 blend weights
@@ -72,7 +90,7 @@ struct NoSide {
 //     right after its last use in the second half (576 MFMA cycles before the next use);
 //   * the side task gets a slot per quarter-step, so its VALU / VMEM work is spread between the MFMAs.
 template <int KT, int R, class Side>
-__device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, const h8* __restrict__ B, int wave, int lane,
+__device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
                                      f32x4 (&acc)[kSlice][kGroups], Side& side) {
   constexpr int NH = 2 * KT;
   h8 a[R][8];                            // half-step ring (static indices after unrolling)
@@ -80,6 +98,7 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, const h
   // scalar base (advanced 8 KB per half-step and kept opaque so the addresses are not all materialised up front)
   // + per-lane 32-bit offset + immediate: no address registers per load
   typedef const __attribute__((address_space(1))) char* gptr;      // stays a global (not flat) access through the asm
+  B.opaque();
   gptr abase = (gptr)(reinterpret_cast<const char*>(layer) + (size_t)wave * KT * 16384 + 4096);
   const unsigned avoff = lane * 16;
   auto load_a2 = [&](h8 (&dst)[8], int pair) {      // fragments 2 pair, 2 pair + 1 of the half-step at abase
@@ -97,8 +116,8 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, const h
 #ifdef DINER_HN_NO_B          // ablation: price the LDS operand reads
     asm volatile("" : "+v"(bb[g][0]), "+v"(bb[g][1]));
 #else
-    bb[g][0] = B[((t * kGroups + g) * 2 + 0) * 64 + lane];
-    bb[g][1] = B[((t * kGroups + g) * 2 + 1) * 64 + lane];
+    bb[g][0] = *B.at(t, g, 0);
+    bb[g][1] = *B.at(t, g, 1);
 #endif
   };
 #if defined(DINER_HN_NO_A) || defined(DINER_HN_NO_B)
@@ -107,7 +126,7 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, const h
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[r][i] = *(reinterpret_cast<const h8*>(layer) + (r * 8 + i) * 64 + lane);
 #pragma unroll
-  for (int g = 0; g < kGroups; ++g) bb[g][0] = bb[g][1] = B[g * 64 + lane];
+  for (int g = 0; g < kGroups; ++g) bb[g][0] = bb[g][1] = *B.at(0, g, 0);
 #endif
   static_for<(R - 1 < NH ? R - 1 : NH)>([&](auto H) {
 #pragma unroll
@@ -131,6 +150,10 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, const h
     for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m + 1], bb[g][0]);
 #pragma unroll
     for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][1]);
+    // Anchor the quarter-step's results here (no code): MFMAs are pure, and without a use in place the optimiser may
+    // sink a whole accumulation chain below all of the GEMM's loads (seen in k_field_post_h3n: every fragment spilled).
+#pragma unroll
+    for (int m = 0; m < 4; ++m) asm volatile("" : "+a"(acc[4 * half + m][g]));
   });
   side.finish();
 }
@@ -146,7 +169,8 @@ __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float
 }
 
 // publish relu(acc)/16 of this wave's 128-feature slice as B operands (k32 blocks 4w .. 4w+3) for all 4 column groups
-__device__ __forceinline__ void publish(h8* __restrict__ B, int wave, int lane, const f32x4 (&acc)[kSlice][kGroups]) {
+__device__ __forceinline__ void publish(LdsB B, int wave, int lane, const f32x4 (&acc)[kSlice][kGroups]) {
+  B.opaque();
 #ifdef DINER_HN_NO_PUBLISH
   return;
 #endif
@@ -157,8 +181,8 @@ __device__ __forceinline__ void publish(h8* __restrict__ B, int wave, int lane, 
       h8 h, l;
       split8(acc[2 * tl][g], acc[2 * tl + 1][g], kInvScale, h, l);
       const int t = 4 * wave + tl;
-      B[((t * kGroups + g) * 2 + 0) * 64 + lane] = h;
-      B[((t * kGroups + g) * 2 + 1) * 64 + lane] = l;
+      *B.at(t, g, 0) = h;
+      *B.at(t, g, 1) = l;
     }
 }
 
@@ -273,6 +297,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, pt = lane & 15;
   const FieldArgs& fa = a.fa;
+  const LdsB Bl = LdsB::make(B, lane);
   const long long n_tiles = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
   const _Float16* w_in = a.w;                                   // [4][2][8][2][64][8]  = 4 * 2 * 16 KB
   const _Float16* w_blk = a.w + (size_t)4 * 2 * 8192;           // then 6 layers of 4 * 16 * 16 KB
@@ -330,28 +355,28 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
     set_bias(xs, a.b, wave, q);
     {
       NoSide none;
-      gemm<2, 2>(w_in, B, wave, lane, xs, none);
+      gemm<2, 2>(w_in, Bl, wave, lane, xs, none);
       GatherSide<8> g0{fa.tz, taps_lds, wave, q, pt, xs};  // lin_z[0]: nothing long enough to hide under yet
       g0.all();
     }
     for (int b = 0; b < 3; ++b) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
       __syncthreads();                            // everybody finished reading the previous B
-      publish(B, wave, lane, xs);
+      publish(Bl, wave, lane, xs);
       __syncthreads();
       set_bias(ns, bias, wave, q);
       {
         NoSide none;
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b) * kLayerHalfs, B, wave, lane, ns, none);
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
       }
       __syncthreads();
-      publish(B, wave, lane, ns);
+      publish(Bl, wave, lane, ns);
       __syncthreads();
       add_bias(xs, bias + kHidden, wave, q);
 #ifdef DINER_HN_STANDALONE_GATHER
       {
         NoSide none;
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, B, wave, lane, xs, none);
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
         if (b < 2) {
           GatherSide<8> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
           gs.all();
@@ -361,10 +386,10 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
 #endif
       if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
         GatherSide<DINER_HN_GDEPTH> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, B, wave, lane, xs, gs);
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, gs);
       } else {
         NoSide none;
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, B, wave, lane, xs, none);
+        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
       }
     }
     // view mean = mean over the four column groups; hand-over at scale 1 in accumulator layout (row tile 8 w + mo)
@@ -372,6 +397,102 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
 #pragma unroll
     for (int mo = 0; mo < kSlice; ++mo)
       out[(8 * wave + mo) * 64] = (((xs[mo][0] + xs[mo][1]) + xs[mo][2]) + xs[mo][3]) * (0.25f * kInvScale);
+  }
+}
+
+// Tell the register allocator that a block of accumulators lives in the AGPR half of the file at this point (no code).
+__device__ __forceinline__ void pin_acc(f32x4 (&acc)[kSlice][kGroups]) {
+#pragma unroll
+  for (int mo = 0; mo < kSlice; ++mo)
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) asm volatile("" : "+a"(acc[mo][g]));
+}
+
+struct PostArgsN {
+  PostArgs pa;
+  const _Float16* w;        // n-split packed fc_0 / fc_1 of blocks 3, 4 (4 layers of 4 * 16 * 16 KB)
+  const _Float16* w_out;    // lin_out fragments [t 16][hl 2][lane 64][8] (rows >= 4 zero), x16
+};
+
+// Blocks 3-4 + lin_out + output activations on the view-averaged hidden state, same feature-sliced scheme: a
+// workgroup takes 64 points (four 16-point tiles = the four column groups), wave w owns features [128 w, 128 w + 128).
+__global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  h8* B = reinterpret_cast<h8*>(smem);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, pt = lane & 15;
+  const PostArgs& pa = a.pa;
+  const LdsB Bl = LdsB::make(B, lane);
+  const long long n_t16 = (pa.P + kPtsPerWave - 1) / kPtsPerWave;
+  const long long n_tiles = (n_t16 + 3) / 4;
+  constexpr size_t kLayerHalfs = (size_t)4 * 16 * 8192;
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      long long t16 = tile * 4 + g;
+      if (t16 >= n_t16) t16 = n_t16 - 1;
+      const f32x4* in = reinterpret_cast<const f32x4*>(pa.xpre) + (size_t)t16 * (kTiles * 64) + lane;
+#pragma unroll
+      for (int mo = 0; mo < kSlice; ++mo) xs[mo][g] = in[(8 * wave + mo) * 64] * kScale;
+    }
+    NoSide none;
+#pragma nounroll
+    for (int b = 0; b < 2; ++b) {
+      const float* bias = pa.b_post + 2 * kHidden * b;
+      __syncthreads();                            // everybody finished reading the previous B
+      publish(Bl, wave, lane, xs);
+      __syncthreads();
+      set_bias(ns, bias, wave, q);
+      pin_acc(xs);                                // the residual stream stays in registers across the fc_0 GEMM
+      gemm<16, DINER_HN_RING>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
+      pin_acc(xs);
+      __syncthreads();
+      publish(Bl, wave, lane, ns);
+      __syncthreads();
+      add_bias(xs, bias + kHidden, wave, q);
+      gemm<16, DINER_HN_RING>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
+    }
+    // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
+    __syncthreads();
+    publish(Bl, wave, lane, xs);
+    __syncthreads();
+    {
+      typedef const __attribute__((address_space(1))) h8* gh8;
+      gh8 wo = (gh8)(reinterpret_cast<const h8*>(a.w_out) + lane);
+      asm volatile("" : "+v"(wo));                // loop-invariant otherwise: 32 hoisted (and spilled) addresses
+      LdsB Bo = Bl;                               // column group `wave`: two fragments = 2 KB further on
+      Bo.lo += wave * 2048;
+      Bo.hi += wave * 2048;
+      Bo.opaque();
+      f32x4 o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keep the operand loads from being hoisted in one burst
+        const h8 ah = wo[(t * 2 + 0) * 64], al = wo[(t * 2 + 1) * 64];
+        const h8 bh = *Bo.at(t, 0, 0), bl = *Bo.at(t, 0, 1);
+        DINER_HN_MFMA(o[t & 3], ah, bh);
+        DINER_HN_MFMA(o[(t + 1) & 3], al, bh);
+        DINER_HN_MFMA(o[(t + 2) & 3], ah, bl);
+      }
+      f32x4 res = ((o[0] + o[1]) + (o[2] + o[3])) * kInvScale;
+      res += *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 4 * q);       // lin_out bias kept at scale 1
+      const long long t16 = tile * 4 + wave;
+      const long long p = t16 * kPtsPerWave + pt;
+      if (t16 < n_t16 && q == 0 && p < pa.P) {
+        if (!pa.raw) {
+          res[0] = 1.0f / (1.0f + expf(-res[0]));
+          res[1] = 1.0f / (1.0f + expf(-res[1]));
+          res[2] = 1.0f / (1.0f + expf(-res[2]));
+          res[3] = fmaxf(res[3], 0.0f);
+        }
+        reinterpret_cast<f32x4*>(pa.out)[p] = res;
+      }
+    }
   }
 }
 
@@ -394,12 +515,18 @@ __global__ void k_pack_layer_h3n(const float* __restrict__ W, int rows, int cols
 
 int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out) {
   using namespace h3n;
-  const size_t halfs = (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
+  const size_t halfs = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
   DINER_HIP_OK(hipMalloc(w_out, halfs * sizeof(_Float16)));
   _Float16* wp = (_Float16*)*w_out;
   hipLaunchKernelGGL(k_pack_layer_h3n, dim3(256), dim3(256), 0, stream, p->lin_in_w, kHidden, kDIn, 2, kScale, wp);
   wp += (size_t)4 * 2 * 8192;
   for (int b = 0; b < 3; ++b) {
+    hipLaunchKernelGGL(k_pack_layer_h3n, dim3(512), dim3(256), 0, stream, p->fc0_w[b], kHidden, kHidden, 16, kScale, wp);
+    wp += (size_t)4 * 16 * 8192;
+    hipLaunchKernelGGL(k_pack_layer_h3n, dim3(512), dim3(256), 0, stream, p->fc1_w[b], kHidden, kHidden, 16, kScale, wp);
+    wp += (size_t)4 * 16 * 8192;
+  }
+  for (int b = 3; b < 5; ++b) {
     hipLaunchKernelGGL(k_pack_layer_h3n, dim3(512), dim3(256), 0, stream, p->fc0_w[b], kHidden, kHidden, 16, kScale, wp);
     wp += (size_t)4 * 16 * 8192;
     hipLaunchKernelGGL(k_pack_layer_h3n, dim3(512), dim3(256), 0, stream, p->fc1_w[b], kHidden, kHidden, 16, kScale, wp);
@@ -411,11 +538,21 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out) {
 int h3n_set_attributes() {
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_pre_h3n, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h3n::kLdsBytes));
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_post_h3n, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h3n::kLdsBytes));
   return 0;
 }
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, hipStream_t stream) {
   h3n::Args a{fa, (const _Float16*)w, b};
   hipLaunchKernelGGL(h3n::k_field_pre_h3n, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
+}
+
+// w: the n-split pack (post layers follow the per-view ones); w_post_h3: mlp_h3.hip's post pack, whose last stage is lin_out
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, hipStream_t stream) {
+  const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
+  const _Float16* wo = (const _Float16*)w_post_h3 + (size_t)(kPostStages - 1) * 2 * kStageFloats;
+  h3n::PostArgsN a{pa, wn, wo};
+  hipLaunchKernelGGL(h3n::k_field_post_h3n, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);
 }
 
 }  // namespace diner

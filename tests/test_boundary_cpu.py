@@ -151,3 +151,10 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
     assert len(idx) > 4000
     spills = [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
     assert not spills, f"{len(spills)} scratch accesses inside the GEMM span, e.g. {spills[:3]}"
+    # the post kernel (blocks 3-4 + lin_out) has no front end: no scratch at all, and its MFMAs stay interleaved with
+    # the operand loads (an optimiser that sinks the accumulation chains below the loads shows up as spills)
+    m = re.search(r"^(\w*k_field_post_h3n\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
+    assert m, "post kernel not found in the assembly"
+    body = m.group(2).split("\n")
+    assert sum("v_mfma" in l for l in body) > 3000
+    assert not [l for l in body if "scratch_" in l]
