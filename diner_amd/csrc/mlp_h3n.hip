@@ -206,6 +206,9 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
 #ifndef DINER_HN_GDEPTH
 #define DINER_HN_GDEPTH 2
 #endif
+#ifndef DINER_HN_G0DEPTH        // units in flight for block 0's stand-alone gather (no GEMM buffers live there)
+#define DINER_HN_G0DEPTH 8
+#endif
 
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
 // (g, mo) of 4 taps each.  As a GEMM side task one unit's taps are requested per half-step and blended / added GD
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
     {
       NoSide none;
       gemm<2, 2>(w_in, Bl, wave, lane, xs, none);
-      GatherSide<8> g0{fa.tz, taps_lds, wave, q, pt, xs};  // lin_z[0]: nothing long enough to hide under yet
+      GatherSide<DINER_HN_G0DEPTH> g0{fa.tz, taps_lds, wave, q, pt, xs};  // lin_z[0]: nothing long enough to hide under yet
       g0.all();
     }
     for (int b = 0; b < 3; ++b) {
