@@ -57,6 +57,9 @@ SIGNATURES = {
     "diner_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                         C.POINTER(C.c_longlong)]),
     "diner_index_f32": (C.c_int, [C.POINTER(DinerScene), C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "diner_depth2normal_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "diner_gen_rays_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -344,6 +344,43 @@ def index(scene: HipScene, mode, uv):
     return out
 
 
+def depth2normal(dmap, K):
+    """Reference src/util/depth2normal.py:7-87 on the device: dmap (N,1,H,W), K (N,3,3) -> normals (N,3,H,W)."""
+    _require_hip(dmap, K)
+    dmap, K = _f32c(dmap), _f32c(K)
+    N, one, H, W = dmap.shape
+    if one != 1 or tuple(K.shape) != (N, 3, 3):
+        raise ValueError(f"diner_amd: depth2normal expects dmap (N,1,H,W) and K (N,3,3), got {tuple(dmap.shape)}, {tuple(K.shape)}")
+    out = torch.empty(N, 3, H, W, device=dmap.device, dtype=torch.float32)
+    with torch.cuda.device(dmap.device):
+        _lib.check(lib.diner_depth2normal_f32(_ptr(dmap), _ptr(K), N, H, W, _ptr(out), _stream()))
+    return out
+
+
+def gen_rays(extrinsics, intrinsics, W, H, z_near, z_far, device, ray0=0, n_rays=None):
+    """Reference src/util/cam_geometry.py:5-48 on the device: rays [ray0, ray0+n_rays) of each camera's row-major
+    (H, W) list -> (B, n_rays, 8).  Camera tensors may live anywhere (they are read on the host: B x 27 floats)."""
+    E = extrinsics.detach().to("cpu", torch.float32).contiguous()
+    Km = intrinsics.detach().to("cpu", torch.float32).contiguous()
+    B = E.shape[0]
+    zn = torch.as_tensor(z_near, dtype=torch.float32).detach().to("cpu").reshape(-1).expand(B).contiguous()
+    zf = torch.as_tensor(z_far, dtype=torch.float32).detach().to("cpu").reshape(-1).expand(B).contiguous()
+    if tuple(E.shape) != (B, 4, 4) or tuple(Km.shape) != (B, 3, 3):
+        raise ValueError(f"diner_amd: gen_rays expects (B,4,4) extrinsics and (B,3,3) intrinsics, got {tuple(E.shape)}, {tuple(Km.shape)}")
+    n = int(W) * int(H) - int(ray0) if n_rays is None else int(n_rays)
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("diner_amd: gen_rays generates on a HIP device; there is no CPU fallback")
+    out = torch.empty(B, n, 8, device=device, dtype=torch.float32)
+    with torch.cuda.device(device):
+        for b0 in range(0, B, 16):
+            b1 = min(B, b0 + 16)
+            _lib.check(lib.diner_gen_rays_f32(E[b0:b1].data_ptr(), Km[b0:b1].data_ptr(), zn[b0:b1].data_ptr(),
+                                              zf[b0:b1].data_ptr(), b1 - b0, int(W), int(H), int(ray0), n,
+                                              _ptr(out[b0:b1]), _stream()))
+    return out
+
+
 # FLOPs of the two field kernels per sample point (SURVEY.md section 8d): NV views x (lin_in + 3 x (lin_z, fc_0, fc_1))
 # before the view mean, 2 x (fc_0, fc_1) + lin_out after it.
 FLOP_PRE_PER_POINT_REFERENCE = 2 * 4 * (55 * 512 + 9 * 512 * 512)     # as the reference computes it (SURVEY 8d)

@@ -48,11 +48,17 @@ def predict_image(nerf, renderer, target_extrinsics, target_intrinsics, W, H, zn
     dev = target_extrinsics.device
     znear = torch.as_tensor(znear, device=dev, dtype=torch.float32).expand(SB)
     zfar = torch.as_tensor(zfar, device=dev, dtype=torch.float32).expand(SB)
-    rays = gen_rays(target_extrinsics, target_intrinsics, W, H, znear, zfar).view(SB, H * W, 8)
     lo, hi = shard_range(H * W, rank, world)
+    if dev.type == "cuda":         # this rank's ray range only, generated on the device (diner_gen_rays_f32)
+        from diner_amd import ops
+        rays = ops.gen_rays(target_extrinsics, target_intrinsics, W, H, znear, zfar, dev, ray0=lo, n_rays=hi - lo)
+        base = lo
+    else:                          # host tensors (gloo tests): the reference's torch ops
+        rays = gen_rays(target_extrinsics, target_intrinsics, W, H, znear, zfar).view(SB, H * W, 8)
+        base = 0
     tiles = []
     for r0 in range(lo, hi, ray_batch_size):
-        rb = rays[:, r0:min(hi, r0 + ray_batch_size)].contiguous()
+        rb = rays[:, r0 - base:min(hi, r0 + ray_batch_size) - base].contiguous()
         out = renderer.forward(model=nerf, rays=rb)
         tiles.append(torch.cat((out.fine.rgb, out.fine.depth.unsqueeze(-1)), dim=-1))      # (SB, b, 4)
     local = torch.cat(tiles, dim=1) if tiles else torch.zeros(SB, 0, 4, device=dev)

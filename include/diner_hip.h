@@ -140,6 +140,19 @@ int diner_posenc_f32(const float* x, long long N, int d_in, int num_freqs, float
  *   1 depth (nearest/border), 2 depth_std (nearest on the 100px exponential padding, zeros), 3 normal. */
 int diner_index_f32(const DinerScene* scene, int mode, const float* uv, long long N, float* out, void* stream);
 
+/* ---- per-image preparation either side of the renderer ------
+ * depth2normal (reference src/util/depth2normal.py:7-87): dmap (N,1,H,W) device, K (N,3,3) device ->
+ *   normals (N,3,H,W) device: normalize(cross(down - up, right - left)) of the back-projected pixel centres with
+ *   replicate padding; pixels with a background neighbour take the un-cleaned normal of the pixel shifted away from
+ *   the hole; 0 where depth == 0 (NaN where the reference produces 0/0). */
+int diner_depth2normal_f32(const float* dmap, const float* K, int N, int H, int W, float* normals, void* stream);
+/* gen_rays (reference src/util/cam_geometry.py:5-48): rays [ray0, ray0 + n_rays) of the row-major (H, W) pixel-centre
+ *   ray list of each of B cameras -> out (B, n_rays, 8) device = [origin(3), world direction(3), near, far].
+ *   extrinsics (B,4,4) world->camera, intrinsics (B,3,3), z_near / z_far (B): HOST float32; B <= 16 per call.
+ *   A sharded rank passes its own [ray0, ray0 + n_rays) (diner_amd/render.py::shard_range). */
+int diner_gen_rays_f32(const float* extrinsics, const float* intrinsics, const float* z_near, const float* z_far, int B,
+                       int W, int H, long long ray0, long long n_rays, float* out, void* stream);
+
 /* ---- arithmetic / kernel variant of the MLP GEMMs (process-wide switch) ------------------------
  * 0 (library default): exact fp32 MFMA (v_mfma_f32_16x16x4_f32), results within fp32 round-off of the reference.
  * 1: "f16x3" split products -- each fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on

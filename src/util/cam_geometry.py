@@ -1,7 +1,9 @@
 """Ray generation (mirrors reference src/util/cam_geometry.py:5-48): pixel-centre rays of a pinhole camera in
 the OpenCV convention, `[origin(3), direction(3), near, far]`, row-major over (H, W).
 
-Not on the hot path (once per image): plain torch ops on the tensors' device.
+Not on the hot path (once per image).  Cameras on a HIP device generate their rays with the
+library's kernel (diner_gen_rays_f32, also used per ray range by the sharded harness); host tensors use the reference's
+torch ops.
 """
 import torch
 
@@ -10,6 +12,9 @@ def gen_rays(extrinsics, intrinsics, W, H, z_near, z_far):
     """extrinsics (B,4,4) world->cam, intrinsics (B,3,3), z_near/z_far (B) -> rays (B,H,W,8)."""
     B = extrinsics.shape[0]
     dev = extrinsics.device
+    if extrinsics.is_cuda:
+        from diner_amd import ops
+        return ops.gen_rays(extrinsics, intrinsics, W, H, z_near, z_far, dev).view(B, H, W, 8)
     focal = intrinsics[:, [0, 1], [0, 1]]
     c = intrinsics[:, [0, 1], [-1, -1]]
     ys, xs = torch.meshgrid(torch.arange(.5, H, 1, device=dev), torch.arange(.5, W, 1, device=dev), indexing="ij")

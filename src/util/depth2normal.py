@@ -1,7 +1,9 @@
 """Normal maps from depth maps by central differences (mirrors reference src/util/depth2normal.py:7-87).
 
-Encode-side preparation (once per image): plain torch ops, runs on
-whatever device the depth map lives on.  The result is an *input* of the depth-guided sampler.
+Encode-side preparation (once per image).  Depth maps on a HIP device go through the
+library's kernel (diner_depth2normal_f32); host tensors are processed with the same torch ops the reference uses
+(that is the form the oracle-side fixtures were checked in, bit-exact against the reference).  The result is an
+*input* of the depth-guided sampler.
 """
 import torch
 import torch.nn.functional as F
@@ -15,6 +17,9 @@ def depth2normal(dmap, K):
     cross(down-up, right-left) normalised [:46-55], for pixels with a background (depth 0) neighbour
     copy the normal of the pixel shifted AWAY from the hole [:57-78], zero the background [:79].
     """
+    if dmap.is_cuda:
+        from diner_amd import ops
+        return ops.depth2normal(dmap, K.to(dmap.device))
     N, _, H, W = dmap.shape
     dev = dmap.device
     ys, xs = torch.meshgrid(torch.arange(0.5, H, 1.0, device=dev), torch.arange(0.5, W, 1.0, device=dev),

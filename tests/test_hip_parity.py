@@ -279,3 +279,55 @@ def test_replicated_points_are_bit_identical(ops, precision):
     assert max_norm_rel(out[0], g["out"]) < TOL_STAGE
     for r in range(1, R):
         assert torch.equal(out[r], out[0]), f"replica {r} differs from replica 0 [{precision}]"
+
+
+def test_depth2normal_against_reference_ops(ops):
+    """Row f2: the HIP depth2normal against the torch restatement that make_golden.py checks bit-exact against the
+    reference (src/util/depth2normal.py on host tensors): synthetic scene depths (sphere + plane + background), plus a
+    map with isolated holes, a hole on the border and a pixel column where the back-projected x is exactly 0."""
+    from src.util.depth2normal import depth2normal
+    sc = oracle_setup(48, 40, 3)[0]
+    d = sc["depths"].clone()                                  # (4,1,H,W)
+    K = sc["src_intrinsics"].clone()
+    g = torch.Generator().manual_seed(5)
+    d2 = torch.rand(2, 1, 33, 47, generator=g) + 0.5
+    d2[0, 0, 5, 7] = 0; d2[0, 0, 0, 3] = 0; d2[0, 0, 32, 46] = 0; d2[1, 0, 10:14, 20:23] = 0; d2[1, 0, :, 0] = 0
+    K2 = torch.tensor([[[40.0, 0, 23.5], [0, 42.0, 16.5], [0, 0, 1]], [[38.0, 0, 20.0], [0, 38.0, 15.0], [0, 0, 1]]])
+    for dm, Km in ((d, K), (d2, K2)):
+        want = depth2normal(dm, Km)                          # host tensors: the reference's ops
+        got = ops.depth2normal(dm.cuda(), Km.cuda()).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        fin = ~torch.isnan(want)
+        diff = (got[fin] - want[fin]).abs().max().item()
+        frac = (got[fin] != want[fin]).float().mean().item()
+        print(f"depth2normal {tuple(dm.shape)}: max abs diff {diff:.2e}, {100 * frac:.3f} % of values differ in the last bits")
+        assert diff <= 2e-6                                   # unit vectors: <= a few ulp (cross / norm association)
+        assert torch.equal(got[:, :, dm[:, 0].eq(0).any(0)].isnan(), want[:, :, dm[:, 0].eq(0).any(0)].isnan())
+    assert torch.equal(ops.depth2normal(d.cuda(), K.cuda()), depth2normal(d.cuda(), K.cuda()))   # module dispatch
+
+
+def test_gen_rays_against_reference_ops(ops):
+    """Row f3: device ray generation against the reference's torch ops (cam_geometry.py:5-48), whole images and the
+    ray ranges a sharded rank asks for (ragged last shard included)."""
+    from src.util.cam_geometry import gen_rays
+    from diner_amd.render import shard_range
+    sc = oracle_setup(40, 30, 1)[0]
+    E = torch.stack([sc["target_extrinsics"].view(4, 4), sc["src_extrinsics"][1], sc["src_extrinsics"][3]])
+    Km = torch.stack([sc["target_intrinsics"].view(3, 3), sc["src_intrinsics"][1], sc["src_intrinsics"][3]])
+    W, H = 37, 29
+    zn, zf = torch.tensor([0.5, 0.6, 0.7]), torch.tensor([1.5, 1.6, 1.7])
+    want = gen_rays(E, Km, W, H, zn, zf).view(3, H * W, 8)
+    got = ops.gen_rays(E, Km, W, H, zn, zf, "cuda").cpu()
+    err = (got - want).abs().max().item()
+    print(f"gen_rays {W}x{H}: max abs diff {err:.2e}")
+    assert err <= 5e-7
+    assert torch.equal(got[..., :3], want[..., :3].expand_as(got[..., :3])) or (got[..., :3] - want[..., :3]).abs().max() <= 2e-7
+    assert torch.equal(got[..., 6:], want[..., 6:])
+    for world in (3, 8):
+        parts = [ops.gen_rays(E, Km, W, H, zn, zf, "cuda", *(lambda lo, hi: (lo, hi - lo))(*shard_range(H * W, r, world)))
+                 for r in range(world)]
+        assert torch.equal(torch.cat(parts, dim=1).cpu(), got)
+    assert ops.gen_rays(E, Km, W, H, zn, zf, "cuda", ray0=H * W, n_rays=0).shape == (3, 0, 8)
+    with pytest.raises(RuntimeError):
+        ops.gen_rays(E, Km, W, H, zn, zf, "cuda", ray0=H * W - 3, n_rays=4)
+    assert torch.equal(gen_rays(E.cuda(), Km.cuda(), W, H, zn.cuda(), zf.cuda()).cpu().view(3, -1, 8), got)   # module dispatch
