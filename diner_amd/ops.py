@@ -202,6 +202,8 @@ def sample_depthguided(scene: HipScene, rays, n_samples, n_candidates, n_gaussia
     K, G = int(n_samples), int(n_gaussian)
     z = torch.empty(NR, K, device=rays.device, dtype=torch.float32)
     zu = torch.empty(NR, K, device=rays.device, dtype=torch.float32) if want_unfilled else None
+    if NR == 0:                     # nothing to do (the C ABI rejects empty launches)
+        return (z, zu) if want_unfilled else z
     nc = ng = nf = None
     if noise is not None:
         nc, ng, nf = (_f32c(t) if t is not None else None for t in noise)
@@ -222,6 +224,8 @@ def fill_uniform(z_in, rays, noise_fill=None, seed=0):
     z_in, rays = _f32c(z_in), _f32c(rays)
     NR, K = z_in.shape
     out = torch.empty_like(z_in)
+    if NR == 0:
+        return out
     nf = _f32c(noise_fill) if noise_fill is not None else None
     with torch.cuda.device(rays.device):
         _lib.check(lib.diner_fill_uniform_f32(_ptr(z_in), _ptr(rays), NR, K, _ptr(nf),
@@ -255,6 +259,8 @@ def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z):
     scene.prepare(mlp)
     _apply_precision(mlp)
     out = torch.empty(NR, K, 4, device=rays.device, dtype=torch.float32)
+    if NR == 0:
+        return out
     rays_per = max(1, MAX_POINTS_PER_LAUNCH // K)
     with torch.cuda.device(rays.device):
         ws = _workspace(lib.diner_field_workspace_bytes(min(NR, rays_per) * K), rays.device)
@@ -273,6 +279,8 @@ def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs):
     scene.prepare(mlp)
     _apply_precision(mlp)
     out = torch.empty(P, 4, device=xyz.device, dtype=torch.float32)
+    if P == 0:
+        return out
     step = MAX_POINTS_PER_LAUNCH
     with torch.cuda.device(xyz.device):
         ws = _workspace(lib.diner_field_workspace_bytes(min(P, step)), xyz.device)
@@ -291,6 +299,8 @@ def mlp_forward(mlp: HipMlp, zx):
     if NV != 4 or D != 567:
         raise ValueError(f"diner_amd: fused ResnetFC is built for (4, B, 567) inputs, got {tuple(zx.shape)}")
     out = torch.empty(B, 4, device=zx.device, dtype=torch.float32)
+    if B == 0:
+        return out
     with torch.cuda.device(zx.device):
         ws = _workspace(lib.diner_mlp_forward_workspace_bytes(B), zx.device)
         _lib.check(lib.diner_mlp_forward_f32(mlp.handle, _ptr(zx), B, _ptr(out), _ptr(ws), _stream()))
@@ -305,6 +315,8 @@ def composite(field, z, rays, white_bkgd, want_weights=True):
     rgb = torch.empty(NR, 3, device=z.device, dtype=torch.float32)
     depth = torch.empty(NR, device=z.device, dtype=torch.float32)
     w = torch.empty(NR, K, device=z.device, dtype=torch.float32) if want_weights else None
+    if NR == 0:
+        return w, rgb, depth
     with torch.cuda.device(z.device):
         _lib.check(lib.diner_composite_f32(_ptr(field), _ptr(z), _ptr(rays), NR, K, int(bool(white_bkgd)),
                                            _ptr(rgb), _ptr(depth), _ptr(w), _stream()))
@@ -323,6 +335,8 @@ def posenc(x, num_freqs, freq_factor, include_input=True):
     xf = _f32c(x).reshape(-1, shp[-1])
     d_out = shp[-1] * (2 * num_freqs + (1 if include_input else 0))
     out = torch.empty(xf.shape[0], d_out, device=x.device, dtype=torch.float32)
+    if xf.shape[0] == 0:
+        return out.reshape(*shp[:-1], d_out)
     with torch.cuda.device(x.device):
         _lib.check(lib.diner_posenc_f32(_ptr(xf), xf.shape[0], shp[-1], int(num_freqs), float(freq_factor),
                                         int(bool(include_input)), _ptr(out), _stream()))
@@ -339,6 +353,8 @@ def index(scene: HipScene, mode, uv):
     NV, N, _ = uv.shape
     cout = {0: scene.C, 1: 1, 2: 1, 3: 3}[mode]
     out = torch.empty(NV, cout, N, device=uv.device, dtype=torch.float32)
+    if N == 0:
+        return out
     with torch.cuda.device(uv.device):
         _lib.check(lib.diner_index_f32(scene.ref, int(mode), _ptr(uv), N, _ptr(out), _stream()))
     return out

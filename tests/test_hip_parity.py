@@ -331,3 +331,47 @@ def test_gen_rays_against_reference_ops(ops):
     with pytest.raises(RuntimeError):
         ops.gen_rays(E, Km, W, H, zn, zf, "cuda", ray0=H * W - 3, n_rays=4)
     assert torch.equal(gen_rays(E.cuda(), Km.cuda(), W, H, zn.cuda(), zf.cuda()).cpu().view(3, -1, 8), got)   # module dispatch
+
+
+def test_edge_cases_empty_ragged_and_limits(ops, precision):
+    """Empty inputs, ragged point counts (1, 15, 17, 1000 points: partial 16-point tiles and partial 64-point groups),
+    rays that see nothing (every likelihood zero: pure stratified fill), and the documented size limits."""
+    sc, scene, w, msd, rays = oracle_setup(32, 32, 2)
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    rc = rays.cuda()
+    # --- empty
+    z0 = ops.sample_depthguided(hs, rc[:0], 64, 1000, 24)
+    assert z0.shape == (0, 64)
+    wts, rgb, dep = ops.render(hs, hm, rc[:0], z0, True)
+    assert rgb.shape == (0, 3) and dep.shape == (0,)
+    assert ops.field_from_points(hs, hm, torch.zeros(0, 3).cuda(), torch.zeros(0, 3).cuda()).shape == (0, 4)
+    # --- ragged point counts: every prefix equals the prefix of the big call, bit for bit
+    g = load("g6_pixelnerf.npz")
+    sc6, _, _, msd6, _ = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    hs6, hm6 = hip_scene(ops, sc6), hip_mlp(ops, msd6)
+    pts, dirs = T(g["pts"]).repeat(2, 1).cuda(), T(g["dirs"]).repeat(2, 1).cuda()      # 1024 points
+    full = ops.field_from_points(hs6, hm6, pts, dirs)
+    assert max_norm_rel(full[:512].cpu(), g["out"]) < TOL_STAGE
+    for n in (1, 15, 17, 63, 65, 1000):
+        part = ops.field_from_points(hs6, hm6, pts[:n], dirs[:n])
+        assert torch.equal(part, full[:n]), f"{n} points [{precision}]"
+    # --- rays that miss every surface: all samples come from the stratified fill, ascending inside [near, far]
+    away = rc[:64].clone()
+    away[:, 3:6] = -away[:, 3:6]                              # look away from the scene
+    gen = torch.Generator().manual_seed(9)
+    noise = (torch.rand(64, 1000, generator=gen).cuda(), torch.randn(64, 24, generator=gen).cuda(),
+             torch.rand(64, 64, generator=gen).cuda())
+    z, zu = ops.sample_depthguided(hs, away, 64, 1000, 24, noise=noise, want_unfilled=True)
+    assert (zu == 0).all()
+    assert (z[:, 1:] >= z[:, :-1]).all() and (z >= away[:, 6:7]).all() and (z <= away[:, 7:8]).all()
+    edges = away[:, 6:7] + (away[:, 7:8] - away[:, 6:7]) * torch.arange(65, device="cuda") / 64
+    assert ((z >= edges[:, :-1] - 1e-6) & (z <= edges[:, 1:] + 1e-6)).all()            # one sample per stratum
+    _, rgb, dep = ops.render(hs, hm, away, z, True)
+    assert torch.isfinite(rgb).all() and torch.isfinite(dep).all()
+    # --- limits
+    ops.sample_depthguided(hs, rc[:8], 256, 1024, 96)                                  # largest supported sizes
+    for bad in ((257, 1000, 96), (64, 1025, 24), (64, 1000, 65)):
+        with pytest.raises(RuntimeError):
+            ops.sample_depthguided(hs, rc[:8], *bad)
+    with pytest.raises(ValueError):
+        ops.mlp_forward(hm, torch.zeros(3, 8, 567).cuda())                             # NV != 4
