@@ -80,6 +80,9 @@ struct NoSide {
 #ifndef DINER_HN_RING
 #define DINER_HN_RING 3
 #endif
+#ifndef DINER_HN_RING0          // A ring of the fc_0 GEMMs (no gather buffers live there)
+#define DINER_HN_RING0 DINER_HN_RING
+#endif
 
 // acc[mo][g] += W[slice rows][all k] . B[k][cols g]   (B from the LDS exchange buffer, A straight from global).
 // Fully unrolled over 2 KT half-steps (k32 block t, row-tile half) of four quarter-steps (column group g): 12 MFMAs
@@ -161,7 +164,10 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
 __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float scale, h8& h, h8& l) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float v = fmaxf(j < 4 ? lo4[j] : hi4[j - 4], 0.0f) * scale;
+    // relu as an integer max on the bit pattern (negative floats, -0 included, are negative integers): one v_max_i32
+    // instead of fmaxf's canonicalise + max pair; a NaN keeps propagating like torch.relu's
+    const float x = j < 4 ? lo4[j] : hi4[j - 4];
+    const float v = __int_as_float(max(__float_as_int(x), 0)) * scale;
     const _Float16 hh = (_Float16)v;
     h[j] = hh;
     l[j] = (_Float16)(v - (float)hh);
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       set_bias(ns, bias, wave, q);
       {
         NoSide none;
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
+        gemm<16, DINER_HN_RING0>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
       }
       __syncthreads();
       publish(Bl, wave, lane, ns);
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       __syncthreads();
       set_bias(ns, bias, wave, q);
       pin_acc(xs);                                // the residual stream stays in registers across the fc_0 GEMM
-      gemm<16, DINER_HN_RING>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
+      gemm<16, DINER_HN_RING0>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
       pin_acc(xs);
       __syncthreads();
       publish(Bl, wave, lane, ns);
