@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--candidates", type=int, default=1000)
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays of the CPU baseline sample (0 disables; -1 auto)")
     ap.add_argument("--ray-batch", type=int, default=8192, help="rays per launch group (bounds the workspace)")
-    ap.add_argument("--precision", choices=["f16x3n", "f16x3", "fp32"], default=None,
+    ap.add_argument("--precision", choices=["f16x3n", "f16x3", "fp32", "f16"], default=None,
                     help="MLP GEMM arithmetic / kernel variant (default: the library default, see diner_amd/ops.py)")
     return ap.parse_args()
 
@@ -74,10 +74,11 @@ def main():
 
     if args.precision:
         ops.set_precision({"f16x3": ops.PRECISION_F16X3, "f16x3n": ops.PRECISION_F16X3_NSPLIT,
-                           "fp32": ops.PRECISION_FP32}[args.precision])
+                           "fp32": ops.PRECISION_FP32, "f16": ops.PRECISION_F16}[args.precision])
     h3 = ops.get_precision() in (ops.PRECISION_F16X3, ops.PRECISION_F16X3_NSPLIT)
+    f16 = ops.get_precision() == ops.PRECISION_F16       # plain fp16 operands: outside the 1e-4 parity bar, never the default
     pre_kernel = {ops.PRECISION_FP32: "k_field_pre", ops.PRECISION_F16X3: "k_field_pre_h3",
-                  ops.PRECISION_F16X3_NSPLIT: "k_field_pre_h3n"}[ops.get_precision()]
+                  ops.PRECISION_F16X3_NSPLIT: "k_field_pre_h3n", ops.PRECISION_F16: "k_field_pre_h3n<plain fp16>"}[ops.get_precision()]
     W, H, K = args.width, args.height, args.samples
     G = int(15 * K / 40)                           # create_prediction_folder.py:44-47
     n_cand = args.candidates
@@ -144,7 +145,7 @@ def main():
     # FLOPs the dominant kernel executes per point: lin_z hoisted; with f16x3 every fp32 product is three fp16 MFMA products
     mfma_per_product = 3 if h3 else 1
     flop_pre = prof["points"] * ops.FLOP_PRE_PER_POINT * mfma_per_product
-    peak = PEAK_F16_MFMA_TFLOPS if h3 else PEAK_FP32_MFMA_TFLOPS
+    peak = PEAK_F16_MFMA_TFLOPS if (h3 or f16) else PEAK_FP32_MFMA_TFLOPS
     achieved = flop_pre / pre_s / 1e12 if pre_s > 0 else 0.0
     fp32_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT / pre_s / 1e12 if pre_s > 0 else 0.0
     ref_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT_REFERENCE / pre_s / 1e12 if pre_s > 0 else 0.0
@@ -157,7 +158,8 @@ def main():
     except Exception:
         pass
     roofline = {"bound": "mfma", "kernel": pre_kernel,
-                "mfma_dtype": "f16 (3 MFMA products per fp32 product, fp32 accumulate)" if h3 else "f32",
+                "mfma_dtype": ("f16 (3 MFMA products per fp32 product, fp32 accumulate)" if h3 else
+                               "f16 operands, fp32 accumulate (reduced precision: ~1e-3, outside the parity bar)" if f16 else "f32"),
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_latest.json)",
                 "launches": prof["launches"],
@@ -215,10 +217,12 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 via f16x3 split MFMA products, fp32 accumulate" if h3 else "f32", "data": "synthetic",
+            "dtype": ("f32 via f16x3 split MFMA products, fp32 accumulate" if h3 else
+                      "f16 operands / f32 accumulate (REDUCED PRECISION, not the headline configuration)" if f16 else "f32"),
+            "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: synthetic 4-view scene, {W}x{H} target = {NR} rays per GPU per "
                                    f"step, {K} samples/ray ({G} gaussian, {n_cand} candidates), MLP d_hidden 512 / 5 blocks "
-                                   f"({'f16x3 split-product' if h3 else 'exact fp32'} MFMA GEMMs), random-init weights, "
+                                   f"({'f16x3 split-product' if h3 else 'plain fp16-operand' if f16 else 'exact fp32'} MFMA GEMMs), random-init weights, "
                                    f"in-kernel Philox noise",
                        "rays_per_step_per_gpu": NR, "samples_per_ray": K, "src_views": 4,
                        "parallelism": f"ray-shard x{world}, RCCL gather of (rgb,depth) tiles"},

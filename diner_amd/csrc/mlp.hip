@@ -60,8 +60,9 @@ void h3_launch_post(const PostArgs& pa, int grid, size_t lds_bytes, hipStream_t 
 // mlp_h3n.hip
 int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out);
 int h3n_set_attributes();
-void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, hipStream_t stream);
-void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, hipStream_t stream);
+void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
+                    hipStream_t stream);
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, bool split, hipStream_t stream);
 
 static int g_precision = 0;   // 0: exact fp32 MFMA, 1: f16x3 split products, 2: f16x3 with the n-split per-view kernel
 
@@ -589,7 +590,8 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
   }
   const bool use_h3 = g_precision >= 1 && !fa.direct_feat;
   // the n-split kernel addresses one projected map with 32-bit byte offsets
-  const bool use_h3n = g_precision == 2 && !fa.direct_feat && fa.tz_stride * sizeof(float) < ((size_t)1 << 32);
+  const bool use_h3n = g_precision >= 2 && !fa.direct_feat && fa.tz_stride * sizeof(float) < ((size_t)1 << 32);
+  const bool split = g_precision != 3;         // mode 3: plain fp16 operands in the n-split kernels
   fa.w_pre = use_h3 ? m->h3_w_pre : m->w_pre;
   fa.b_pre = use_h3 ? m->h3_b_pre : m->b_pre;
   fa.xpre = (float*)workspace;
@@ -610,7 +612,7 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     DINER_HIP_OK(hipEventCreate(&e2));
     DINER_HIP_OK(hipEventRecord(e0, stream));
   }
-  if (use_h3n) h3n_launch_pre(*sc, fa, m->h3n_w, m->h3_b_pre, grid_pre, stream);
+  if (use_h3n) h3n_launch_pre(*sc, fa, m->h3n_w, m->h3_b_pre, grid_pre, split, stream);
   else if (use_h3) h3_launch_pre(*sc, fa, grid_pre, lds_bytes, stream);
   else hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), lds_bytes, stream, *sc, fa);
   DINER_LAUNCH_OK();
@@ -619,7 +621,7 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
               nv, raw};
   const long long n_tiles = (n_t16 + 3) / 4;
   const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
-  if (use_h3n) h3n_launch_post(pa, m->h3n_w, m->h3_w_post, grid_post, stream);
+  if (use_h3n) h3n_launch_post(pa, m->h3n_w, m->h3_w_post, grid_post, split, stream);
   else if (use_h3) h3_launch_post(pa, grid_post, lds_bytes, stream);
   else hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), lds_bytes, stream, pa);
   DINER_LAUNCH_OK();
@@ -732,7 +734,8 @@ extern "C" int diner_mlp_destroy(DinerMlp* m) {
 }
 
 extern "C" int diner_set_precision(int mode) {
-  DINER_CHECK_ARG(mode >= 0 && mode <= 2, "set_precision: mode must be 0 (fp32), 1 (f16x3) or 2 (f16x3 n-split), got %d", mode);
+  DINER_CHECK_ARG(mode >= 0 && mode <= 3,
+                  "set_precision: mode must be 0 (fp32), 1 (f16x3), 2 (f16x3 n-split) or 3 (plain fp16 operands), got %d", mode);
   g_precision = mode;
   return 0;
 }

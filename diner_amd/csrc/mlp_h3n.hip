@@ -92,7 +92,8 @@ struct NoSide {
 //   * B fragments (hi, lo of one column group, shared) live in one buffer: group g of the next k32 block is re-read
 //     right after its last use in the second half (576 MFMA cycles before the next use);
 //   * the side task gets a slot per quarter-step, so its VALU / VMEM work is spread between the MFMAs.
-template <int KT, int R, class Side>
+// LO = false: plain fp16 operands (hi parts only, one MFMA per product; diner_set_precision(3)).
+template <int KT, int R, bool LO, class Side>
 __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
                                      f32x4 (&acc)[kSlice][kGroups], Side& side) {
   constexpr int NH = 2 * KT;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
     asm volatile("" : "+s"(abase));
 #pragma unroll
     for (int i = 2 * pair; i < 2 * pair + 2; ++i)
-      dst[i] = *(const __attribute__((address_space(1))) h8*)(abase + avoff + (i * 1024 - 4096));
+      if (LO || (i & 1) == 0) dst[i] = *(const __attribute__((address_space(1))) h8*)(abase + avoff + (i * 1024 - 4096));
     if (pair == 3) abase += 8192;
 #endif
   };
@@ -120,7 +121,7 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
     asm volatile("" : "+v"(bb[g][0]), "+v"(bb[g][1]));
 #else
     bb[g][0] = *B.at(t, g, 0);
-    bb[g][1] = *B.at(t, g, 1);
+    if (LO) bb[g][1] = *B.at(t, g, 1);
 #endif
   };
 #if defined(DINER_HN_NO_A) || defined(DINER_HN_NO_B)
@@ -149,10 +150,12 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
     h8 (&ac)[8] = a[h % R];
 #pragma unroll
     for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][0]);
+    if constexpr (LO) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m + 1], bb[g][0]);
+      for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m + 1], bb[g][0]);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][1]);
+      for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][1]);
+    }
     // Anchor the quarter-step's results here (no code): MFMAs are pure, and without a use in place the optimiser may
     // sink a whole accumulation chain below all of the GEMM's loads (seen in k_field_post_h3n: every fragment spilled).
 #pragma unroll
@@ -175,6 +178,7 @@ __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float
 }
 
 // publish relu(acc)/16 of this wave's 128-feature slice as B operands (k32 blocks 4w .. 4w+3) for all 4 column groups
+template <bool LO>
 __device__ __forceinline__ void publish(LdsB B, int wave, int lane, const f32x4 (&acc)[kSlice][kGroups]) {
   B.opaque();
 #ifdef DINER_HN_NO_PUBLISH
@@ -188,7 +192,7 @@ __device__ __forceinline__ void publish(LdsB B, int wave, int lane, const f32x4 
       split8(acc[2 * tl][g], acc[2 * tl + 1][g], kInvScale, h, l);
       const int t = 4 * wave + tl;
       *B.at(t, g, 0) = h;
-      *B.at(t, g, 1) = l;
+      if constexpr (LO) *B.at(t, g, 1) = l;
     }
 }
 
@@ -298,6 +302,7 @@ struct GatherSide {
   }
 };
 
+template <bool LO>
 __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   h8* B = reinterpret_cast<h8*>(smem);
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
           l[j] = (_Float16)(v - (float)hh);
         }
         B[((t * kGroups + wave) * 2 + 0) * 64 + lane] = h;
-        B[((t * kGroups + wave) * 2 + 1) * 64 + lane] = l;
+        if constexpr (LO) B[((t * kGroups + wave) * 2 + 1) * 64 + lane] = l;
       }
       if (q == 0) {
         TapRec r;
@@ -364,28 +369,28 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
     set_bias(xs, a.b, wave, q);
     {
       NoSide none;
-      gemm<2, 2>(w_in, Bl, wave, lane, xs, none);
+      gemm<2, 2, LO>(w_in, Bl, wave, lane, xs, none);
       GatherSide<DINER_HN_G0DEPTH> g0{fa.tz, taps_lds, wave, q, pt, xs};  // lin_z[0]: nothing long enough to hide under yet
       g0.all();
     }
     for (int b = 0; b < 3; ++b) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
       __syncthreads();                            // everybody finished reading the previous B
-      publish(Bl, wave, lane, xs);
+      publish<LO>(Bl, wave, lane, xs);
       __syncthreads();
       set_bias(ns, bias, wave, q);
       {
         NoSide none;
-        gemm<16, DINER_HN_RING0>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
+        gemm<16, DINER_HN_RING0, LO>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
       }
       __syncthreads();
-      publish(Bl, wave, lane, ns);
+      publish<LO>(Bl, wave, lane, ns);
       __syncthreads();
       add_bias(xs, bias + kHidden, wave, q);
 #ifdef DINER_HN_STANDALONE_GATHER
       {
         NoSide none;
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
+        gemm<16, DINER_HN_RING, LO>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
         if (b < 2) {
           GatherSide<8> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
           gs.all();
@@ -395,10 +400,10 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
 #endif
       if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
         GatherSide<DINER_HN_GDEPTH> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, gs);
+        gemm<16, DINER_HN_RING, LO>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, gs);
       } else {
         NoSide none;
-        gemm<16, DINER_HN_RING>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
+        gemm<16, DINER_HN_RING, LO>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
       }
     }
     // view mean = mean over the four column groups; hand-over at scale 1 in accumulator layout (row tile 8 w + mo)
@@ -425,6 +430,7 @@ struct PostArgsN {
 
 // Blocks 3-4 + lin_out + output activations on the view-averaged hidden state, same feature-sliced scheme: a
 // workgroup takes 64 points (four 16-point tiles = the four column groups), wave w owns features [128 w, 128 w + 128).
+template <bool LO>
 __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   h8* B = reinterpret_cast<h8*>(smem);
@@ -452,21 +458,21 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     for (int b = 0; b < 2; ++b) {
       const float* bias = pa.b_post + 2 * kHidden * b;
       __syncthreads();                            // everybody finished reading the previous B
-      publish(Bl, wave, lane, xs);
+      publish<LO>(Bl, wave, lane, xs);
       __syncthreads();
       set_bias(ns, bias, wave, q);
       pin_acc(xs);                                // the residual stream stays in registers across the fc_0 GEMM
-      gemm<16, DINER_HN_RING0>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
+      gemm<16, DINER_HN_RING0, LO>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
       pin_acc(xs);
       __syncthreads();
-      publish(Bl, wave, lane, ns);
+      publish<LO>(Bl, wave, lane, ns);
       __syncthreads();
       add_bias(xs, bias + kHidden, wave, q);
-      gemm<16, DINER_HN_RING>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
+      gemm<16, DINER_HN_RING, LO>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
     }
     // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
     __syncthreads();
-    publish(Bl, wave, lane, xs);
+    publish<LO>(Bl, wave, lane, xs);
     __syncthreads();
     {
       typedef const __attribute__((address_space(1))) h8* gh8;
@@ -485,8 +491,10 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
         const h8 ah = wo[(t * 2 + 0) * 64], al = wo[(t * 2 + 1) * 64];
         const h8 bh = *Bo.at(t, 0, 0), bl = *Bo.at(t, 0, 1);
         DINER_HN_MFMA(o[t & 3], ah, bh);
-        DINER_HN_MFMA(o[(t + 1) & 3], al, bh);
-        DINER_HN_MFMA(o[(t + 2) & 3], ah, bl);
+        if constexpr (LO) {
+          DINER_HN_MFMA(o[(t + 1) & 3], al, bh);
+          DINER_HN_MFMA(o[(t + 2) & 3], ah, bl);
+        }
       }
       f32x4 res = ((o[0] + o[1]) + (o[2] + o[3])) * kInvScale;
       res += *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 4 * q);       // lin_out bias kept at scale 1
@@ -545,23 +553,31 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out) {
   return 0;
 }
 int h3n_set_attributes() {
-  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_pre_h3n, hipFuncAttributeMaxDynamicSharedMemorySize,
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_pre_h3n<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h3n::kLdsBytes));
-  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_post_h3n, hipFuncAttributeMaxDynamicSharedMemorySize,
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_post_h3n<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h3n::kLdsBytes));
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_pre_h3n<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h3n::kLdsBytes));
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_post_h3n<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h3n::kLdsBytes));
   return 0;
 }
-void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, hipStream_t stream) {
+// split = true: f16x3 split products (hi and lo parts, three MFMAs per product); false: plain fp16 operands
+void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
+                    hipStream_t stream) {
   h3n::Args a{fa, (const _Float16*)w, b};
-  hipLaunchKernelGGL(h3n::k_field_pre_h3n, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
+  if (split) hipLaunchKernelGGL(h3n::k_field_pre_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
+  else hipLaunchKernelGGL(h3n::k_field_pre_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
 }
 
 // w: the n-split pack (post layers follow the per-view ones); w_post_h3: mlp_h3.hip's post pack, whose last stage is lin_out
-void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, hipStream_t stream) {
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, bool split, hipStream_t stream) {
   const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
   const _Float16* wo = (const _Float16*)w_post_h3 + (size_t)(kPostStages - 1) * 2 * kStageFloats;
   h3n::PostArgsN a{pa, wn, wo};
-  hipLaunchKernelGGL(h3n::k_field_post_h3n, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);
+  if (split) hipLaunchKernelGGL(h3n::k_field_post_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);
+  else hipLaunchKernelGGL(h3n::k_field_post_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);
 }
 
 }  // namespace diner

@@ -416,12 +416,14 @@ def profile_collect():
     return dict(pre_ms=a.value, post_ms=b.value, launches=n.value, points=p.value)
 
 
-PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X3_NSPLIT = 0, 1, 2
+PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X3_NSPLIT, PRECISION_F16 = 0, 1, 2, 3
 
 
 def set_precision(mode):
     """0: exact fp32 MFMA; 1: f16x3 split products, weights streamed through LDS; 2: f16x3, feature-sliced waves
-    (see include/diner_hip.h).  Default: 2 (env DINER_AMD_PRECISION = fp32 | f16x3 | f16x3n)."""
+    (see include/diner_hip.h); 3: plain fp16 operands with fp32 accumulation in the same kernels (BASELINE configs[4],
+    "fp16 MLP on MFMA": ~1e-3 relative, NOT inside the 1e-4 parity bar).
+    Default: 2 (env DINER_AMD_PRECISION = fp32 | f16x3 | f16x3n | f16)."""
     _lib.check(lib.diner_set_precision(int(mode)))
     _requested_precision[0] = int(mode)
 
@@ -437,7 +439,9 @@ if _want in ("f16x3", "1", "split"):
     set_precision(PRECISION_F16X3)
 elif _want in ("f16x3n", "2", "nsplit"):
     set_precision(PRECISION_F16X3_NSPLIT)
+elif _want in ("f16", "fp16", "3", "half"):
+    set_precision(PRECISION_F16)
 elif _want in ("fp32", "f32", "0", "exact"):
     set_precision(PRECISION_FP32)
 else:
-    raise ValueError(f"DINER_AMD_PRECISION={_want!r}: expected 'f16x3n', 'f16x3' or 'fp32'")
+    raise ValueError(f"DINER_AMD_PRECISION={_want!r}: expected 'f16x3n', 'f16x3', 'f16' or 'fp32'")

@@ -162,6 +162,9 @@ int diner_gen_rays_f32(const float* extrinsics, const float* intrinsics, const f
  *    diner_amd/csrc/mlp_h3n.hip: every wave owns 128 output features of all 64 columns, weights go global ->
  *    registers, activations are exchanged through LDS as fp16 hi/lo operands.  The Python host selects this mode
  *    by default (diner_amd/ops.py).  Falls back to mode 1 when one projected map exceeds 4 GB.
+ * 3: plain fp16 operands (the hi parts only: one MFMA per product) with fp32 accumulation, in the kernels of mode 2 --
+ *    BASELINE configs[4] ("fp16 MLP on MFMA").  About 1e-3 relative on the rendered colours: outside the 1e-4 parity
+ *    bar, never a default; 2x the rate of mode 2.
  * diner_mlp_forward_f32 (explicit matrices) always uses mode 0.  Returns <0 for an unknown mode. */
 int diner_set_precision(int mode);
 int diner_get_precision(void);

@@ -144,17 +144,18 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
                                                 os.path.join(B.CSRC, "mlp_h3n.hip"), "-o", str(out)],
                           stderr=subprocess.DEVNULL)
     txt = out.read_text()
-    m = re.search(r"^(\w*k_field_pre_h3n\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
-    assert m, "kernel not found in the assembly"
-    body = m.group(2).split("\n")
-    idx = [i for i, l in enumerate(body) if "v_mfma" in l]
-    assert len(idx) > 4000
-    spills = [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
-    assert not spills, f"{len(spills)} scratch accesses inside the GEMM span, e.g. {spills[:3]}"
+    pre = list(re.finditer(r"^(\w*k_field_pre_h3n\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M))
+    post = list(re.finditer(r"^(\w*k_field_post_h3n\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M))
+    assert len(pre) == 2 and len(post) == 2, "expected the split (f16x3) and the plain-fp16 instance of each kernel"
+    for m in pre:
+        body = m.group(2).split("\n")
+        idx = [i for i, l in enumerate(body) if "v_mfma" in l]
+        assert len(idx) > 1500
+        spills = [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
+        assert not spills, f"{m.group(1)}: {len(spills)} scratch accesses inside the GEMM span, e.g. {spills[:3]}"
     # the post kernel (blocks 3-4 + lin_out) has no front end: no scratch at all, and its MFMAs stay interleaved with
     # the operand loads (an optimiser that sinks the accumulation chains below the loads shows up as spills)
-    m = re.search(r"^(\w*k_field_post_h3n\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
-    assert m, "post kernel not found in the assembly"
-    body = m.group(2).split("\n")
-    assert sum("v_mfma" in l for l in body) > 3000
-    assert not [l for l in body if "scratch_" in l]
+    for m in post:
+        body = m.group(2).split("\n")
+        assert sum("v_mfma" in l for l in body) > 1000
+        assert not [l for l in body if "scratch_" in l], m.group(1)
