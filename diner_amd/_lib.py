@@ -57,6 +57,16 @@ SIGNATURES = {
     "diner_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                         C.POINTER(C.c_longlong)]),
     "diner_index_f32": (C.c_int, [C.POINTER(DinerScene), C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "diner_gemm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "diner_train_inputs_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_scatter_latent_grad_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "diner_view_mean_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p]),
+    "diner_colsum_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "diner_field_act_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
+    "diner_composite_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_depth2normal_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_gen_rays_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),

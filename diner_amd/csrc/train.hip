@@ -1,0 +1,354 @@
+// Training path of the field MLP and the compositor: un-fused forward that keeps the
+// activations, and the backward pass, as plain building blocks driven by diner_amd/train.py:
+//   * one general fp32 GEMM on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products) with the epilogues the
+//     ResnetFC backward needs: relu on either operand, bias, "+=" output, relu mask from a saved pre-activation,
+//     split-K with atomics for the weight gradients;
+//   * the per-(view, point) inputs (55 encoded features, 4 bilinear taps, interpolated latent) and the scatter-add of
+//     the latent gradient through the same taps;
+//   * view mean / its adjoint, the output activations and their adjoint, bias-gradient column sums;
+//   * the adjoint of the compositor.
+// Training batches are small (reference: 128 rays x 40 samples x 4 views = 20 k columns per object and step,
+// configs/train_dtu.yaml:55-65), so these kernels are written for clarity: the fused inference kernels stay the fast path.
+// Reference: ResnetFC.forward resnetfc.py:129-159, PixelNeRF.forward pixelnerf.py:55-145, NeRFRendererDGS.composite
+// nerf_renderer.py:286-365, differentiated by torch autograd in DINER.calc_losses (diner.py:217-290).
+#include "field_common.hpp"
+
+namespace diner {
+namespace train {
+
+constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
+enum : int { kTA = 1, kTB = 2, kReluA = 4, kReluB = 8, kAccum = 16, kAtomic = 32 };
+
+struct GemmArgs {
+  const float* A;       // op(A) is M x K: stored [M][lda] (or [K][lda] with kTA)
+  const float* B;       // op(B) is K x N: stored [K][ldb] (or [N][ldb] with kTB)
+  float* C;             // M x N, [M][ldc]
+  const float* bias;    // N or null: added to every row
+  const float* mask;    // M x N (ldc) or null: C *= (mask > 0)   (relu adjoint with the saved pre-activation)
+  long long M;
+  int N, K, lda, ldb, ldc, flags, k_chunk;      // k_chunk: K range per blockIdx.z (split-K, needs kAtomic)
+};
+
+// C tile 64 x 64 per workgroup, four waves 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles; operands staged k-major in LDS.
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+  __shared__ float As[BK][BM + PAD], Bs[BK][BN + PAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool ta = g.flags & kTA, tb = g.flags & kTB, ra = g.flags & kReluA, rb = g.flags & kReluB;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // 64 x 16 elements of each operand, four per thread; the fast index follows the storage order
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;
+      int am, ak;
+      if (ta) { am = idx & 63; ak = idx >> 6; } else { ak = idx & 15; am = idx >> 4; }
+      float av = 0.0f;
+      if (m0 + am < g.M && k0 + ak < kend)
+        av = ta ? g.A[(size_t)(k0 + ak) * g.lda + (m0 + am)] : g.A[(size_t)(m0 + am) * g.lda + (k0 + ak)];
+      As[ak][am] = ra ? fmaxf(av, 0.0f) : av;
+      int bn, bk;
+      if (tb) { bk = idx & 15; bn = idx >> 4; } else { bn = idx & 63; bk = idx >> 6; }
+      float bv = 0.0f;
+      if (n0 + bn < g.N && k0 + bk < kend)
+        bv = tb ? g.B[(size_t)(n0 + bn) * g.ldb + (k0 + bk)] : g.B[(size_t)(k0 + bk) * g.ldb + (n0 + bn)];
+      Bs[bk][bn] = rb ? fmaxf(bv, 0.0f) : bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kk + (lane >> 4)][32 * wm + 16 * i + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kk + (lane >> 4)][32 * wn + 16 * j + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D layout: lane holds rows 4 (lane >> 4) .. + 3 of column lane & 15
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 32 * wn + 16 * j + (lane & 15);
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long m = m0 + 32 * wm + 16 * i + 4 * (lane >> 4) + r;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r];
+        float* c = g.C + (size_t)m * g.ldc + n;
+        if (g.bias && blockIdx.z == 0) v += g.bias[n];
+        if (g.mask && !(g.mask[(size_t)m * g.ldc + n] > 0.0f)) v = 0.0f;
+        if (g.flags & kAtomic) atomicAdd(c, v);
+        else if (g.flags & kAccum) *c += v;
+        else *c = v;
+      }
+    }
+}
+
+// ---- per-(view, point) inputs ---------------------------------------------------------------------------------
+// one 64-lane wave per (view, 16 points): the front end of the inference kernels, written out instead of consumed
+__global__ __launch_bounds__(256) void k_train_inputs(SceneDev sc, FieldArgs fa, float* __restrict__ feat,
+                                                      int* __restrict__ tap_row, float* __restrict__ tap_w) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, pt = lane & 15;
+  const long long n_t16 = (fa.P + 15) / 16;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= n_t16 * sc.nv) return;
+  const int v = (int)(wid / n_t16);
+  const long long p = (wid - (long long)v * n_t16) * 16 + pt;
+  if (p >= fa.P) return;
+  Taps taps;
+  float f[16];
+  field_frontend(sc, fa, v, q, p, taps, f);
+  const size_t col = (size_t)v * fa.P + p;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) feat[col * kDInPad + 16 * m + 4 * q + r] = f[4 * m + r];
+  if (q == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tap_row[col * 4 + k] = (int)(taps.off[k] / kLatent);
+      tap_w[col * 4 + k] = taps.w[k];
+    }
+  }
+}
+
+// lat[col][c] = sum_k w_k latent_cl[row_k][c]      (SpatialEncoder.index, bilinear / border, image_encoder.py:97-146)
+__global__ __launch_bounds__(256) void k_gather_latent(const float* __restrict__ latent_cl, const int* __restrict__ tap_row,
+                                                       const float* __restrict__ tap_w, long long cols,
+                                                       float* __restrict__ lat) {
+  const long long col = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= cols) return;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(latent_cl + (size_t)tap_row[col * 4 + k] * kLatent + 256 * h + 4 * lane);
+      s += t * tap_w[col * 4 + k];
+    }
+    *reinterpret_cast<f32x4*>(lat + (size_t)col * kLatent + 256 * h + 4 * lane) = s;
+  }
+}
+
+// adjoint: d_latent_cl[row_k][c] += w_k d_lat[col][c]
+__global__ __launch_bounds__(256) void k_scatter_latent(const float* __restrict__ d_lat, const int* __restrict__ tap_row,
+                                                        const float* __restrict__ tap_w, long long cols,
+                                                        float* __restrict__ d_latent_cl) {
+  const long long col = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= cols) return;
+  const int lane = threadIdx.x & 63;
+  for (int c = lane; c < kLatent; c += 64) {
+    const float gv = d_lat[(size_t)col * kLatent + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(d_latent_cl + (size_t)tap_row[col * 4 + k] * kLatent + c, gv * tap_w[col * 4 + k]);
+  }
+}
+
+// y[p][c] = mean_v x[v][p][c]   (combine_interleaved, resnetfc.py:150-152); adjoint: dx[v][p][c] = dy[p][c] / nv
+__global__ void k_view_mean(const float* __restrict__ x, int nv, long long PC, float* __restrict__ y) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < PC; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int v = 0; v < nv; ++v) s += x[(size_t)v * PC + i];
+    y[i] = s / (float)nv;
+  }
+}
+__global__ void k_view_bcast(const float* __restrict__ dy, int nv, long long PC, float* __restrict__ dx) {
+  const float inv = 1.0f / (float)nv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < PC; i += (long long)gridDim.x * blockDim.x) {
+    const float gv = dy[i] * inv;
+    for (int v = 0; v < nv; ++v) dx[(size_t)v * PC + i] = gv;
+  }
+}
+
+// db[n] += sum_m dY[m][n]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, long long M, int N, int ld, float* __restrict__ db) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  if (n >= N) return;
+  float s = 0.0f;
+  for (long long m = (long long)blockIdx.y * 4 + part; m < M; m += (long long)gridDim.y * 4) s += dY[(size_t)m * ld + n];
+  atomicAdd(db + n, s);
+}
+
+// out = [sigmoid(raw rgb), relu(raw sigma)]  (pixelnerf.py:139-143) and its adjoint
+__global__ void k_field_act(const float* __restrict__ raw, long long P, int ld, float* __restrict__ out) {
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+    const float* r = raw + (size_t)p * ld;
+    f32x4 o;
+    o[0] = 1.0f / (1.0f + expf(-r[0]));
+    o[1] = 1.0f / (1.0f + expf(-r[1]));
+    o[2] = 1.0f / (1.0f + expf(-r[2]));
+    o[3] = fmaxf(r[3], 0.0f);
+    reinterpret_cast<f32x4*>(out)[p] = o;
+  }
+}
+__global__ void k_field_act_bwd(const float* __restrict__ raw, const float* __restrict__ dout, long long P, int ld,
+                                float* __restrict__ draw) {
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+    const float* r = raw + (size_t)p * ld;
+    const f32x4 g4 = reinterpret_cast<const f32x4*>(dout)[p];
+    float* d = draw + (size_t)p * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float s = 1.0f / (1.0f + expf(-r[c]));
+      d[c] = g4[c] * s * (1.0f - s);
+    }
+    d[3] = r[3] > 0.0f ? g4[3] : 0.0f;
+    for (int c = 4; c < ld; ++c) d[c] = 0.0f;
+  }
+}
+
+// Adjoint of the compositing arithmetic (nerf_renderer.py:299-301, :341-360) with respect to the field values:
+//   delta_k = z_{k+1} - z_k (last: far - z_K); s_k = relu(sigma_k); a_k = 1 - exp(-delta_k s_k); t_k = 1 - a_k + 1e-10;
+//   T_k = prod_{j<k} t_j; w_k = a_k T_k; rgb = sum w c (+ 1 - sum w); depth = sum w z.
+// One thread per ray (K <= 256): G_k = g_rgb.c_k + g_depth z_k - [white] sum(g_rgb); dL/da_k = G_k T_k - S_k / t_k with
+// S_k = sum_{m>k} G_m w_m; dL/dsigma_k = dL/da_k * delta_k (1 - a_k) * [sigma_k > 0]; dL/dc_k = w_k g_rgb.
+constexpr int kCompBwdMaxK = 256;
+__global__ void k_composite_bwd(const float* __restrict__ field, const float* __restrict__ z, const float* __restrict__ rays,
+                                int NR, int K, int white, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                float* __restrict__ d_field) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= NR) return;
+  const float far = rays[(size_t)r * 8 + 7];
+  const float gr = g_rgb[3 * r], gg = g_rgb[3 * r + 1], gb = g_rgb[3 * r + 2];
+  const float gd = g_depth ? g_depth[r] : 0.0f;
+  const float gw = white ? (gr + gg + gb) : 0.0f;
+  const float* f = field + (size_t)r * K * 4;
+  const float* zr = z + (size_t)r * K;
+  float* df = d_field + (size_t)r * K * 4;
+  float T = 1.0f;
+  for (int k = 0; k < K; ++k) {                    // forward sweep: w_k -> dL/dc_k, stash T_k in the sigma slot
+    const float delta = (k + 1 < K ? zr[k + 1] : far) - zr[k];
+    const float a = 1.0f - expf(-delta * fmaxf(f[4 * k + 3], 0.0f));
+    const float w = a * T;
+    df[4 * k + 0] = w * gr;
+    df[4 * k + 1] = w * gg;
+    df[4 * k + 2] = w * gb;
+    df[4 * k + 3] = T;
+    T *= 1.0f - a + 1e-10f;
+  }
+  float S = 0.0f;
+  for (int k = K - 1; k >= 0; --k) {               // backward sweep with the suffix sum S_k
+    const float delta = (k + 1 < K ? zr[k + 1] : far) - zr[k];
+    const float sg = f[4 * k + 3];
+    const float a = 1.0f - expf(-delta * fmaxf(sg, 0.0f));
+    const float t = 1.0f - a + 1e-10f;
+    const float Tk = df[4 * k + 3];
+    const float G = gr * f[4 * k] + gg * f[4 * k + 1] + gb * f[4 * k + 2] + gd * zr[k] - gw;
+    const float da = G * Tk - S / t;
+    df[4 * k + 3] = sg > 0.0f ? da * delta * (1.0f - a) : 0.0f;
+    S += G * a * Tk;
+  }
+}
+
+static int grid1d(long long n, int block = 256, int cap = 8192) {
+  const long long b = (n + block - 1) / block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace train
+}  // namespace diner
+
+using namespace diner;
+using namespace diner::train;
+
+extern "C" int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc,
+                              int flags, const float* bias, const float* mask, int k_split, void* stream) {
+  DINER_CHECK_ARG(A && B && C, "gemm: null pointer argument");
+  DINER_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad sizes M=%lld N=%d K=%d", M, N, K);
+  DINER_CHECK_ARG((flags & ~63) == 0, "gemm: unknown flags 0x%x", flags);
+  DINER_CHECK_ARG(k_split >= 1 && (k_split == 1 || (flags & kAtomic)), "gemm: split-K needs the atomic output flag");
+  DINER_CHECK_ARG(!((flags & kAtomic) && mask), "gemm: a relu mask cannot be combined with atomic accumulation");
+  int chunk = (K + k_split - 1) / k_split;
+  chunk = (chunk + BK - 1) / BK * BK;
+  GemmArgs g{A, B, C, bias, mask, M, N, K, lda, ldb, ldc, flags, chunk};
+  const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM), (K + chunk - 1) / chunk);
+  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, (hipStream_t)stream, g);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P,
+                                      float* feat, int* tap_row, float* tap_w, float* lat, void* stream) {
+  DINER_CHECK_ARG(scene && xyz && viewdirs && feat && tap_row && tap_w && lat, "train_inputs: null pointer argument");
+  DINER_CHECK_ARG(P > 0, "train_inputs: P must be positive");
+  SceneDev sd;
+  int rc = make_scene_dev(scene, &sd);
+  if (rc) return rc;
+  DINER_CHECK_ARG(scene->latent_cl && scene->depth && sd.C == kLatent, "train_inputs: latent (512 channels-last) / depth maps missing");
+  FieldArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.xyz = xyz;
+  fa.viewdirs = viewdirs;
+  fa.K = 1;
+  fa.P = P;
+  fa.freq_factor = 6.28f;
+  const long long waves = (P + 15) / 16 * sd.nv;
+  hipLaunchKernelGGL(k_train_inputs, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sd, fa, feat,
+                     tap_row, tap_w);
+  const long long cols = P * sd.nv;
+  hipLaunchKernelGGL(k_gather_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)scene->latent_cl, tap_row, tap_w, cols, lat);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_scatter_latent_grad_f32(const float* d_lat, const int* tap_row, const float* tap_w, long long cols,
+                                             float* d_latent_cl, void* stream) {
+  DINER_CHECK_ARG(d_lat && tap_row && tap_w && d_latent_cl, "scatter_latent_grad: null pointer argument");
+  DINER_CHECK_ARG(cols > 0, "scatter_latent_grad: cols must be positive");
+  hipLaunchKernelGGL(k_scatter_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_lat, tap_row,
+                     tap_w, cols, d_latent_cl);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_view_mean_f32(const float* x, int nv, long long PC, float* y, int adjoint, void* stream) {
+  DINER_CHECK_ARG(x && y && nv > 0 && PC > 0, "view_mean: bad arguments");
+  if (adjoint) hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y);
+  else hipLaunchKernelGGL(k_view_mean, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_colsum_f32(const float* dY, long long M, int N, int ld, float* db, void* stream) {
+  DINER_CHECK_ARG(dY && db && M > 0 && N > 0 && ld >= N, "colsum: bad arguments");
+  long long gy = (M + 255) / 256;
+  if (gy > 256) gy = 256;
+  hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, dY, M, N, ld, db);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_field_act_f32(const float* raw, const float* dout, long long P, int ld, float* out, void* stream) {
+  DINER_CHECK_ARG(raw && out && P > 0 && ld >= 4, "field_act: bad arguments");
+  if (dout) hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, (hipStream_t)stream, raw, dout, P, ld, out);
+  else hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, (hipStream_t)stream, raw, P, ld, out);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_composite_bwd_f32(const float* field, const float* z, const float* rays, int NR, int K, int white_bkgd,
+                                       const float* g_rgb, const float* g_depth, float* d_field, void* stream) {
+  DINER_CHECK_ARG(field && z && rays && g_rgb && d_field, "composite_bwd: null pointer argument");
+  DINER_CHECK_ARG(NR > 0 && K > 0 && K <= kCompBwdMaxK, "composite_bwd: bad sizes NR=%d K=%d (K <= %d)", NR, K, kCompBwdMaxK);
+  hipLaunchKernelGGL(k_composite_bwd, dim3((NR + 63) / 64), dim3(64), 0, (hipStream_t)stream, field, z, rays, NR, K,
+                     white_bkgd, g_rgb, g_depth, d_field);
+  DINER_LAUNCH_OK();
+  return 0;
+}

@@ -153,6 +153,36 @@ int diner_depth2normal_f32(const float* dmap, const float* K, int N, int H, int 
 int diner_gen_rays_f32(const float* extrinsics, const float* intrinsics, const float* z_near, const float* z_far, int B,
                        int W, int H, long long ray0, long long n_rays, float* out, void* stream);
 
+/* ---- training path: building blocks of the un-fused forward that keeps activations and
+ * of the backward pass that torch autograd performs in DINER.calc_losses (diner.py:217-290); driven by
+ * diner_amd/train.py.  All pointers are device pointers unless noted; enqueue-only on `stream`.
+ *
+ * General fp32 GEMM on the matrix cores, C (M x N, row stride ldc) = op(A) (M x K) . op(B) (K x N), row-major:
+ *   flags: 1 A is stored K x M, 2 B is stored N x K (torch Linear weights: y = x W^T), 4 / 8 relu applied to A / B while
+ *   loading, 16 C += result, 32 atomicAdd into C (required for k_split > 1: weight gradients reduce over ~1e4 rows);
+ *   bias (N) added to every row, mask (M x N, stride ldc): C = 0 where mask <= 0 (relu adjoint). */
+int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc, int flags,
+                   const float* bias, const float* mask, int k_split, void* stream);
+/* Per-(view, point) MLP inputs of PixelNeRF.forward (pixelnerf.py:91-128) for explicit points xyz / viewdirs (P,3):
+ *   feat (NV*P, 64) the 55 encoded inputs zero-padded, tap_row (NV*P, 4) int32 texel rows of the channels-last latent,
+ *   tap_w (NV*P, 4) bilinear weights, lat (NV*P, 512) the interpolated latent (SpatialEncoder.index). */
+int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P, float* feat,
+                           int* tap_row, float* tap_w, float* lat, void* stream);
+/* adjoint of the latent interpolation: d_latent_cl[tap_row][c] += tap_w * d_lat[col][c] (atomic; caller zero-fills) */
+int diner_scatter_latent_grad_f32(const float* d_lat, const int* tap_row, const float* tap_w, long long cols,
+                                  float* d_latent_cl, void* stream);
+/* y (PC) = mean over nv slabs of x (nv, PC) (resnetfc.py:150-152); adjoint != 0: y (nv, PC) = x (PC) / nv */
+int diner_view_mean_f32(const float* x, int nv, long long PC, float* y, int adjoint, void* stream);
+/* db (N) += column sums of dY (M x N, row stride ld): bias gradients (caller zero-fills) */
+int diner_colsum_f32(const float* dY, long long M, int N, int ld, float* db, void* stream);
+/* dout == NULL: out (P,4) = [sigmoid(raw[:, :3]), relu(raw[:, 3])] (pixelnerf.py:139-143), raw has row stride ld;
+ * dout (P,4) given: out (P, ld) = its adjoint with respect to raw (columns >= 4 zero) */
+int diner_field_act_f32(const float* raw, const float* dout, long long P, int ld, float* out, void* stream);
+/* adjoint of diner_composite_f32 with respect to the field values (nerf_renderer.py:299-301, :341-360):
+ *   g_rgb (NR,3), g_depth (NR) or NULL -> d_field (NR,K,4).  z and rays carry no gradient (the sampler is no_grad). */
+int diner_composite_bwd_f32(const float* field, const float* z, const float* rays, int NR, int K, int white_bkgd,
+                            const float* g_rgb, const float* g_depth, float* d_field, void* stream);
+
 /* ---- arithmetic / kernel variant of the MLP GEMMs (process-wide switch) ------------------------
  * 0 (library default): exact fp32 MFMA (v_mfma_f32_16x16x4_f32), results within fp32 round-off of the reference.
  * 1: "f16x3" split products -- each fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on

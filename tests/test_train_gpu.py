@@ -1,0 +1,118 @@
+"""Row f1 (training path): the HIP GEMM building block against torch, and the gradients of the radiance field and the
+compositor against torch autograd on the CPU oracle (the form in which the reference itself differentiates them,
+diner.py:217-290).  Tolerance: 1e-4 max-norm relative per gradient tensor, as for the forward path."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load, oracle_setup, max_norm_rel
+from oracle import diner_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.as_tensor(np.asarray(a)).float()
+TOL_GRAD = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from diner_amd import ops as _ops
+    return _ops
+
+
+def test_gemm_against_torch(ops):
+    from diner_amd import train
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in ((300, 512, 55), (1000, 4, 512), (4, 512, 2500), (129, 65, 17), (512, 512, 4096)):
+        A = torch.randn(M, K, generator=g); B = torch.randn(K, N, generator=g)
+        bias = torch.randn(N, generator=g); mask = torch.randn(M, N, generator=g)
+        C0 = torch.randn(M, N, generator=g)
+        ref = A.double() @ B.double()
+        Ac, Bc = A.cuda(), B.cuda()
+        At, Bt = A.t().contiguous().cuda(), B.t().contiguous().cuda()
+        scale = ref.abs().max().item()
+
+        def run(a, b, lda, ldb, flags, **kw):
+            C = C0.clone().cuda()
+            train.gemm(a, b, C, M, N, K, lda, ldb, N, flags, **kw)
+            return C.cpu().double()
+        assert (run(Ac, Bc, K, N, 0) - ref).abs().max() / scale < 1e-5
+        assert (run(At, Bc, M, N, train.TA) - ref).abs().max() / scale < 1e-5
+        assert (run(Ac, Bt, K, K, train.TB) - ref).abs().max() / scale < 1e-5
+        assert (run(At, Bt, M, K, train.TA | train.TB) - ref).abs().max() / scale < 1e-5
+        assert (run(Ac, Bc, K, N, train.ACCUM, bias=bias.cuda()) - (ref + bias.double() + C0.double())).abs().max() / scale < 1e-5
+        want = (A.clamp(min=0).double() @ B.clamp(min=0).double()) * (mask > 0).double()
+        assert (run(Ac, Bc, K, N, train.RELU_A | train.RELU_B, mask=mask.cuda()) - want).abs().max() / want.abs().max() < 1e-5
+        C = torch.zeros(M, N).cuda()
+        train.gemm(Ac, Bc, C, M, N, K, K, N, N, train.ATOMIC, k_split=7)
+        assert (C.cpu().double() - ref).abs().max() / scale < 1e-5
+    with pytest.raises(RuntimeError):
+        train.gemm(Ac, Bc, C, M, N, K, K, N, N, 0, k_split=2)             # split-K without the atomic flag
+
+
+def _oracle_grads(scene, w, xyz, dirs, G):
+    scene.latent.requires_grad_(True)
+    names = []
+    for k, v in vars(w).items():
+        for i, t in enumerate(v if isinstance(v, (list, tuple)) else [v]):
+            if torch.is_tensor(t) and t.is_floating_point():
+                t.requires_grad_(True)
+                names.append((k, i if isinstance(v, (list, tuple)) else None, t))
+    out = O.pixelnerf_forward(scene, w, xyz, dirs)
+    (out * G).sum().backward()
+    return out.detach(), scene.latent.grad, {(k, i): t.grad for k, i, t in names}
+
+
+def test_field_forward_and_backward_against_oracle_autograd(ops):
+    from diner_amd import train
+    from tests.tests_train_util import module_param_list
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    P = 200
+    xyz, dirs = T(g["pts"])[:P], T(g["dirs"])[:P]
+    G = torch.randn(P, 4, generator=torch.Generator().manual_seed(3))
+    out_o, dlat_o, gr_o = _oracle_grads(scene, w, xyz, dirs, G)
+    hs = ops.HipScene(sc["latent"].detach().cuda(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(),
+                      sc["src_extrinsics"], sc["src_intrinsics"][:, [0, 1], [0, 1]], sc["src_intrinsics"][:, :2, -1],
+                      sc["image_shape"], sc["feature_padding"])
+    latent = sc["latent"].detach().cuda().requires_grad_(True)
+    params, names = module_param_list(msd)
+    out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
+    e_fwd = max_norm_rel(out.detach().cpu(), g["out"][:P])
+    (out * G.cuda()).sum().backward()
+    e_lat = max_norm_rel(latent.grad.cpu(), dlat_o)
+    worst = ("", 0.0)
+    for p, (k, i) in zip(params, names):
+        e = max_norm_rel(p.grad.cpu(), gr_o[(k, i)])
+        if e > worst[1]:
+            worst = (f"{k}[{i}]", e)
+    print(f"training path: forward {e_fwd:.2e}, d latent {e_lat:.2e}, worst parameter gradient {worst[0]} {worst[1]:.2e}")
+    assert e_fwd < 2e-5 and e_lat < TOL_GRAD and worst[1] < TOL_GRAD
+    assert (latent.grad != 0).any() and all((p.grad != 0).any() for p in params)
+
+
+def test_composite_backward_against_oracle_autograd(ops):
+    from diner_amd import train
+    g = torch.Generator().manual_seed(11)
+    NR, K = 70, 40
+    field = torch.rand(NR, K, 4, generator=g)
+    field[..., 3] = torch.relu(torch.randn(NR, K, generator=g)) * 30
+    rays = torch.zeros(NR, 8); rays[:, 6] = 0.5; rays[:, 7] = 1.5
+    z = (0.5 + torch.rand(NR, K, generator=g)).sort(-1).values.clamp(max=1.49)
+    z[3, -1] = 1.6                                                     # a sample beyond `far`: negative delta (:301)
+    Grgb, Gd = torch.randn(NR, 3, generator=g), torch.randn(NR, generator=g)
+    for white in (False, True):
+        fo = field.clone().requires_grad_(True)
+        _, rgb_o, d_o = O.composite_from_field(fo, rays, z, white)
+        ((rgb_o * Grgb).sum() + (d_o * Gd).sum()).backward()
+        fh = field.clone().cuda().requires_grad_(True)
+        rgb, dep = train.composite_train(fh, z.cuda(), rays.cuda(), white)
+        assert max_norm_rel(rgb.detach().cpu(), rgb_o.detach()) < 1e-5
+        ((rgb * Grgb.cuda()).sum() + (dep * Gd.cuda()).sum()).backward()
+        e = max_norm_rel(fh.grad.cpu(), fo.grad)
+        print(f"compositor adjoint (white={white}): {e:.2e}")
+        assert e < TOL_GRAD
