@@ -36,11 +36,20 @@ class NeRFRendererDGS(torch.nn.Module):
         if not (hasattr(model, "hip_scene") and hasattr(model, "hip_mlp")):
             raise TypeError("diner_amd: `model` must be src.models.pixelnerf.PixelNeRF of this package")
 
-    @staticmethod
-    def _no_grad_only(*tensors):
-        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-            raise NotImplementedError("diner_amd: the HIP renderer has no backward yet (DESIGN.md, row f1); "
-                                      "run under torch.no_grad()")
+    def _render_train(self, model, sb, rays, z, want_weights):
+        """Differentiable composite for one object (training): sample points as in
+        nerf_renderer.py:304, the radiance field and the compositor through diner_amd/train.py (HIP forward + backward).
+        Gradients reach the MLP parameters and encoder.latent; z and rays carry none (the sampler is @no_grad)."""
+        from diner_amd import train
+        NR, K = z.shape
+        r = rays.detach()
+        xyz = (r[:, None, :3] + z[..., None] * r[:, None, 3:6]).reshape(-1, 3)
+        dirs = r[:, None, 3:6].expand(-1, K, -1).reshape(-1, 3)
+        field = train.field_train(model.hip_scene(sb), xyz, dirs, model.encoder.latent[sb],
+                                  train.mlp_params(model.mlp_fine)).view(NR, K, 4)
+        rgb, depth = train.composite_train(field, z, r, self.white_bkgd)
+        w = ops.composite(field.detach(), z, r, self.white_bkgd, want_weights=True)[0] if want_weights else None
+        return w, rgb, depth
 
     def sample_coarse(self, rays, n_coarse=None):
         """Stratified candidates (:39-63) as a stand-alone helper (torch ops on the rays' device).  The depth-guided
@@ -83,23 +92,25 @@ class NeRFRendererDGS(torch.nn.Module):
     def composite(self, model, rays, z_samp):
         """-> weights (SB,B,K), rgb (SB,B,3), depth (SB,B)   (:286-365)."""
         self._check_model(model)
-        self._no_grad_only(rays, z_samp, *model.parameters())
         model._check_poscode()
         SB = rays.shape[0]
-        mlp = model.hip_mlp()
-        res = [ops.render(model.hip_scene(sb), mlp, rays[sb], z_samp[sb], self.white_bkgd, want_weights=True)
-               for sb in range(SB)]
+        if model.needs_grad():
+            res = [self._render_train(model, sb, rays[sb], z_samp[sb].detach(), True) for sb in range(SB)]
+        else:
+            mlp = model.hip_mlp()
+            res = [ops.render(model.hip_scene(sb), mlp, rays[sb], z_samp[sb], self.white_bkgd, want_weights=True)
+                   for sb in range(SB)]
         return tuple(torch.stack([r[i] for r in res]) for i in range(3))
 
     def forward(self, model, rays, want_weights=False):
         """rays (SB,B,8) -> DotMap(fine=DotMap(rgb (SB,B,3), depth (SB,B) [, weights (SB,B,K)]))   (:399-430)."""
         assert len(rays.shape) == 3
         self._check_model(model)
-        self._no_grad_only(rays, *model.parameters())
         model._check_poscode()
         assert self.n_samples >= self.n_gaussian
         SB = rays.shape[0]
-        mlp = model.hip_mlp()
+        training = model.needs_grad()
+        mlp = None if training else model.hip_mlp()
         inj = _noise.current()
         rgbs, depths, wts = [], [], []
         for sb in range(SB):
@@ -107,7 +118,10 @@ class NeRFRendererDGS(torch.nn.Module):
             nz = None if inj is None else tuple(None if t is None else t[sb] for t in inj)
             z = ops.sample_depthguided(scene, rays[sb], self.n_samples, self.n_depth_candidates, self.n_gaussian,
                                        0.05, noise=nz, seed=_seed())
-            w, rgb, depth = ops.render(scene, mlp, rays[sb], z, self.white_bkgd, want_weights=want_weights)
+            if training:
+                w, rgb, depth = self._render_train(model, sb, rays[sb], z, want_weights)
+            else:
+                w, rgb, depth = ops.render(scene, mlp, rays[sb], z, self.white_bkgd, want_weights=want_weights)
             rgbs.append(rgb)
             depths.append(depth)
             wts.append(w)

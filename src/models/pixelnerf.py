@@ -4,7 +4,8 @@ import_obj plugin seam), attributes (`poses`, `focal`, `c`, `image_shape`, `enco
 
 `forward(xyz, viewdirs)` evaluates the radiance field with the fused HIP kernels (projection + positional encoding +
 bilinear feature gather + ResnetFC on fp32 MFMA, diner_amd/csrc/mlp.hip) through diner_field_from_points_f32.
-`encode` is per-image setup and stays in torch ops, as in the reference."""
+`encode` is per-image setup and stays in torch ops, as in the reference.  In grad mode `forward` switches to the training
+path of diner_amd/train.py (HIP forward that keeps activations + HIP backward)."""
 import torch
 
 from diner_amd import ops
@@ -77,6 +78,11 @@ class PixelNeRF(torch.nn.Module):
     def hip_mlp(self):
         return self.mlp_fine.hip_mlp()
 
+    def needs_grad(self):
+        """True when a call must be differentiable: grad mode and some parameter (or the encoded latent) wants a gradient."""
+        return torch.is_grad_enabled() and (self.encoder.latent.requires_grad or
+                                            any(p.requires_grad for p in self.mlp_fine.parameters()))
+
     def _check_poscode(self):
         pc = self.poscode
         if pc.num_freqs != 6 or abs(pc.freq_factor - 6.28) > 1e-12 or not pc.include_input:
@@ -87,9 +93,14 @@ class PixelNeRF(torch.nn.Module):
         """(r, g, b, sigma) at world-space points: xyz (SB,B,3), viewdirs (SB,B,3) -> (SB,B,4) (:55-145)."""
         SB, B, _ = xyz.shape
         assert SB == self.encoder.nobjects
-        if torch.is_grad_enabled() and (xyz.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("diner_amd: the fused HIP radiance field has no backward yet (DESIGN.md, row "
-                                      "f1); run inference under torch.no_grad()")
+        self._check_poscode()
+        if self.needs_grad():
+            # training (SURVEY.md section 8 row f1): un-fused HIP forward that keeps the activations + HIP backward
+            # (diner_amd/train.py); gradients reach the MLP parameters and, through encoder.latent, the image encoder
+            from diner_amd import train
+            params = train.mlp_params(self.mlp_fine)
+            return torch.stack([train.field_train(self.hip_scene(sb), xyz[sb], viewdirs[sb], self.encoder.latent[sb], params)
+                                for sb in range(SB)])
         self._check_poscode()
         mlp = self.hip_mlp()
         return torch.stack([ops.field_from_points(self.hip_scene(sb), mlp, xyz[sb], viewdirs[sb]) for sb in range(SB)])

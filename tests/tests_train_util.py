@@ -2,6 +2,17 @@
 import torch
 
 
+def oracle_key(k):
+    """ResnetFC parameter name -> (MLPWeights field, index)."""
+    parts = k.split(".")
+    kind = "w" if parts[-1] == "weight" else "b"
+    if parts[0] in ("lin_in", "lin_out"):
+        return (f"{parts[0]}_{kind}", None)
+    if parts[0] == "lin_z":
+        return (f"lin_z_{kind}", int(parts[1]))
+    return (f"fc{parts[2][-1]}_{kind}", int(parts[1]))
+
+
 def module_param_list(msd):
     """state dict of src.models.resnetfc.ResnetFC -> (30 leaf tensors on the GPU in diner_amd.train.PARAM_ORDER,
     the matching (MLPWeights field, index) keys of the oracle)."""
