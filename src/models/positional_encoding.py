@@ -28,8 +28,9 @@ class PositionalEncoding(torch.nn.Module):
     def forward(self, x):
         """x (..., d_in) -> (..., d_out): [x, sin(x f0), cos(x f0), sin(x f1), ...] with cos(a) = sin(a + fp32(pi/2))."""
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("diner_amd: the HIP positional encoding has no backward yet "
-                                      "(DESIGN.md, row f1); call under torch.no_grad()")
+            raise NotImplementedError("diner_amd: the stand-alone HIP positional encoding is not differentiable (the "
+                                      "reference never differentiates it with respect to its input either); the training "
+                                      "path is PixelNeRF.forward / NeRFRendererDGS.forward (diner_amd/train.py)")
         assert x.shape[-1] == self.d_in
         return ops.posenc(x, self.num_freqs, self.freq_factor, self.include_input)
 

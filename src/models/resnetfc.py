@@ -77,8 +77,9 @@ class ResnetFC(nn.Module):
         or (NV, B, d_latent + d_in) with combine_dim=0  ->  (SB, B, d_out) / (B, d_out)."""
         assert zx.size(-1) == self.d_latent + self.d_in
         if torch.is_grad_enabled() and (zx.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("diner_amd: the fused HIP MLP has no backward yet (DESIGN.md, row f1); "
-                                      "run inference under torch.no_grad()")
+            raise NotImplementedError("diner_amd: ResnetFC.forward on an explicit matrix is inference-only; the "
+                                      "differentiable path is PixelNeRF.forward / NeRFRendererDGS.forward "
+                                      "(diner_amd/train.py, DESIGN.md row f1)")
         mlp = self.hip_mlp()
         if zx.dim() == 4 and combine_dim in (1, -3):
             return torch.stack([ops.mlp_forward(mlp, zx[i]) for i in range(zx.shape[0])])
