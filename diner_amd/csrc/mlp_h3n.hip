@@ -230,9 +230,6 @@ struct GatherSide {
   int wave, q, pt;
   f32x4 (&xs)[kSlice][kGroups];
   f32x4 r[GD][4];
-#ifdef DINER_HN_W_AT_ISSUE
-  f32x4 wr[GD];
-#endif
   template <int U>
   __device__ __forceinline__ void issue() {
     constexpr int g = U >> 3, mo = U & 7;
@@ -242,42 +239,21 @@ struct GatherSide {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       r[U % GD][k] = *reinterpret_cast<const f32x4*>(base + (tp.off[k] * 2048u + lane_off) + mo * 64);
-#ifdef DINER_HN_W_AT_ISSUE
-    wr[U % GD] = *reinterpret_cast<const f32x4*>(tp.w);
-#endif
   }
   template <int U>
   __device__ __forceinline__ void blend() {
     constexpr int g = U >> 3, mo = U & 7;
-#ifdef DINER_HN_W_AT_ISSUE
-    const f32x4 w = wr[U % GD];
-#else
-#ifdef DINER_HN_NOPUN
-    const float* wp = taps_lds[g * 16 + pt].w;
-    const f32x4 w = {wp[0], wp[1], wp[2], wp[3]};
-#else
-    const f32x4 w = *reinterpret_cast<const f32x4*>(taps_lds[g * 16 + pt].w);
-#endif
-#endif
-#ifdef DINER_HN_FIXL
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(const_cast<f32x4&>(w)));
-#endif
-    // Keep w an opaque register value.  Without this the hipcc 7.2 build of this kernel returns wrong sums whenever
-    // the blend reads its weights from LDS inside the GEMM (standalone it is fine; -amdgpu-waitcnt-forcezero, an
-    // extra s_waitcnt or this empty asm all cure it; LDS / VMEM return order checked in tools/ubench/{lds,vm}_order).
-    asm volatile("" : "+v"(const_cast<f32x4&>(w)));
-#ifdef DINER_HN_FIXV
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(const_cast<f32x4&>(w)));
-#endif
+    f32x4 w = *reinterpret_cast<const f32x4*>(taps_lds[g * 16 + pt].w);
+    // Keep w an opaque register value.  Without this the hipcc 7.2 build of an earlier version of this kernel returned
+    // wrong sums when the blend read its weights from LDS inside the GEMM (standalone it was fine;
+    // -amdgpu-waitcnt-forcezero, an extra s_waitcnt or this empty asm all cured it; LDS / VMEM return order checked in
+    // tools/ubench/{lds,vm}_order; see DESIGN.md "A hazard worth recording").
+    asm volatile("" : "+v"(w));
     const f32x4 (&t)[4] = r[U % GD];
     const f32x4 v = (t[0] * w[0] + t[1] * w[1] + t[2] * w[2] + t[3] * w[3]) * kScale;
-#ifndef DINER_HN_NO_PIN
     asm volatile("" : "+a"(xs[mo][g]));      // keep the accumulator file assignment: read, add, write back
-#endif
     xs[mo][g] += v;
-#ifndef DINER_HN_NO_PIN
     asm volatile("" : "+a"(xs[mo][g]));
-#endif
   }
   // half-step H: quarter 0 requests unit H's taps (ring slot H % GD), quarter 2 blends unit H - GD + 1
   template <int H, int G>
@@ -317,28 +293,12 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   const _Float16* w_blk = a.w + (size_t)4 * 2 * 8192;           // then 6 layers of 4 * 16 * 16 KB
   constexpr size_t kLayerHalfs = (size_t)4 * 16 * 8192;
 
-#ifdef DINER_HN_NO_FRONT
-  float smem_keep[16]; size_t keep_off[4]; float keep_w[4];
-#endif
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     long long p = tile * kPtsPerWave + pt;
     if (p >= fa.P) p = fa.P - 1;
-#ifdef DINER_HN_NO_FRONT      // ablation: price the projection / encoding front end (first tile's inputs reused)
-    static_assert(true, "");
-    Taps taps;
-    float feat[16];
-    if (tile == blockIdx.x) {
-      field_frontend(sc, fa, wave, q, p, taps, feat);
-      for (int i = 0; i < 16; ++i) smem_keep[i] = feat[i];
-      for (int i = 0; i < 4; ++i) { keep_off[i] = taps.off[i]; keep_w[i] = taps.w[i]; }
-    }
-    for (int i = 0; i < 16; ++i) feat[i] = smem_keep[i];
-    for (int i = 0; i < 4; ++i) { taps.off[i] = keep_off[i]; taps.w[i] = keep_w[i]; }
-#else
     Taps taps;
     float feat[16];
     field_frontend(sc, fa, /*view=*/wave, q, p, taps, feat);
-#endif
     __syncthreads();                              // previous tile's readers of B / taps are done
     {   // publish lin_in B operands (scale 1) for column group `wave` and this column's taps
 #pragma unroll
@@ -387,17 +347,6 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       publish<LO>(Bl, wave, lane, ns);
       __syncthreads();
       add_bias(xs, bias + kHidden, wave, q);
-#ifdef DINER_HN_STANDALONE_GATHER
-      {
-        NoSide none;
-        gemm<16, DINER_HN_RING, LO>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
-        if (b < 2) {
-          GatherSide<8> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
-          gs.all();
-        }
-      }
-      continue;
-#endif
       if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
         GatherSide<DINER_HN_GDEPTH> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
         gemm<16, DINER_HN_RING, LO>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, gs);
