@@ -98,6 +98,97 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     }
 }
 
+// The same GEMM with 128 x 128 x 16 tiles for the layer-sized products (N, M >= 128): each wave owns 64 x 64 = 4 x 4 MFMA
+// tiles, so one k-step of 4 costs 8 LDS operand reads for 16 MFMAs (the 64 x 64 kernel: 4 for 4), and the next k-tile's
+// global loads are issued before the current tile's MFMAs.
+constexpr int BM2 = 128, BN2 = 128;
+__global__ __launch_bounds__(256) void k_gemm128(GemmArgs g) {
+  __shared__ float As[2][BK][BM2 + PAD], Bs[2][BK][BN2 + PAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.y * BM2;
+  const int n0 = blockIdx.x * BN2;
+  const int kbeg = blockIdx.z * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool ta = g.flags & kTA, tb = g.flags & kTB, ra = g.flags & kReluA, rb = g.flags & kReluB;
+  float ra_v[8], rb_v[8];
+  auto fetch = [&](int k0) {                       // 128 x 16 elements of each operand, eight per thread
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = tid + 256 * e;
+      int am, ak;
+      if (ta) { am = idx & 127; ak = idx >> 7; } else { ak = idx & 15; am = idx >> 4; }
+      float av = 0.0f;
+      if (m0 + am < g.M && k0 + ak < kend)
+        av = ta ? g.A[(size_t)(k0 + ak) * g.lda + (m0 + am)] : g.A[(size_t)(m0 + am) * g.lda + (k0 + ak)];
+      ra_v[e] = ra ? fmaxf(av, 0.0f) : av;
+      int bn, bk;
+      if (tb) { bk = idx & 15; bn = idx >> 4; } else { bn = idx & 127; bk = idx >> 7; }
+      float bv = 0.0f;
+      if (n0 + bn < g.N && k0 + bk < kend)
+        bv = tb ? g.B[(size_t)(n0 + bn) * g.ldb + (k0 + bk)] : g.B[(size_t)(k0 + bk) * g.ldb + (n0 + bn)];
+      rb_v[e] = rb ? fmaxf(bv, 0.0f) : bv;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = tid + 256 * e;
+      int am, ak, bn, bk;
+      if (ta) { am = idx & 127; ak = idx >> 7; } else { ak = idx & 15; am = idx >> 4; }
+      if (tb) { bk = idx & 15; bn = idx >> 4; } else { bn = idx & 127; bk = idx >> 7; }
+      As[buf][ak][am] = ra_v[e];
+      Bs[buf][bk][bn] = rb_v[e];
+    }
+  };
+  fetch(kbeg);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) fetch(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[buf][kk + (lane >> 4)][64 * wm + 16 * i + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kk + (lane >> 4)][64 * wn + 16 * j + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 64 * wn + 16 * j + (lane & 15);
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long m = m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + r;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r];
+        float* c = g.C + (size_t)m * g.ldc + n;
+        if (g.bias && blockIdx.z == 0) v += g.bias[n];
+        if (g.mask && !(g.mask[(size_t)m * g.ldc + n] > 0.0f)) v = 0.0f;
+        if (g.flags & kAtomic) atomicAdd(c, v);
+        else if (g.flags & kAccum) *c += v;
+        else *c = v;
+      }
+    }
+}
+
 // ---- per-(view, point) inputs ---------------------------------------------------------------------------------
 // one 64-lane wave per (view, 16 points): the front end of the inference kernels, written out instead of consumed
 __global__ __launch_bounds__(256) void k_train_inputs(SceneDev sc, FieldArgs fa, float* __restrict__ feat,
@@ -277,8 +368,13 @@ extern "C" int diner_gemm_f32(const float* A, const float* B, float* C, long lon
   int chunk = (K + k_split - 1) / k_split;
   chunk = (chunk + BK - 1) / BK * BK;
   GemmArgs g{A, B, C, bias, mask, M, N, K, lda, ldb, ldc, flags, chunk};
-  const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM), (K + chunk - 1) / chunk);
-  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, (hipStream_t)stream, g);
+  if (N >= BN2 && M >= BM2) {
+    const dim3 grid((N + BN2 - 1) / BN2, (unsigned)((M + BM2 - 1) / BM2), (K + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, (hipStream_t)stream, g);
+  } else {
+    const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM), (K + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, (hipStream_t)stream, g);
+  }
   DINER_LAUNCH_OK();
   return 0;
 }
