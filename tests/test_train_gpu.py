@@ -194,3 +194,55 @@ def test_module_training_step_against_oracle_autograd(ops):
     # a rgb loss through 40 alpha-composited samples is ill-conditioned in float32: float32 torch autograd itself is
     # ~2e-3 from the float64 gradient on the worst tensor; the HIP path must be no further than that (and 1e-4 when it is easy)
     assert worst[1] < max(TOL_GRAD, 1.5 * worst_o[1]) and e_lat < max(TOL_GRAD, 1.5 * e_lat_o)
+
+
+def test_three_adam_steps_track_torch_autograd(ops):
+    """A miniature of Trainer.fit on the MLP (diner.py:292-299 optimises with Adam): three optimisation steps of a rgb
+    loss through renderer.composite on fixed sample positions, once with the drop-in modules on the HIP training path
+    and once with torch autograd through the CPU oracle; the loss trajectories must agree."""
+    from tests.test_boundary_gpu import setup_model
+    from tests.tests_train_util import oracle_key
+    sc, nerf, R, rays = setup_model(32, 32, 6)
+    nerf.train()
+    NR, K = 64, 40
+    r = rays[torch.linspace(0, rays.shape[0] - 1, NR).long()]
+    gen = torch.Generator().manual_seed(33)
+    z = (r[:, 6:7] + (r[:, 7:8] - r[:, 6:7]) * torch.rand(NR, K, generator=gen).sort(-1).values)
+    target = torch.rand(NR, 3, generator=gen)
+    ren = R(n_samples=K, n_depth_candidates=1000, n_gaussian=15, white_bkgd=True)
+    opt = torch.optim.Adam(nerf.mlp_fine.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        _, rgb, _ = ren.composite(nerf, r.cuda()[None], z.cuda()[None])
+        loss = (rgb[0] - target.cuda()).square().mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    # the same three steps with torch autograd on the CPU oracle
+    _, scene, w, msd, _ = oracle_setup(32, 32, 6)
+    leaves = {}
+    for k, v in vars(w).items():
+        for i, t in enumerate(v if isinstance(v, (list, tuple)) else [v]):
+            if torch.is_tensor(t) and t.is_floating_point():
+                leaves[(k, i if isinstance(v, (list, tuple)) else None)] = t.requires_grad_(True)
+    names = [n for n, _ in nerf.mlp_fine.named_parameters()]
+    opt_o = torch.optim.Adam([leaves[oracle_key(n)] for n in names], lr=1e-3)
+    xyz = (r[:, None, :3] + z[..., None] * r[:, None, 3:6]).reshape(-1, 3)
+    dirs = r[:, None, 3:6].expand(-1, K, -1).reshape(-1, 3)
+    losses_o = []
+    for _ in range(3):
+        opt_o.zero_grad()
+        field = O.pixelnerf_forward(scene, w, xyz, dirs).view(NR, K, 4)
+        _, rgb_o, _ = O.composite_from_field(field, r, z, True)
+        loss = (rgb_o - target).square().mean()
+        loss.backward()
+        opt_o.step()
+        losses_o.append(loss.item())
+    print("losses HIP   ", " ".join(f"{l:.6f}" for l in losses))
+    print("losses oracle", " ".join(f"{l:.6f}" for l in losses_o))
+    assert max(abs(a - b) / b for a, b in zip(losses, losses_o)) < 1e-4
+    worst = max(max_norm_rel(p.detach().cpu(), leaves[oracle_key(n)].detach()) for n, p in nerf.mlp_fine.named_parameters())
+    print(f"weights after 3 Adam steps: worst max-norm relative difference {worst:.2e}")
+    # (informational: Adam's first steps move every weight by +-lr whatever the gradient's size, so weights whose
+    #  gradient is ~0 can step in opposite directions in the two runs; the loss trajectory is the meaningful check)
