@@ -115,38 +115,103 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool ta = g.flags & kTA, tb = g.flags & kTB, ra = g.flags & kReluA, rb = g.flags & kReluB;
+  // Operand staging: two float4 per thread and operand along the storage's contiguous dimension when the whole tile is
+  // in range and 16 B aligned (every layer-sized product of the MLP), else the element-wise path below.
+  const bool vec_a = ((g.lda & 3) == 0) && ((reinterpret_cast<size_t>(g.A) & 15) == 0) && m0 + BM2 <= g.M;
+  const bool vec_b = ((g.ldb & 3) == 0) && ((reinterpret_cast<size_t>(g.B) & 15) == 0) && n0 + BN2 <= g.N;
   float ra_v[8], rb_v[8];
   auto fetch = [&](int k0) {                       // 128 x 16 elements of each operand, eight per thread
+    const bool kfull = k0 + BK <= kend;
+    if (vec_a && kfull) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = tid + 256 * e;
-      int am, ak;
-      if (ta) { am = idx & 127; ak = idx >> 7; } else { ak = idx & 15; am = idx >> 4; }
-      float av = 0.0f;
-      if (m0 + am < g.M && k0 + ak < kend)
-        av = ta ? g.A[(size_t)(k0 + ak) * g.lda + (m0 + am)] : g.A[(size_t)(m0 + am) * g.lda + (k0 + ak)];
-      ra_v[e] = ra ? fmaxf(av, 0.0f) : av;
-      int bn, bk;
-      if (tb) { bk = idx & 15; bn = idx >> 4; } else { bn = idx & 127; bk = idx >> 7; }
-      float bv = 0.0f;
-      if (n0 + bn < g.N && k0 + bk < kend)
-        bv = tb ? g.B[(size_t)(n0 + bn) * g.ldb + (k0 + bk)] : g.B[(size_t)(k0 + bk) * g.ldb + (n0 + bn)];
-      rb_v[e] = rb ? fmaxf(bv, 0.0f) : bv;
+      for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 256 * e;             // float4 index
+        const float* src = ta ? g.A + (size_t)(k0 + (idx >> 5)) * g.lda + (m0 + 4 * (idx & 31))
+                              : g.A + (size_t)(m0 + (idx >> 2)) * g.lda + (k0 + 4 * (idx & 3));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ra_v[4 * e + c] = ra ? fmaxf(v[c], 0.0f) : v[c];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = tid + 256 * e;
+        int am, ak;
+        if (ta) { am = idx & 127; ak = idx >> 7; } else { ak = idx & 15; am = idx >> 4; }
+        float av = 0.0f;
+        if (m0 + am < g.M && k0 + ak < kend)
+          av = ta ? g.A[(size_t)(k0 + ak) * g.lda + (m0 + am)] : g.A[(size_t)(m0 + am) * g.lda + (k0 + ak)];
+        ra_v[e] = ra ? fmaxf(av, 0.0f) : av;
+      }
+    }
+    if (vec_b && kfull) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 256 * e;
+        const float* src = tb ? g.B + (size_t)(n0 + (idx >> 2)) * g.ldb + (k0 + 4 * (idx & 3))
+                              : g.B + (size_t)(k0 + (idx >> 5)) * g.ldb + (n0 + 4 * (idx & 31));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rb_v[4 * e + c] = rb ? fmaxf(v[c], 0.0f) : v[c];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = tid + 256 * e;
+        int bn, bk;
+        if (tb) { bk = idx & 15; bn = idx >> 4; } else { bn = idx & 127; bk = idx >> 7; }
+        float bv = 0.0f;
+        if (n0 + bn < g.N && k0 + bk < kend)
+          bv = tb ? g.B[(size_t)(n0 + bn) * g.ldb + (k0 + bk)] : g.B[(size_t)(k0 + bk) * g.ldb + (n0 + bn)];
+        rb_v[e] = rb ? fmaxf(bv, 0.0f) : bv;
+      }
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, int k0) {
+    const bool kfull = k0 + BK <= kend;
+    if (vec_a && kfull) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = tid + 256 * e;
-      int am, ak, bn, bk;
-      if (ta) { am = idx & 127; ak = idx >> 7; } else { ak = idx & 15; am = idx >> 4; }
-      if (tb) { bk = idx & 15; bn = idx >> 4; } else { bn = idx & 127; bk = idx >> 7; }
-      As[buf][ak][am] = ra_v[e];
-      Bs[buf][bk][bn] = rb_v[e];
+      for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 256 * e;
+        if (ta) {
+          *reinterpret_cast<f32x4*>(&As[buf][idx >> 5][4 * (idx & 31)]) = (f32x4){ra_v[4 * e], ra_v[4 * e + 1], ra_v[4 * e + 2], ra_v[4 * e + 3]};
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) As[buf][4 * (idx & 3) + c][idx >> 2] = ra_v[4 * e + c];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = tid + 256 * e;
+        int am, ak;
+        if (ta) { am = idx & 127; ak = idx >> 7; } else { ak = idx & 15; am = idx >> 4; }
+        As[buf][ak][am] = ra_v[e];
+      }
+    }
+    if (vec_b && kfull) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 256 * e;
+        if (tb) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Bs[buf][4 * (idx & 3) + c][idx >> 2] = rb_v[4 * e + c];
+        } else {
+          *reinterpret_cast<f32x4*>(&Bs[buf][idx >> 5][4 * (idx & 31)]) = (f32x4){rb_v[4 * e], rb_v[4 * e + 1], rb_v[4 * e + 2], rb_v[4 * e + 3]};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = tid + 256 * e;
+        int bn, bk;
+        if (tb) { bk = idx & 15; bn = idx >> 4; } else { bn = idx & 127; bk = idx >> 7; }
+        Bs[buf][bk][bn] = rb_v[e];
+      }
     }
   };
   fetch(kbeg);
-  stash(0);
+  stash(0, kbeg);
   __syncthreads();
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -164,7 +229,7 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1);
+    if (more) stash(buf ^ 1, k0 + BK);
     __syncthreads();
     buf ^= 1;
   }
