@@ -207,6 +207,15 @@ def test_render_cfg1_end_to_end(ops, precision):
           f"{e_rgb.max().item():.3e}, depth {e_d.max().item():.3e}")
     assert n_diff <= 0.005 * W * H
     assert e_rgb[same].max().item() < TOL and e_d[same].max().item() < TOL
+    # the metric's "PSNR vs ref": the whole 64x64 image (all rays, including the handful with a different sample set)
+    # against the reference's image, colours in [0, 1]
+    mse = (rgb.cpu() - ref_rgb).square().mean().item()
+    mse_same = (rgb.cpu() - ref_rgb)[same].square().mean().item()
+    psnr, psnr_same = (10 * np.log10(1.0 / max(m, 1e-30)) for m in (mse, mse_same))
+    print(f"e2e cfg1 [{precision}]: PSNR of the HIP image against the reference's image {psnr:.1f} dB "
+          f"({psnr_same:.1f} dB without the {n_diff} erf-saturation rays)")
+    # an image 55 dB from the reference's moves a ~30 dB PSNR-vs-ground-truth by < 0.01 dB (the metric allows 0.05)
+    assert psnr > 55.0 and psnr_same > 90.0
 
 
 def test_ray_batch_split_invariance(ops, precision):
