@@ -67,6 +67,12 @@ SIGNATURES = {
     "diner_field_act_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_composite_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_train_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
+    "diner_field_train_forward_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams), C.c_void_p, C.c_void_p,
+                                                C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_train_backward_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams),
+                                                 C.POINTER(DinerMlpParams), C.c_longlong, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]),
     "diner_depth2normal_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_gen_rays_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),

@@ -423,8 +423,8 @@ static int grid1d(long long n, int block = 256, int cap = 8192) {
 using namespace diner;
 using namespace diner::train;
 
-extern "C" int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc,
-                              int flags, const float* bias, const float* mask, int k_split, void* stream) {
+static int gemm_launch(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc,
+                       int flags, const float* bias, const float* mask, int k_split, hipStream_t stream) {
   DINER_CHECK_ARG(A && B && C, "gemm: null pointer argument");
   DINER_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad sizes M=%lld N=%d K=%d", M, N, K);
   DINER_CHECK_ARG((flags & ~63) == 0, "gemm: unknown flags 0x%x", flags);
@@ -435,13 +435,18 @@ extern "C" int diner_gemm_f32(const float* A, const float* B, float* C, long lon
   GemmArgs g{A, B, C, bias, mask, M, N, K, lda, ldb, ldc, flags, chunk};
   if (N >= BN2 && M >= BM2) {
     const dim3 grid((N + BN2 - 1) / BN2, (unsigned)((M + BM2 - 1) / BM2), (K + chunk - 1) / chunk);
-    hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, stream, g);
   } else {
     const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM), (K + chunk - 1) / chunk);
-    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, stream, g);
   }
   DINER_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc,
+                              int flags, const float* bias, const float* mask, int k_split, void* stream) {
+  return gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, flags, bias, mask, k_split, (hipStream_t)stream);
 }
 
 extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P,
@@ -510,6 +515,146 @@ extern "C" int diner_composite_bwd_f32(const float* field, const float* z, const
   DINER_CHECK_ARG(NR > 0 && K > 0 && K <= kCompBwdMaxK, "composite_bwd: bad sizes NR=%d K=%d (K <= %d)", NR, K, kCompBwdMaxK);
   hipLaunchKernelGGL(k_composite_bwd, dim3((NR + 63) / 64), dim3(64), 0, (hipStream_t)stream, field, z, rays, NR, K,
                      white_bkgd, g_rgb, g_depth, d_field);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+// ---- the whole forward / backward of the field as one call each (what diner_amd/train.py does call by call; one entry
+// saves ~100 host round trips per step, which matter at the reference's 128-ray training batch) -------------------------
+namespace {
+struct TrainWs {               // float offsets into the workspace
+  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, total;
+};
+TrainWs train_ws(long long P, int nv) {
+  TrainWs w;
+  const size_t cols = (size_t)P * nv;
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += (n + 63) / 64 * 64; return at; };
+  w.feat = take(cols * kDInPad);
+  w.tap_row = take(cols * 4);
+  w.tap_w = take(cols * 4);
+  w.lat = take(cols * kLatent);
+  for (int b = 0; b < 5; ++b) {
+    const size_t m = b < 3 ? cols : (size_t)P;
+    w.X[b] = take(m * kHidden);
+    w.H[b] = take(m * kHidden);
+  }
+  w.x_last = take((size_t)P * kHidden);
+  w.raw = take((size_t)P * 4);
+  w.d_raw = take((size_t)P * 4);
+  w.dx = take(cols * kHidden);
+  w.dH = take(cols * kHidden);
+  w.d_lat = take(cols * kLatent);
+  w.total = o;
+  return w;
+}
+int check_train_params(const DinerMlpParams* p) {
+  DINER_CHECK_ARG(p && p->lin_in_w && p->lin_in_b && p->lin_out_w && p->lin_out_b && p->fc0_w && p->fc0_b && p->fc1_w &&
+                      p->fc1_b && p->lin_z_w && p->lin_z_b, "field_train: parameter pointers missing");
+  if (p->d_in != kDIn || p->d_latent != kLatent || p->d_hidden != kHidden || p->d_out != 4 || p->n_blocks != 5 ||
+      p->combine_layer != 3) {
+    set_error("field_train: built for d_in=55, d_latent=d_hidden=512, d_out=4, 5 blocks, combine_layer=3");
+    return DINER_E_UNSUPPORTED;
+  }
+  return 0;
+}
+// adjoint of y = act(x) W^T + b: dW = dy^T act(x) (split-K atomics into zeroed dW), db = column sums, dx (+)= (dy W) [masked]
+int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, const float* W, float* dW, float* db,
+               long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st) {
+  DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
+  DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
+  long long split = M / 1024;
+  split = split < 1 ? 1 : (split > 32 ? 32 : split);
+  int rc = gemm_launch(dy, x, dW, N, K, M, ldy, ldx, K, kTA | kAtomic | (relu_in ? kReluB : 0), nullptr, nullptr, (int)split, st);
+  if (rc) return rc;
+  long long gy = (M + 255) / 256;
+  if (gy > 256) gy = 256;
+  hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, (unsigned)gy), dim3(256), 0, st, dy, M, N, ldy, db);
+  if (dx) rc = gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
+  return rc;
+}
+}  // namespace
+
+extern "C" size_t diner_field_train_workspace_bytes(long long P, int nv) {
+  if (P <= 0 || nv <= 0) return 0;
+  return train_ws(P, nv).total * sizeof(float);
+}
+
+extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
+                                             const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
+  DINER_CHECK_ARG(scene && xyz && viewdirs && out && workspace && P > 0, "field_train_forward: bad arguments");
+  int rc = check_train_params(p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const TrainWs w = train_ws(P, scene->nv);
+  const long long cols = P * scene->nv;
+  rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
+  if (rc) return rc;
+  auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
+                 bool accum) {
+    return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st);
+  };
+  if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, false))) return rc;
+  for (int b = 0; b < 5; ++b) {
+    const long long M = b < 3 ? cols : P;
+    float* X = ws + w.X[b];
+    if (b < 3 && (rc = lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], X, M, kHidden, kLatent, false, true))) return rc;
+    if ((rc = lin(X, kHidden, p->fc0_w[b], p->fc0_b[b], ws + w.H[b], M, kHidden, kHidden, true, false))) return rc;
+    // next residual stream: X + fc_1(relu(H)); the view mean comes after block 2
+    float* nx = b == 4 ? ws + w.x_last : (b == 2 ? ws + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
+    DINER_HIP_OK(hipMemcpyAsync(nx, X, (size_t)M * kHidden * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, true))) return rc;
+    if (b == 2)
+      hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3]);
+  }
+  if ((rc = lin(ws + w.x_last, kHidden, p->lin_out_w, p->lin_out_b, ws + w.raw, P, 4, kHidden, true, false))) return rc;
+  hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, P, 4, out);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+// grads: the same structure as the parameters, device buffers of the parameters' shapes (overwritten);
+// d_latent_cl (nv, Hf, Wf, 512) or NULL: overwritten with the gradient of the channels-last feature map
+extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* p, const DinerMlpParams* grads,
+                                              long long P, const float* d_out, void* workspace, float* d_latent_cl,
+                                              void* stream) {
+  DINER_CHECK_ARG(scene && d_out && workspace && P > 0, "field_train_backward: bad arguments");
+  int rc = check_train_params(p);
+  if (rc) return rc;
+  rc = check_train_params(grads);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const TrainWs w = train_ws(P, scene->nv);
+  const long long cols = P * scene->nv;
+  float* dx = ws + w.dx;
+  float* dH = ws + w.dH;
+  hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, ws + w.d_raw);
+  if ((rc = linear_bwd(ws + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
+                       (float*)grads->lin_out_b, P, 4, kHidden, dx, ws + w.x_last, false, st))) return rc;
+  for (int b = 4; b >= 0; --b) {
+    const long long M = b < 3 ? cols : P;
+    const float* X = ws + w.X[b];
+    const float* H = ws + w.H[b];
+    if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
+                         kHidden, kHidden, dH, H, false, st))) return rc;
+    if ((rc = linear_bwd(dH, kHidden, X, kHidden, true, p->fc0_w[b], (float*)grads->fc0_w[b], (float*)grads->fc0_b[b], M,
+                         kHidden, kHidden, dx, X, true, st))) return rc;
+    if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
+                                  (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st))) return rc;
+    if (b == 3) {          // adjoint of the view mean: dH is free here
+      hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P * kHidden)), dim3(256), 0, st, dx, scene->nv, P * kHidden, dH);
+      float* t = dx; dx = dH; dH = t;
+    }
+  }
+  if ((rc = linear_bwd(dx, kHidden, ws + w.feat, kDInPad, false, p->lin_in_w, (float*)grads->lin_in_w,
+                       (float*)grads->lin_in_b, cols, kHidden, kDIn, nullptr, nullptr, false, st))) return rc;
+  if (d_latent_cl) {
+    DINER_HIP_OK(hipMemsetAsync(d_latent_cl, 0, (size_t)scene->nv * scene->Hf * scene->Wf * kLatent * sizeof(float), st));
+    hipLaunchKernelGGL(k_scatter_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, ws + w.d_lat,
+                       (const int*)(ws + w.tap_row), ws + w.tap_w, cols, d_latent_cl);
+  }
   DINER_LAUNCH_OK();
   return 0;
 }

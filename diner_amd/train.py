@@ -5,8 +5,10 @@ touches `fine.rgb` only, gradients flow through the compositor (nerf_renderer.py
 (pixelnerf.py:139-143), ResnetFC (resnetfc.py:129-159) and the bilinear latent lookup (image_encoder.py:97-146) into the
 MLP parameters and the encoder's feature maps; sample positions carry no gradient (`sample_depthguided` is `@no_grad`).
 
-Here that is two `torch.autograd.Function`s whose forward AND backward are sequences of calls into libdiner_hip.so
-(csrc/train.hip: one fp32 MFMA GEMM with the needed epilogues + small kernels); torch only owns the buffers.  The forward
+Here that is two `torch.autograd.Function`s whose forward AND backward are calls into libdiner_hip.so (csrc/train.hip: one
+fp32 MFMA GEMM with the needed epilogues + small kernels, sequenced on the C side); torch only owns the buffers.  The
+building blocks are also exported one by one (`gemm`, `_linear`, `_linear_backward` below drive them from Python; the
+tests use them).  The forward
 is the un-fused one that keeps every pre-activation, which is what a backward pass needs; inference keeps using the fused
 kernels.  Sizes: 128 rays x 40 samples x 4 views = 20 k columns per object and step (configs/train_dtu.yaml).
 """
@@ -63,95 +65,66 @@ def mlp_params(mlp_module):
     return [sd[k] for k in PARAM_ORDER]
 
 
+def _param_struct(tensors):
+    """DinerMlpParams over 30 device tensors in PARAM_ORDER (parameters or gradient buffers); returns (struct, keep-alive)."""
+    import ctypes as C
+    t = dict(zip(PARAM_ORDER, tensors))
+    p = _lib.DinerMlpParams()
+    p.d_in, p.d_hidden, p.d_out = t["lin_in.weight"].shape[1], t["lin_in.weight"].shape[0], t["lin_out.weight"].shape[0]
+    p.d_latent, p.n_blocks, p.combine_layer = t["lin_z.0.weight"].shape[1], 5, 3
+    p.lin_in_w, p.lin_in_b = t["lin_in.weight"].data_ptr(), t["lin_in.bias"].data_ptr()
+    p.lin_out_w, p.lin_out_b = t["lin_out.weight"].data_ptr(), t["lin_out.bias"].data_ptr()
+    keep = [tensors]
+    for field, fmt, n in (("fc0_w", "blocks.{}.fc_0.weight", 5), ("fc0_b", "blocks.{}.fc_0.bias", 5),
+                          ("fc1_w", "blocks.{}.fc_1.weight", 5), ("fc1_b", "blocks.{}.fc_1.bias", 5),
+                          ("lin_z_w", "lin_z.{}.weight", 3), ("lin_z_b", "lin_z.{}.bias", 3)):
+        arr = (C.c_void_p * n)(*[t[fmt.format(i)].data_ptr() for i in range(n)])
+        keep.append(arr)
+        setattr(p, field, C.cast(arr, C.POINTER(C.c_void_p)))
+    return p, keep
+
+
 class FieldFunction(torch.autograd.Function):
     """PixelNeRF.forward (pixelnerf.py:55-145) for one object: (xyz, viewdirs) (P,3) -> (P,4) [sigmoid rgb, relu sigma],
-    differentiable with respect to the encoder's latent (NV,512,Hf,Wf) and the MLP parameters."""
+    differentiable with respect to the encoder's latent (NV,512,Hf,Wf) and the MLP parameters.  One library call for the
+    forward (keeps every pre-activation in `ws`), one for the backward (diner_field_train_{forward,backward}_f32)."""
 
     @staticmethod
     def forward(ctx, scene: HipScene, xyz, viewdirs, latent, *params):
+        import ctypes as C
         _require_hip(xyz, viewdirs, latent)
         xyz, viewdirs = _f32c(xyz.detach()), _f32c(viewdirs.detach())
         params = [_f32c(p.detach()) for p in params]
         P, NV = xyz.shape[0], scene.nv
-        cols = NV * P
         dev = xyz.device
-        w_in, b_in = params[0], params[1]
-        wz = [(params[2 + 2 * b], params[3 + 2 * b]) for b in range(3)]
-        blk = [tuple(params[8 + 4 * b: 12 + 4 * b]) for b in range(5)]
-        w_out, b_out = params[-2], params[-1]
         with torch.cuda.device(dev):
-            feat = torch.empty(cols, 64, device=dev)
-            tap_row = torch.empty(cols, 4, device=dev, dtype=torch.int32)
-            tap_w = torch.empty(cols, 4, device=dev)
-            lat = torch.empty(cols, 512, device=dev)
-            _lib.check(lib.diner_train_inputs_f32(scene.ref, _ptr(xyz), _ptr(viewdirs), P, _ptr(feat), _ptr(tap_row),
-                                                  _ptr(tap_w), _ptr(lat), _stream()))
-            x = _linear(feat, w_in, b_in)                                        # resnetfc.py:143
-            X, Hh = [], []
-            for b in range(5):
-                if b == 3:                                                       # combine_interleaved (:150-152)
-                    xm = torch.empty(P, 512, device=dev)
-                    _lib.check(lib.diner_view_mean_f32(_ptr(x), NV, P * 512, _ptr(xm), 0, _stream()))
-                    x = xm
-                if b < 3:
-                    _linear(lat, wz[b][0], wz[b][1], out=x, accumulate=True)     # x = x + lin_z[b](z) (:153-155)
-                w0, b0, w1, b1 = blk[b]
-                h = _linear(x, w0, b0, relu_in=True)                             # fc_0(relu(x))   (resnetfc.py:61-69)
-                X.append(x)
-                Hh.append(h)
-                x = x.clone()
-                _linear(h, w1, b1, out=x, relu_in=True, accumulate=True)         # x + fc_1(relu(h))
-            raw = _linear(x, w_out, b_out, relu_in=True)                         # lin_out(relu(x)) (:157)
+            ws = torch.empty(int(lib.diner_field_train_workspace_bytes(P, NV)), dtype=torch.uint8, device=dev)
             out = torch.empty(P, 4, device=dev)
-            _lib.check(lib.diner_field_act_f32(_ptr(raw), None, P, 4, _ptr(out), _stream()))
-        ctx.scene, ctx.P, ctx.NV = scene, P, NV
+            ps, keep = _param_struct(params)
+            _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
+                                                         _ptr(ws), _stream()))
+        ctx.scene, ctx.P = scene, P
         ctx.latent_shape = tuple(latent.shape)
-        ctx.save_for_backward(feat, tap_row, tap_w, lat, x, raw, *X, *Hh, *params)
+        ctx.save_for_backward(ws, *params)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        saved = ctx.saved_tensors
-        feat, tap_row, tap_w, lat, x_last, raw = saved[:6]
-        X, Hh, params = list(saved[6:11]), list(saved[11:16]), list(saved[16:])
-        P, NV = ctx.P, ctx.NV
-        cols = NV * P
+        import ctypes as C
+        ws, params = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
         dev = d_out.device
-        w_in = params[0]
-        wz = [params[2 + 2 * b] for b in range(3)]
-        blk = [tuple(params[8 + 4 * b: 12 + 4 * b]) for b in range(5)]
-        w_out = params[-2]
-        grads = [None] * len(params)
         with torch.cuda.device(dev):
             d_out = _f32c(d_out)
-            d_raw = torch.empty(P, 4, device=dev)
-            _lib.check(lib.diner_field_act_f32(_ptr(raw), _ptr(d_out), P, 4, _ptr(d_raw), _stream()))
-            grads[-2], grads[-1], dx = _linear_backward(d_raw, x_last, w_out, relu_in=True, dx_mask=x_last)
-            d_lat = None
-            for b in range(4, -1, -1):
-                w0, _, w1, _ = blk[b]
-                # x_out = X + fc_1(relu(H)),  H = fc_0(relu(X))
-                gw1, gb1, dH = _linear_backward(dx, Hh[b], w1, relu_in=True, dx_mask=Hh[b])
-                gw0, gb0, _ = _linear_backward(dH, X[b], w0, relu_in=True, dx_out=dx, dx_mask=X[b], dx_accumulate=True)
-                grads[8 + 4 * b: 12 + 4 * b] = [gw0, gb0, gw1, gb1]
-                if b < 3:                                                        # X = x_prev + lin_z[b](lat)
-                    if d_lat is None:
-                        d_lat = torch.empty(cols, 512, device=dev)
-                    gz, gbz, _ = _linear_backward(dx, lat, wz[b], relu_in=False, dx_out=d_lat, dx_accumulate=(b < 2))
-                    grads[2 + 2 * b], grads[3 + 2 * b] = gz, gbz
-                if b == 3:                                                       # adjoint of the view mean
-                    dxv = torch.empty(cols, 512, device=dev)
-                    _lib.check(lib.diner_view_mean_f32(_ptr(dx), NV, P * 512, _ptr(dxv), 1, _stream()))
-                    dx = dxv
-            grads[0], grads[1], _ = _linear_backward(dx, feat, w_in, relu_in=False, need_dx=False)
-            d_latent = None
+            grads = [torch.empty_like(p) for p in params]
+            ps, keep = _param_struct(params)
+            gs, keep_g = _param_struct(grads)
+            d_cl = None
             if ctx.needs_input_grad[3]:
-                nv, C, Hf, Wf = ctx.latent_shape
-                d_cl = torch.zeros(nv, Hf, Wf, C, device=dev)
-                _lib.check(lib.diner_scatter_latent_grad_f32(_ptr(d_lat), _ptr(tap_row), _ptr(tap_w), cols, _ptr(d_cl),
-                                                             _stream()))
-                d_latent = d_cl.permute(0, 3, 1, 2)
-        return (None, None, None, d_latent) + tuple(grads)
+                nv, Cc, Hf, Wf = ctx.latent_shape
+                d_cl = torch.empty(nv, Hf, Wf, Cc, device=dev)
+            _lib.check(lib.diner_field_train_backward_f32(ctx.scene.ref, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out),
+                                                          _ptr(ws), _ptr(d_cl), _stream()))
+        return (None, None, None, d_cl.permute(0, 3, 1, 2) if d_cl is not None else None) + tuple(grads)
 
 
 class CompositeFunction(torch.autograd.Function):

@@ -183,6 +183,20 @@ int diner_field_act_f32(const float* raw, const float* dout, long long P, int ld
 int diner_composite_bwd_f32(const float* field, const float* z, const float* rays, int NR, int K, int white_bkgd,
                             const float* g_rgb, const float* g_depth, float* d_field, void* stream);
 
+/* The whole training forward / backward of the field for one object as one call each (the sequences of the building
+ * blocks above that PixelNeRF.forward + ResnetFC.forward and their autograd adjoints amount to; pixelnerf.py:55-145,
+ * resnetfc.py:129-159).  `params`: DEVICE parameter tensors in nn.Linear layout (d_in=55, d_latent=d_hidden=512, 5 blocks,
+ * combine_layer=3); `workspace`: diner_field_train_workspace_bytes(P, nv) bytes, written by the forward (saved
+ * pre-activations, taps, interpolated latent) and consumed by the backward of the same call pair.
+ *   forward : xyz, viewdirs (P,3) -> out (P,4) = [sigmoid rgb, relu sigma]
+ *   backward: d_out (P,4) -> `grads` (same structure as `params`, device buffers of the parameters' shapes, overwritten)
+ *             and d_latent_cl (nv,Hf,Wf,512) or NULL (gradient of the channels-last feature map, overwritten). */
+size_t diner_field_train_workspace_bytes(long long P, int nv);
+int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* params, const float* xyz,
+                                  const float* viewdirs, long long P, float* out, void* workspace, void* stream);
+int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* params, const DinerMlpParams* grads,
+                                   long long P, const float* d_out, void* workspace, float* d_latent_cl, void* stream);
+
 /* ---- arithmetic / kernel variant of the MLP GEMMs (process-wide switch) ------------------------
  * 0 (library default): exact fp32 MFMA (v_mfma_f32_16x16x4_f32), results within fp32 round-off of the reference.
  * 1: "f16x3" split products -- each fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on
