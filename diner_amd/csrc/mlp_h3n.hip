@@ -221,8 +221,8 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
 #endif
 
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
-// (g, mo) of 4 taps each.  As a GEMM side task one unit's taps are requested per half-step and blended / added GD
-// half-steps later (the additions commute with the GEMM's accumulation into the same registers).
+// (g, mo) of 4 taps each.  As a GEMM side task one unit's taps are requested per half-step, one per quarter-step, and
+// blended / added GD - 1 half-steps later (the additions commute with the GEMM's accumulation into the same registers).
 template <int GD>
 struct GatherSide {
   const float* __restrict__ tz;
@@ -230,15 +230,13 @@ struct GatherSide {
   int wave, q, pt;
   f32x4 (&xs)[kSlice][kGroups];
   f32x4 r[GD][4];
-  template <int U>
-  __device__ __forceinline__ void issue() {
+  template <int U, int KTAP>       // one of the unit's four taps (the GEMM side task spreads them over the quarter-steps)
+  __device__ __forceinline__ void issue_tap() {
     constexpr int g = U >> 3, mo = U & 7;
-    const TapRec tp = taps_lds[g * 16 + pt];
+    const unsigned off = taps_lds[g * 16 + pt].off[KTAP];
     const char* base = reinterpret_cast<const char*>(tz);          // scalar base + 32-bit lane offset + immediate
     const unsigned lane_off = (32 * wave + q) * 16;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      r[U % GD][k] = *reinterpret_cast<const f32x4*>(base + (tp.off[k] * 2048u + lane_off) + mo * 64);
+    r[U % GD][KTAP] = *reinterpret_cast<const f32x4*>(base + (off * 2048u + lane_off) + mo * 64);
   }
   template <int U>
   __device__ __forceinline__ void blend() {
@@ -259,8 +257,11 @@ struct GatherSide {
   template <int H, int G>
   __device__ __forceinline__ void run() {
 #ifndef DINER_HN_NO_GATHER
-    if constexpr (G == 0 && H < 32) issue<H>();
-    if constexpr (G == 2 && H - GD + 1 >= 0 && H - GD + 1 < 32) blend<(H - GD + 1 >= 0 ? H - GD + 1 : 0)>();
+    // one tap per quarter-step (a smoother request stream for the vector-memory path: +2 % over four at once), the
+    // blend of unit H - GD + 1 in the last quarter, four quarter-steps after its last tap was requested (GD >= 2)
+    static_assert(GD >= 2, "the blend of a unit comes one half-step after its last tap request");
+    if constexpr (G == 3 && H - GD + 1 >= 0 && H - GD + 1 < 32) blend<(H - GD + 1 >= 0 ? H - GD + 1 : 0)>();
+    if constexpr (H < 32) issue_tap<(H < 32 ? H : 0), G>();
 #endif
   }
   __device__ __forceinline__ void finish() {
@@ -272,7 +273,9 @@ struct GatherSide {
   __device__ __forceinline__ void all() {
     static_for<32>([&](auto H) {
       run<decltype(H)::value, 0>();
+      run<decltype(H)::value, 1>();
       run<decltype(H)::value, 2>();
+      run<decltype(H)::value, 3>();
     });
     finish();
   }
