@@ -216,6 +216,45 @@ struct FieldArgs {
   float* xpre;                  // (P/16 tiles, NV, 32, 64) f32x4
 };
 
+// sample point p of the call: position (and viewing direction) from explicit xyz / viewdirs or from (ray, z)
+__device__ __forceinline__ void load_point(const FieldArgs& a, long long p, float& px, float& py, float& pz, float& dx,
+                                           float& dy, float& dz) {
+  if (a.xyz) {
+    px = a.xyz[p * 3 + 0]; py = a.xyz[p * 3 + 1]; pz = a.xyz[p * 3 + 2];
+    dx = a.viewdirs[p * 3 + 0]; dy = a.viewdirs[p * 3 + 1]; dz = a.viewdirs[p * 3 + 2];
+  } else {
+    const long long ray = p / a.K;
+    const float* r = a.rays + ray * 8;
+    const float zz = a.z[p];
+    dx = r[3]; dy = r[4]; dz = r[5];
+    px = __fadd_rn(r[0], __fmul_rn(zz, dx));                                 // nerf_renderer.py:304
+    py = __fadd_rn(r[1], __fmul_rn(zz, dy));
+    pz = __fadd_rn(r[2], __fmul_rn(zz, dz));
+  }
+}
+
+// bilinear / border taps of view v on the padded feature map at normalised image position (u, w)
+// (image_encoder.py:112-123)
+__device__ __forceinline__ void bilinear_taps(const SceneDev& sc, int v, float u, float w, Taps& taps) {
+  const int Wf = sc.Wf, Hf = sc.Hf;
+  const float su = __fmul_rn(u, __fdiv_rn(__fsub_rn((float)Wf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Wf));
+  const float sv = __fmul_rn(w, __fdiv_rn(__fsub_rn((float)Hf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Hf));
+  const float fx = clip_border(unnormalize(su, Wf), Wf), fy = clip_border(unnormalize(sv, Hf), Hf);
+  const float x0f = floorf(fx), y0f = floorf(fy);
+  const float wx = fx - x0f, wy = fy - y0f;
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int x1 = min(x0 + 1, Wf - 1), y1 = min(y0 + 1, Hf - 1);
+  const size_t base = (size_t)v * Hf * Wf;
+  taps.off[0] = (base + (size_t)y0 * Wf + x0) * kLatent;
+  taps.off[1] = (base + (size_t)y0 * Wf + x1) * kLatent;
+  taps.off[2] = (base + (size_t)y1 * Wf + x0) * kLatent;
+  taps.off[3] = (base + (size_t)y1 * Wf + x1) * kLatent;
+  taps.w[0] = (1.0f - wy) * (1.0f - wx);
+  taps.w[1] = (1.0f - wy) * wx;
+  taps.w[2] = wy * (1.0f - wx);
+  taps.w[3] = wy * wx;
+}
+
 // Everything per (sample point, view) that precedes the MLP: world->camera transform, projection, nearest depth tap,
 // the 55 encoded inputs (as lin_in B operands: feat[4 m + r] = input 16 m + 4 q + r) and the four bilinear taps.
 __device__ __forceinline__ void field_frontend(const SceneDev& sc, const FieldArgs& a, int v, int q, long long p,
@@ -233,18 +272,7 @@ __device__ __forceinline__ void field_frontend(const SceneDev& sc, const FieldAr
     }
   } else {
     float px, py, pz, dx, dy, dz;
-    if (a.xyz) {
-      px = a.xyz[p * 3 + 0]; py = a.xyz[p * 3 + 1]; pz = a.xyz[p * 3 + 2];
-      dx = a.viewdirs[p * 3 + 0]; dy = a.viewdirs[p * 3 + 1]; dz = a.viewdirs[p * 3 + 2];
-    } else {
-      const long long ray = p / a.K;
-      const float* r = a.rays + ray * 8;
-      const float zz = a.z[p];
-      dx = r[3]; dy = r[4]; dz = r[5];
-      px = __fadd_rn(r[0], __fmul_rn(zz, dx));                                 // nerf_renderer.py:304
-      py = __fadd_rn(r[1], __fmul_rn(zz, dy));
-      pz = __fadd_rn(r[2], __fmul_rn(zz, dz));
-    }
+    load_point(a, p, px, py, pz, dx, dy, dz);
     float xc[3], vd[3];
     world_to_cam(sc.R[v], sc.t[v], px, py, pz, xc[0], xc[1], xc[2]);           // pixelnerf.py:91-93
     vd[0] = rot_row(sc.R[v] + 0, dx, dy, dz);                                  // :100
@@ -259,24 +287,7 @@ __device__ __forceinline__ void field_frontend(const SceneDev& sc, const FieldAr
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) feat[4 * m + r] = input_feature(16 * m + 4 * q + r, xc, vd, dd);
-    // bilinear / border taps on the padded feature map (image_encoder.py:112-123)
-    const int Wf = sc.Wf, Hf = sc.Hf;
-    const float su = __fmul_rn(u, __fdiv_rn(__fsub_rn((float)Wf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Wf));
-    const float sv = __fmul_rn(w, __fdiv_rn(__fsub_rn((float)Hf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Hf));
-    const float fx = clip_border(unnormalize(su, Wf), Wf), fy = clip_border(unnormalize(sv, Hf), Hf);
-    const float x0f = floorf(fx), y0f = floorf(fy);
-    const float wx = fx - x0f, wy = fy - y0f;
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    const int x1 = min(x0 + 1, Wf - 1), y1 = min(y0 + 1, Hf - 1);
-    const size_t base = (size_t)v * Hf * Wf;
-    taps.off[0] = (base + (size_t)y0 * Wf + x0) * kLatent;
-    taps.off[1] = (base + (size_t)y0 * Wf + x1) * kLatent;
-    taps.off[2] = (base + (size_t)y1 * Wf + x0) * kLatent;
-    taps.off[3] = (base + (size_t)y1 * Wf + x1) * kLatent;
-    taps.w[0] = (1.0f - wy) * (1.0f - wx);
-    taps.w[1] = (1.0f - wy) * wx;
-    taps.w[2] = wy * (1.0f - wx);
-    taps.w[3] = wy * wx;
+    bilinear_taps(sc, v, u, w, taps);
   }
 
 }
