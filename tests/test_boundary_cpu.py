@@ -159,3 +159,32 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
         body = m.group(2).split("\n")
         assert sum("v_mfma" in l for l in body) > 1000
         assert not [l for l in body if "scratch_" in l], m.group(1)
+
+
+def test_bench_line_contract():
+    """The committed bench line (profiles/, produced by `python bench.py` on an MI355X) carries every field of the
+    driver's contract, the roofline object and the CPU baseline object."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r01_v8_bench_line_with_cpu_baseline.json")) as f:
+        line = json.loads(f.read())
+    with open(os.path.join(root, "BASELINE.json")) as f:
+        base = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"].split(" at ")[0] in base["metric"] and line["unit"] == "rays/s"
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert "configs[1]" in line["config"]["workload"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == "rays/s" and c["cores"] >= 1
+    assert abs(line["value"] - line["config"]["rays_per_step_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) \
+        < 0.01 * line["value"]
