@@ -73,6 +73,9 @@ SIGNATURES = {
     "diner_field_train_backward_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams),
                                                  C.POINTER(DinerMlpParams), C.c_longlong, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p]),
+    "diner_quantize_rgb_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "diner_minmax_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "diner_colormap_u8": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "diner_depth2normal_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_gen_rays_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),

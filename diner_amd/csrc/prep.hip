@@ -1,8 +1,10 @@
 // Per-image preparation either side of the renderer, once per image:
 //   depth2normal   normal maps from depth maps by central differences      (reference src/util/depth2normal.py:7-87)
 //   gen_rays       pixel-centre rays of a pinhole camera, row-major (H, W) (reference src/util/cam_geometry.py:5-48)
-// Both are HBM-trivial (a few bytes per pixel); they exist so that encode and ray generation stay on the device and a
-// sharded rank generates only its own ray range.
+//   image output   8-bit quantisation of rgb and the colour-mapped depth (torchvision save_image / torch_cmap as used by
+//                  DINER.create_prediction_folder, diner.py:119-133; torch_helpers.py:42-75)
+// All are HBM-trivial (a few bytes per pixel); they exist so that encode, ray generation and output preparation stay on
+// the device and a sharded rank generates only its own ray range.
 #include "common.hpp"
 
 namespace diner {
@@ -105,6 +107,64 @@ __global__ void k_gen_rays(RayCams cams, int B, int W, long long ray0, long long
   }
 }
 
+// ---- image output -------------------------------------------------------------------------------------------------
+// save_image's quantisation: uint8(clamp(v * 255 + 0.5, 0, 255)) in fp32, (3,H,W) planar -> (H,W,3) interleaved
+__global__ void k_quantize_rgb(const float* __restrict__ img, long long HW, unsigned char* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = __fadd_rn(__fmul_rn(img[(size_t)c * HW + i], 255.0f), 0.5f);
+      v = fminf(fmaxf(v, 0.0f), 255.0f);                                   // NaN -> 0 like clamp_ + the uint8 cast of 0
+      out[i * 3 + c] = (unsigned char)(v != v ? 0.0f : v);
+    }
+  }
+}
+
+// order-preserving integer image of a float (for atomicMin / atomicMax)
+__device__ __forceinline__ int float_key(float f) {
+  const int b = __float_as_int(f);
+  return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__global__ void k_minmax(const float* __restrict__ x, long long n, int* __restrict__ keys) {      // keys: {min, max}
+  int lo = 0x7fffffff, hi = (int)0x80000000;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (v == v) {                                                            // numpy's min / max would return NaN; see host
+      const int k = float_key(v);
+      lo = min(lo, k);
+      hi = max(hi, k);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(keys, lo);
+    atomicMax(keys + 1, hi);
+  }
+}
+// matplotlib colormap lookup: index = int(xn * 256) clipped to [0, 255] with xn = (x - vmin) / (vmax - vmin) in
+// float64 (torch_cmap converts to float64 first), NaN -> the "bad" colour (0,0,0); lut: 256 x 3 uint8, already quantised
+// like save_image does
+__global__ void k_colormap(const float* __restrict__ x, long long n, const unsigned char* __restrict__ lut, double vmin,
+                           double vmax, unsigned char* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double xn = ((double)x[i] - vmin) / (vmax - vmin);
+    unsigned char r = 0, g = 0, b = 0;
+    if (xn == xn) {
+      int idx = xn >= 1.0 ? 255 : (xn < 0.0 ? 0 : (int)(xn * 256.0));
+      idx = min(max(idx, 0), 255);
+      r = lut[3 * idx];
+      g = lut[3 * idx + 1];
+      b = lut[3 * idx + 2];
+    }
+    out[i * 3] = r;
+    out[i * 3 + 1] = g;
+    out[i * 3 + 2] = b;
+  }
+}
+
 }  // namespace diner
 
 using namespace diner;
@@ -148,6 +208,34 @@ extern "C" int diner_gen_rays_f32(const float* extrinsics, const float* intrinsi
   const long long total = (long long)B * n_rays;
   const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   hipLaunchKernelGGL(k_gen_rays, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cams, B, W, ray0, n_rays, out);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_quantize_rgb_u8(const float* img, int H, int W, unsigned char* out, void* stream) {
+  DINER_CHECK_ARG(img && out && H > 0 && W > 0, "quantize_rgb: bad arguments");
+  const long long HW = (long long)H * W;
+  const int blocks = (int)((HW + 255) / 256 > 8192 ? 8192 : (HW + 255) / 256);
+  hipLaunchKernelGGL(k_quantize_rgb, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, HW, out);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_minmax_f32(const float* x, long long n, float* out2, void* stream) {
+  DINER_CHECK_ARG(x && out2 && n > 0, "minmax: bad arguments");
+  const int init[2] = {0x7fffffff, (int)0x80000000};
+  DINER_HIP_OK(hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, (hipStream_t)stream));
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_minmax, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, (int*)out2);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int diner_colormap_u8(const float* x, long long n, const unsigned char* lut_u8, double vmin, double vmax,
+                                 unsigned char* out, void* stream) {
+  DINER_CHECK_ARG(x && lut_u8 && out && n > 0, "colormap: bad arguments");
+  const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_colormap, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, lut_u8, vmin, vmax, out);
   DINER_LAUNCH_OK();
   return 0;
 }

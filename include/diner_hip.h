@@ -153,6 +153,17 @@ int diner_depth2normal_f32(const float* dmap, const float* K, int N, int H, int 
 int diner_gen_rays_f32(const float* extrinsics, const float* intrinsics, const float* z_near, const float* z_far, int B,
                        int W, int H, long long ray0, long long n_rays, float* out, void* stream);
 
+/* Image output (row f3): what DINER.create_prediction_folder does with a rendered image before it is written
+ * (diner.py:119-133): torchvision.utils.save_image's quantisation, uint8(clamp(v * 255 + 0.5, 0, 255)), of a (3,H,W)
+ * image into (H,W,3) bytes; and torch_cmap (torch_helpers.py:42-75): per-image min / max (NaNs skipped; the keys come back
+ * as order-preserving int32 images of the floats, see diner_amd/imageio.py), then the matplotlib lookup
+ * index = int((x - vmin) / (vmax - vmin) * 256) clipped to [0, 255] in float64 through a 256 x 3 uint8 table that the
+ * host quantised the same way. */
+int diner_quantize_rgb_u8(const float* img, int H, int W, unsigned char* out, void* stream);
+int diner_minmax_f32(const float* x, long long n, float* out2, void* stream);
+int diner_colormap_u8(const float* x, long long n, const unsigned char* lut_u8, double vmin, double vmax,
+                      unsigned char* out, void* stream);
+
 /* ---- training path: building blocks of the un-fused forward that keeps activations and
  * of the backward pass that torch autograd performs in DINER.calc_losses (diner.py:217-290); driven by
  * diner_amd/train.py.  All pointers are device pointers unless noted; enqueue-only on `stream`.

@@ -409,3 +409,29 @@ def test_plain_fp16_mode_accuracy(ops):
         assert 1e-5 < e_field < 5e-3 and e_rgb < 5e-3
     finally:
         ops.set_precision(prev)
+
+
+def test_image_output_against_reference_ops(ops, tmp_path):
+    """Row f3: quantisation and depth colour map on the device against the reference's host path restated with numpy /
+    matplotlib (torch_cmap torch_helpers.py:42-75 + save_image's uint8(clamp(v*255+0.5, 0, 255))), bit-exact, and the PNG
+    files written from them."""
+    import matplotlib.pyplot as plt
+    from diner_amd import imageio
+    g = torch.Generator().manual_seed(12)
+    rgb = torch.rand(3, 45, 61, generator=g) * 1.2 - 0.1               # some values outside [0, 1]
+    want = (rgb * 255 + 0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8)
+    got = imageio.to_uint8(rgb.cuda()).cpu()
+    assert torch.equal(got, want)
+    depth = torch.rand(1, 45, 61, generator=g) * 0.9 + 0.5
+    depth[0, 3, 4] = depth.max()                                        # x == 1 exactly -> last table entry
+    for vmin, vmax in ((None, None), (0.25, 1.75), (None, 2.0)):
+        x = depth.numpy().astype(float)[None]                           # (B,1,H,W) float64, as torch_cmap does
+        lo = vmin if vmin else np.min(x.reshape(1, -1), axis=-1).reshape(-1, 1, 1, 1)
+        hi = vmax if vmax else np.max(x.reshape(1, -1), axis=-1).reshape(-1, 1, 1, 1)
+        col = torch.from_numpy(plt.get_cmap("viridis")(((x - lo) / (hi - lo))[:, 0])[..., :3])[0]      # (H,W,3) float64
+        want_d = (col * 255 + 0.5).clamp(0, 255).to(torch.uint8)
+        got_d = imageio.depth_to_uint8(depth.cuda(), vmin=vmin, vmax=vmax).cpu()
+        assert torch.equal(got_d, want_d), (vmin, vmax)
+    imageio.save_prediction(str(tmp_path), "v0", rgb.cuda(), depth.cuda())
+    assert np.array_equal(imageio.read_png(str(tmp_path / "v0_pred.png")), want.numpy())
+    assert imageio.read_png(str(tmp_path / "v0_depth.png")).shape == (45, 61, 3)
