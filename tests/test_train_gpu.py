@@ -246,3 +246,29 @@ def test_three_adam_steps_track_torch_autograd(ops):
     print(f"weights after 3 Adam steps: worst max-norm relative difference {worst:.2e}")
     # (informational: Adam's first steps move every weight by +-lr whatever the gradient's size, so weights whose
     #  gradient is ~0 can step in opposite directions in the two runs; the loss trajectory is the meaningful check)
+
+
+def test_gradient_reaches_the_image_encoder(ops):
+    """encode() in grad mode (ResNet trunk in torch) -> renderer.forward on the HIP training path -> loss.backward():
+    the latent gradient returned by the HIP backward continues through torch autograd into the encoder's convolutions, as
+    in the reference's training (train.py -> DINER.training_step)."""
+    from tests.test_boundary_cpu import build_nerf
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict
+    from src.util.import_helper import import_obj
+    from src.util.cam_geometry import gen_rays
+    W = H = 32
+    sc = make_scene(W, H, seed=4, latent=False)
+    nerf = build_nerf().cuda().train()
+    nerf.mlp_fine.load_state_dict(make_mlp_state_dict())
+    imgs = torch.rand(1, 4, 3, H, W, generator=torch.Generator().manual_seed(0)).cuda()
+    nerf.encode(imgs, sc["depths"][None].cuda(), sc["depths_std"][None].cuda(), sc["src_extrinsics"][None].cuda(),
+                sc["src_intrinsics"][None].cuda())
+    assert nerf.encoder.latent.requires_grad
+    rays = gen_rays(sc["target_extrinsics"].view(1, 4, 4).cuda(), sc["target_intrinsics"].view(1, 3, 3).cuda(), W, H,
+                    torch.tensor([sc["znear"]]).cuda(), torch.tensor([sc["zfar"]]).cuda()).view(1, -1, 8)
+    ren = import_obj("src.models.nerf_renderer.NeRFRendererDGS")(n_samples=40, n_gaussian=15, white_bkgd=True)
+    out = ren.forward(nerf, rays[:, ::8].contiguous())
+    (out.fine.rgb - 0.5).square().mean().backward()
+    conv = [p for n, p in nerf.encoder.named_parameters() if n.endswith("conv1.weight")][0]
+    assert conv.grad is not None and torch.isfinite(conv.grad).all() and float(conv.grad.abs().max()) > 0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in nerf.mlp_fine.parameters())
