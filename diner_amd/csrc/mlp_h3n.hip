@@ -9,7 +9,8 @@
 //   * activations are exchanged between layers through a 128 KB LDS buffer already in B-operand form (fp16 hi / lo,
 //     1/16 scale folded in): every wave converts its 128-feature slice, two barriers per layer instead of 32;
 //   * LDS traffic per MFMA drops 8x, the view mean is a register sum over the four column groups.
-// Arithmetic, scaling and results are those of mlp_h3.hip (same products, same accumulation order over k).
+// Arithmetic and scaling are those of mlp_h3.hip (same products, same accumulation order over k; results agree to fp32
+// round-off: the lin_z contribution joins the accumulation at a different point).
 #include <utility>
 #include <vector>
 #include "field_common.hpp"

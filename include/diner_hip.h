@@ -213,7 +213,8 @@ int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams
  * 1: "f16x3" split products -- each fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on
  *    v_mfma_f32_16x16x32_f16 with fp32 accumulation and power-of-two pre-scaling (diner_amd/csrc/mlp_h3.hip);
  *    ~2^-21 relative error per product.  Weights are streamed through LDS and shared by the four waves.
- * 2: the same arithmetic (bit-identical sums) with the per-view part computed by the feature-sliced kernel of
+ * 2: the same arithmetic (same products and accumulation order over k; the lin_z contribution is added at a different
+ *    point, so results agree to fp32 round-off, not bit for bit) with the per-view part computed by the feature-sliced kernel of
  *    diner_amd/csrc/mlp_h3n.hip: every wave owns 128 output features of all 64 columns, weights go global ->
  *    registers, activations are exchanged through LDS as fp16 hi/lo operands.  The Python host selects this mode
  *    by default (diner_amd/ops.py).  Falls back to mode 1 when one projected map exceeds 4 GB.
