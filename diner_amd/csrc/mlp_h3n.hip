@@ -1,4 +1,4 @@
-// f16x3 field kernel, "n-split" variant of the per-view part (experimental, diner_set_precision(2)).
+// f16x3 field kernels, "n-split" (feature-sliced) variant: the default (diner_set_precision(2); 3 = plain fp16 operands).
 //
 // mlp_h3.hip keeps the fp32 design: one wave = 16 (point,view) columns x all 512 features, weights streamed through
 // LDS and read by all four waves -- with fp16 MFMAs the matrix pipe is no longer the bound, the LDS fragment reads are
