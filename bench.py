@@ -213,14 +213,14 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "rendered rays/sec (128 samples/ray, 4 src views)", "value": round(rays_per_s, 1),
+            "metric": f"rendered rays/sec ({K} samples/ray, 4 src views)", "value": round(rays_per_s, 1),
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32 via f16x3 split MFMA products, fp32 accumulate" if h3 else
                       "f16 operands / f32 accumulate (REDUCED PRECISION, not the headline configuration)" if f16 else "f32"),
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: synthetic 4-view scene, {W}x{H} target = {NR} rays per GPU per "
+            "config": {"workload": f"{'BASELINE configs[1]' if (W, H, K) == (400, 300, 128) else 'variant of BASELINE configs[1]'}: synthetic 4-view scene, {W}x{H} target = {NR} rays per GPU per "
                                    f"step, {K} samples/ray ({G} gaussian, {n_cand} candidates), MLP d_hidden 512 / 5 blocks "
                                    f"({'f16x3 split-product' if h3 else 'plain fp16-operand' if f16 else 'exact fp32'} MFMA GEMMs), random-init weights, "
                                    f"in-kernel Philox noise",
