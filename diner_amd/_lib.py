@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DINER_AMD_LIB") or os.path.join(_HERE, "libdiner_hip.
 
 class DinerScene(C.Structure):
     _fields_ = [("latent_cl", C.c_void_p), ("latent_proj", C.c_void_p), ("depth", C.c_void_p), ("depth_std", C.c_void_p),
-                ("normals", C.c_void_p), ("poses", C.c_void_p), ("focal", C.c_void_p), ("c", C.c_void_p),
+                ("normals", C.c_void_p), ("poses_host", C.c_void_p), ("focal_host", C.c_void_p), ("c_host", C.c_void_p),
                 ("std_pad_scale", C.c_void_p),
                 ("img_w", C.c_float), ("img_h", C.c_float), ("feature_padding", C.c_float),
                 ("nv", C.c_int32), ("C", C.c_int32), ("Hf", C.c_int32), ("Wf", C.c_int32),
@@ -18,6 +18,7 @@ class DinerScene(C.Structure):
 class DinerMlpParams(C.Structure):
     _fields_ = [("d_in", C.c_int32), ("d_latent", C.c_int32), ("d_hidden", C.c_int32), ("d_out", C.c_int32),
                 ("n_blocks", C.c_int32), ("combine_layer", C.c_int32),
+                ("num_freqs", C.c_int32), ("include_input", C.c_int32), ("freq_factor", C.c_float),
                 ("lin_in_w", C.c_void_p), ("lin_in_b", C.c_void_p),
                 ("lin_out_w", C.c_void_p), ("lin_out_b", C.c_void_p),
                 ("fc0_w", C.POINTER(C.c_void_p)), ("fc0_b", C.POINTER(C.c_void_p)),
@@ -31,6 +32,7 @@ SIGNATURES = {
     "diner_last_error": (C.c_char_p, []),
     "diner_mlp_create": (C.c_int, [C.POINTER(DinerMlpParams), C.c_void_p, C.POINTER(C.c_void_p)]),
     "diner_mlp_destroy": (C.c_int, [C.c_void_p]),
+    "diner_mlp_weights_fit_f16x3": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "diner_sample_depthguided_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -40,26 +42,25 @@ SIGNATURES = {
     "diner_scene_prepare_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "diner_field_from_rays_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_from_points_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p,
-                                              C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                              C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_mlp_forward_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "diner_mlp_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_composite_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_render_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
     "diner_posenc_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                    C.c_void_p]),
-    "diner_set_precision": (C.c_int, [C.c_int]),
-    "diner_get_precision": (C.c_int, []),
     "diner_profile_enable": (C.c_int, [C.c_int]),
     "diner_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                         C.POINTER(C.c_longlong)]),
     "diner_index_f32": (C.c_int, [C.POINTER(DinerScene), C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "diner_gemm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "diner_train_inputs_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
+    "diner_train_inputs_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_scatter_latent_grad_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "diner_view_mean_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p]),
@@ -81,6 +82,7 @@ SIGNATURES = {
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),
 }
 
+ABI_VERSION = 2          # DINER_ABI_VERSION of include/diner_hip.h
 _lib = None
 
 
@@ -96,8 +98,8 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.diner_abi_version() != 1:
-        raise ImportError(f"libdiner_hip.so ABI version {lib.diner_abi_version()} != 1; rebuild")
+    if lib.diner_abi_version() != ABI_VERSION:
+        raise ImportError(f"libdiner_hip.so ABI version {lib.diner_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

@@ -36,6 +36,9 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 int validate_scene(const DinerScene* s);
+// ResnetFC / positional-encoding configuration the kernels are built for (host-only check, before any device work);
+// poscode = false skips the encoding fields (gradient structs carry none)
+int check_mlp_config(const DinerMlpParams* p, const char* who, bool poscode);
 
 constexpr int kMaxViews = 4;      // NV of every shipped config (dtu.py:48, facescape.py:42, multiface.py:46)
 constexpr int kStdPad = 100;      // image_encoder.py:190-191

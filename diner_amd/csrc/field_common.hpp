@@ -176,7 +176,7 @@ __device__ __forceinline__ void taps_load(const float* __restrict__ map, const T
 }
 
 // MLP input feature f of [x_c(3), 36 sin/cos of x_c, R d (3), dd, 12 sin/cos of dd]  (pixelnerf.py:96-128)
-__device__ __forceinline__ float input_feature(int f, const float* xc, const float* vd, float dd) {
+__device__ __forceinline__ float input_feature(int f, const float* xc, const float* vd, float dd, float freq_factor) {
   float arg;
   int j;
   if (f < 3) return f == 0 ? xc[0] : (f == 1 ? xc[1] : xc[2]);
@@ -194,7 +194,7 @@ __device__ __forceinline__ float input_feature(int f, const float* xc, const flo
   } else {
     return 0.0f;
   }
-  const float freq = __fmul_rn(6.28f, (float)(1 << (j >> 1)));                  // positional_encoding.py:18
+  const float freq = __fmul_rn(freq_factor, (float)(1 << (j >> 1)));            // positional_encoding.py:18
   const float phase = (j & 1) ? 1.57079637050628662109375f : 0.0f;               // fp32(pi/2), :30
   return sin_posenc(__fmaf_rn(arg, freq, phase));                                 // addcmul is fused, :46
 }
@@ -210,7 +210,8 @@ struct FieldArgs {
   size_t tz_stride;             // floats between lin_z[b] and lin_z[b+1] maps
   long long P;
   int K;
-  float freq_factor;
+  float freq_factor;            // PositionalEncoding.freq_factor of the MLP handle (6.28 in every shipped config)
+  const int* gate;              // optional: the kernel returns at once when *gate == 0 (device-side fp32 fall-back, mlp.hip)
   const float* w_pre;
   const float* b_pre;
   float* xpre;                  // (P/16 tiles, NV, 32, 64) f32x4
@@ -286,7 +287,7 @@ __device__ __forceinline__ void field_frontend(const SceneDev& sc, const FieldAr
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) feat[4 * m + r] = input_feature(16 * m + 4 * q + r, xc, vd, dd);
+      for (int r = 0; r < 4; ++r) feat[4 * m + r] = input_feature(16 * m + 4 * q + r, xc, vd, dd, a.freq_factor);
     bilinear_taps(sc, v, u, w, taps);
   }
 
@@ -300,6 +301,8 @@ struct PostArgs {
   long long P;
   int nv;
   int raw;             // 1: ResnetFC.forward output; 0: sigmoid(rgb), relu(sigma) (pixelnerf.py:139-143)
+  const int* gate;     // optional: return at once when *gate == 0
+  int* overflow;       // optional (fp16-operand kernels): set to 1 when a raw lin_out value is not finite
 };
 
 }  // namespace diner

@@ -31,6 +31,7 @@
 //  * the view-mean boundary (resnetfc.py:148-151) splits the network into two persistent kernels;
 //    the hand-over is 8 KB/point of pre-mean activations stored in accumulator layout (coalesced 1 KB
 //    wave stores).
+#include <mutex>
 #include <vector>
 #include "field_common.hpp"
 
@@ -43,28 +44,22 @@ struct DinerMlpImpl {
   float* b_hoist;  // lin_z biases, 3 x 512
   float* b_pre;    // lin_in, then per block b<3: fc_0, fc_1  -> 7 x 512
   float* b_post;   // per block b=3,4: fc_0, fc_1 -> 4 x 512, then lin_out (4, padded to 16)
-  // split-precision (f16x3) copies, see mlp_h3.hip: same stage structure, fp16 hi/lo fragments, x16 pre-scaled
-  float* h3_w_pre;
-  float* h3_w_post;
-  float* h3_b_pre;
-  float* h3_b_post;
-  float* h3n_w;    // n-split packing of the per-view layers (mlp_h3n.hip), fp16 hi/lo, x16
+  // split-precision (f16x3 / f16) copies for the feature-sliced kernels of mlp_h3n.hip: fp16 hi/lo fragments and biases, x16
+  float* hn_w;     // n-split packing of lin_in + the 6 per-view layers + the 4 post layers
+  float* hn_w_out; // lin_out fragments
+  float* hn_b_pre; // 7 x 512, x16
+  float* hn_b_post;// 4 x 512 x16, then lin_out bias (scale 1, padded to 16)
+  float* wmax_dev; // max |parameter| (device scalar, reduced at pack time)
+  float wmax;      // ... read back at the end of diner_mlp_create
+  float freq_factor;   // PositionalEncoding.freq_factor of the inputs this MLP was trained on
 };
 
-// mlp_h3.hip
-int h3_pack(const DinerMlpParams* p, hipStream_t stream, float** w_pre, float** w_post, float** b_pre, float** b_post);
-int h3_set_attributes(size_t lds_bytes);
-void h3_launch_pre(const SceneDev& sc, const FieldArgs& fa, int grid, size_t lds_bytes, hipStream_t stream);
-void h3_launch_post(const PostArgs& pa, int grid, size_t lds_bytes, hipStream_t stream);
-
 // mlp_h3n.hip
-int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out);
+int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w, float** w_out, float** b_pre, float** b_post);
 int h3n_set_attributes();
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
                     hipStream_t stream);
-void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, bool split, hipStream_t stream);
-
-static int g_precision = 0;   // 0: exact fp32 MFMA, 1: f16x3 split products, 2: f16x3 with the n-split per-view kernel
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_out, int grid, bool split, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing (runs once per parameter version, on the device)
@@ -388,6 +383,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre(SceneDev sc, FieldArgs a) 
   const int q = lane >> 4, pt = lane & 15;
   const int v = wave;                                   // one wave per source view
   const long long n_tiles = (a.P + kPtsPerWave - 1) / kPtsPerWave;
+  if (a.gate && *a.gate == 0) return;                   // fp32 fall-back pass of an fp16-operand call: nothing overflowed
 
   WeightStream ws;
   ws.base = a.w_pre;
@@ -474,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
   const int q = lane >> 4, pt = lane & 15;
   const long long n_t16 = (a.P + kPtsPerWave - 1) / kPtsPerWave;
   const long long n_tiles = (n_t16 + 3) / 4;           // 4 waves x 16 points per workgroup tile
+  if (a.gate && *a.gate == 0) return;
 
   WeightStream ws;
   ws.base = a.w_post;
@@ -549,20 +546,57 @@ __global__ void k_split_zx(const float* __restrict__ zx, long long rows, float* 
   }
 }
 
-static int g_num_cus = 0;
-static int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
+// max |x| over n floats into *dst (non-negative floats order like their bit patterns)
+__global__ void k_absmax(const float* __restrict__ x, long long n, float* __restrict__ dst) {
+  float m = 0.0f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = fabsf(x[i]);
+    m = (v > m || v != v) ? v : m;                        // a NaN parameter wins (and fails the range check)
   }
-  return g_num_cus;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(m, o, 64);
+    m = (t > m || t != t) ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (m != m) atomicExch(reinterpret_cast<unsigned*>(dst), 0x7fc00000u);
+    else atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+  }
+}
+
+// ---- per-device launch state: function attributes (dynamic LDS above 64 KB) are per device, and so is the CU count ----
+constexpr int kMaxDevices = 64;
+struct DeviceState {
+  std::mutex mu;
+  bool attrs[kMaxDevices] = {};
+  int cus[kMaxDevices] = {};
+};
+static DeviceState g_dev;
+static constexpr size_t kFp32LdsBytes = (kRing * kStageFloats + kExchFloats) * sizeof(float);
+
+// Returns the CU count of the current device (>0) after making sure the kernels' attributes are set on it; <0 on error.
+static int prepare_device() {
+  int dev = 0;
+  DINER_HIP_OK(hipGetDevice(&dev));
+  DINER_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "device index %d outside [0,%d)", dev, kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_dev.mu);
+  if (!g_dev.attrs[dev]) {
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFp32LdsBytes));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFp32LdsBytes));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFp32LdsBytes));
+    int rc = h3n_set_attributes();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    DINER_HIP_OK(hipGetDeviceProperties(&prop, dev));
+    g_dev.cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_dev.attrs[dev] = true;
+  }
+  return g_dev.cus[dev];
 }
 
 // ---- optional per-kernel timing (HIP events on the launch stream), used by bench.py for the roofline ----
 struct KernelTimer {
+  std::mutex mu;
   bool enabled = false;
   std::vector<hipEvent_t> ev;      // triples: before pre, between pre and post, after post
   std::vector<long long> points;
@@ -573,31 +607,34 @@ static size_t xpre_bytes(long long P, int /*nv*/) {
   const long long n_t16 = (P + kPtsPerWave - 1) / kPtsPerWave;
   return (size_t)n_t16 * kTiles * 64 * sizeof(f32x4);        // view-averaged hand-over: 2 KB per point
 }
+constexpr size_t kFlagBytes = 256;                           // overflow flag of the fp16-operand kernels (+ padding)
 
+// precision: DINER_PRECISION_*.  The fp16-operand modes are followed by a GATED pass of the exact-fp32 kernels: the post
+// kernel raises a device flag when a raw output is not finite (an activation left the fp16 range, or an input was not
+// finite to begin with), and only then do the fp32 kernels (which return at once otherwise) recompute the launch.  No
+// host synchronisation, no silent inf/NaN from a checkpoint with large activations.
 static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa, int nv, float* out, int raw,
-                        void* workspace, hipStream_t stream) {
-  static bool attr_set = false;
-  const size_t lds_bytes = (kRing * kStageFloats + kExchFloats) * sizeof(float);
-  if (!attr_set) {
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_field_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    int rc = h3_set_attributes(lds_bytes);
-    if (rc) return rc;
-    rc = h3n_set_attributes();
-    if (rc) return rc;
-    attr_set = true;
+                        void* workspace, int precision, hipStream_t stream) {
+  DINER_CHECK_ARG(precision == DINER_PRECISION_FP32 || precision == DINER_PRECISION_F16X3 || precision == DINER_PRECISION_F16,
+                  "field: precision must be DINER_PRECISION_FP32 (0), _F16X3 (1) or _F16 (2), got %d", precision);
+  const int cus = prepare_device();
+  if (cus < 0) return cus;
+  // explicit matrices (diner_mlp_forward_f32) and weights outside the fp16 range always take the exact kernels
+  const bool fits = m->wmax == m->wmax && m->wmax < 1024.0f;
+  const bool use_hn = precision != DINER_PRECISION_FP32 && !fa.direct_feat && fits;
+  if (use_hn && fa.tz_stride * sizeof(float) >= ((size_t)1 << 32)) {
+    set_error("field: one projected feature map is %.1f GiB; the fp16-operand kernels address it with 32-bit offsets "
+              "(< 4 GiB) -- use DINER_PRECISION_FP32 for this scene", (double)(fa.tz_stride * sizeof(float)) / (1u << 30));
+    return DINER_E_UNSUPPORTED;
   }
-  const bool use_h3 = g_precision >= 1 && !fa.direct_feat;
-  // the n-split kernel addresses one projected map with 32-bit byte offsets
-  const bool use_h3n = g_precision >= 2 && !fa.direct_feat && fa.tz_stride * sizeof(float) < ((size_t)1 << 32);
-  const bool split = g_precision != 3;         // mode 3: plain fp16 operands in the n-split kernels
-  fa.w_pre = use_h3 ? m->h3_w_pre : m->w_pre;
-  fa.b_pre = use_h3 ? m->h3_b_pre : m->b_pre;
+  const bool split = precision != DINER_PRECISION_F16;
+  fa.w_pre = m->w_pre;
+  fa.b_pre = m->b_pre;
   fa.xpre = (float*)workspace;
-  fa.freq_factor = 6.28f;
+  fa.freq_factor = m->freq_factor;
+  fa.gate = nullptr;
+  int* flag = reinterpret_cast<int*>((char*)workspace + xpre_bytes(fa.P, nv));
   const long long n_t16 = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
-  const int cus = num_cus();
   SceneDev dummy;
   if (!sc) {
     memset(&dummy, 0, sizeof(dummy));
@@ -605,28 +642,45 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     sc = &dummy;
   }
   const int grid_pre = (int)(n_t16 < cus ? n_t16 : cus);
+  const long long n_tiles = (n_t16 + 3) / 4;
+  const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  if (g_timer.enabled) {
+  bool timed;
+  {
+    std::lock_guard<std::mutex> lock(g_timer.mu);
+    timed = g_timer.enabled;
+  }
+  if (timed) {
     DINER_HIP_OK(hipEventCreate(&e0));
     DINER_HIP_OK(hipEventCreate(&e1));
     DINER_HIP_OK(hipEventCreate(&e2));
+  }
+  PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw, nullptr, nullptr};
+  if (use_hn) {
+    DINER_HIP_OK(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    if (timed) DINER_HIP_OK(hipEventRecord(e0, stream));
+    h3n_launch_pre(*sc, fa, m->hn_w, m->hn_b_pre, grid_pre, split, stream);
+    DINER_LAUNCH_OK();
+    if (timed) DINER_HIP_OK(hipEventRecord(e1, stream));
+    PostArgs pn = pa;
+    pn.b_post = m->hn_b_post;
+    pn.overflow = flag;
+    h3n_launch_post(pn, m->hn_w, m->hn_w_out, grid_post, split, stream);
+    DINER_LAUNCH_OK();
+    if (timed) DINER_HIP_OK(hipEventRecord(e2, stream));
+    fa.gate = flag;                 // the exact kernels below only run when the flag was raised
+    pa.gate = flag;
+  } else if (timed) {
     DINER_HIP_OK(hipEventRecord(e0, stream));
   }
-  if (use_h3n) h3n_launch_pre(*sc, fa, m->h3n_w, m->h3_b_pre, grid_pre, split, stream);
-  else if (use_h3) h3_launch_pre(*sc, fa, grid_pre, lds_bytes, stream);
-  else hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), lds_bytes, stream, *sc, fa);
+  hipLaunchKernelGGL(k_field_pre, dim3(grid_pre), dim3(256), kFp32LdsBytes, stream, *sc, fa);
   DINER_LAUNCH_OK();
-  if (g_timer.enabled) DINER_HIP_OK(hipEventRecord(e1, stream));
-  PostArgs pa{(const float*)workspace, use_h3 ? m->h3_w_post : m->w_post, use_h3 ? m->h3_b_post : m->b_post, out, fa.P,
-              nv, raw};
-  const long long n_tiles = (n_t16 + 3) / 4;
-  const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
-  if (use_h3n) h3n_launch_post(pa, m->h3n_w, m->h3_w_post, grid_post, split, stream);
-  else if (use_h3) h3_launch_post(pa, grid_post, lds_bytes, stream);
-  else hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), lds_bytes, stream, pa);
+  if (timed && !use_hn) DINER_HIP_OK(hipEventRecord(e1, stream));
+  hipLaunchKernelGGL(k_field_post, dim3(grid_post), dim3(256), kFp32LdsBytes, stream, pa);
   DINER_LAUNCH_OK();
-  if (g_timer.enabled) {
-    DINER_HIP_OK(hipEventRecord(e2, stream));
+  if (timed) {
+    if (!use_hn) DINER_HIP_OK(hipEventRecord(e2, stream));
+    std::lock_guard<std::mutex> lock(g_timer.mu);
     g_timer.ev.push_back(e0);
     g_timer.ev.push_back(e1);
     g_timer.ev.push_back(e2);
@@ -636,16 +690,11 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
 }
 
 static int launch_hoist(const DinerMlpImpl* m, const float* src, long long rows, float* dst, hipStream_t stream) {
-  static bool attr_set = false;
-  const size_t lds_bytes = (kRing * kStageFloats + kExchFloats) * sizeof(float);
-  if (!attr_set) {
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_hoist_linz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  const int cus = prepare_device();
+  if (cus < 0) return cus;
   HoistArgs ha{src, dst, rows, m->w_hoist, m->b_hoist};
   const long long n_tiles = (rows + 63) / 64;
-  const int cus = num_cus();
-  hipLaunchKernelGGL(k_hoist_linz, dim3((unsigned)(n_tiles < cus ? n_tiles : cus)), dim3(256), lds_bytes, stream, ha);
+  hipLaunchKernelGGL(k_hoist_linz, dim3((unsigned)(n_tiles < cus ? n_tiles : cus)), dim3(256), kFp32LdsBytes, stream, ha);
   DINER_LAUNCH_OK();
   return 0;
 }
@@ -658,96 +707,98 @@ struct DinerMlp {
   DinerMlpImpl impl;
 };
 
-extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp** out) {
-  DINER_CHECK_ARG(p && out, "mlp_create: null argument");
-  if (p->d_in != kDIn || p->d_latent != kLatent || p->d_hidden != kHidden || p->d_out != 4 || p->n_blocks != 5 ||
-      p->combine_layer != 3) {
-    set_error("mlp_create: unsupported ResnetFC configuration d_in=%d d_latent=%d d_hidden=%d d_out=%d n_blocks=%d "
-              "combine_layer=%d (built for 55/512/512/4/5/3, configs/train_dtu.yaml:44-50)",
-              p->d_in, p->d_latent, p->d_hidden, p->d_out, p->n_blocks, p->combine_layer);
-    return DINER_E_UNSUPPORTED;
-  }
-  hipStream_t stream = (hipStream_t)stream_;
-  DinerMlp* m = new DinerMlp();
-  memset(&m->impl, 0, sizeof(m->impl));
-  DINER_HIP_OK(hipMalloc(&m->impl.w_hoist, (size_t)kHoistStages * kStageFloats * sizeof(float)));
-  DINER_HIP_OK(hipMalloc(&m->impl.w_pre, (size_t)kPreStages * kStageFloats * sizeof(float)));
-  DINER_HIP_OK(hipMalloc(&m->impl.w_post, (size_t)kPostStages * kStageFloats * sizeof(float)));
-  DINER_HIP_OK(hipMalloc(&m->impl.b_hoist, 3 * kHidden * sizeof(float)));
-  DINER_HIP_OK(hipMalloc(&m->impl.b_pre, 7 * kHidden * sizeof(float)));
-  DINER_HIP_OK(hipMalloc(&m->impl.b_post, (4 * kHidden + 16) * sizeof(float)));
+static int mlp_pack(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& im) {
+  DINER_HIP_OK(hipMalloc(&im.w_hoist, (size_t)kHoistStages * kStageFloats * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&im.w_pre, (size_t)kPreStages * kStageFloats * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&im.w_post, (size_t)kPostStages * kStageFloats * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&im.b_hoist, 3 * kHidden * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&im.b_pre, 7 * kHidden * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&im.b_post, (4 * kHidden + 16) * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&im.wmax_dev, sizeof(float)));
+  DINER_HIP_OK(hipMemsetAsync(im.wmax_dev, 0, sizeof(float), stream));
   auto pack = [&](const float* W, int rows, int cols, int n_kc, float* dst) {
     hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, W, rows, cols, n_kc, dst);
+    hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, stream, W, (long long)rows * cols, im.wmax_dev);
   };
   auto bias = [&](const float* b, int n, int n_pad, float* dst) {
     hipLaunchKernelGGL(k_copy_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, dst);
+    hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, stream, b, (long long)n, im.wmax_dev);
   };
-  float* wp = m->impl.w_pre;
+  float* wp = im.w_pre;
   pack(p->lin_in_w, kHidden, kDIn, 1, wp);
   wp += 4 * kStageFloats;
-  bias(p->lin_in_b, kHidden, kHidden, m->impl.b_pre);
+  bias(p->lin_in_b, kHidden, kHidden, im.b_pre);
   for (int b = 0; b < 3; ++b) {
-    pack(p->lin_z_w[b], kHidden, kLatent, 8, m->impl.w_hoist + (size_t)b * kStagesPerLayer * kStageFloats);
-    bias(p->lin_z_b[b], kHidden, kHidden, m->impl.b_hoist + kHidden * b);
+    pack(p->lin_z_w[b], kHidden, kLatent, 8, im.w_hoist + (size_t)b * kStagesPerLayer * kStageFloats);
+    bias(p->lin_z_b[b], kHidden, kHidden, im.b_hoist + kHidden * b);
     pack(p->fc0_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
     pack(p->fc1_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
-    float* bb = m->impl.b_pre + kHidden * (1 + 2 * b);
+    float* bb = im.b_pre + kHidden * (1 + 2 * b);
     bias(p->fc0_b[b], kHidden, kHidden, bb);
     bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
   }
-  wp = m->impl.w_post;
+  wp = im.w_post;
   for (int b = 3; b < 5; ++b) {
     pack(p->fc0_w[b], kHidden, kHidden, 8, wp); wp += kStagesPerLayer * kStageFloats;
     pack(p->fc1_w[b], kHidden, kHidden, 8, wp); wp += kStagesPerLayer * kStageFloats;
-    float* bb = m->impl.b_post + 2 * kHidden * (b - 3);
+    float* bb = im.b_post + 2 * kHidden * (b - 3);
     bias(p->fc0_b[b], kHidden, kHidden, bb);
     bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
   }
-  {
-    int rc = h3_pack(p, stream, &m->impl.h3_w_pre, &m->impl.h3_w_post, &m->impl.h3_b_pre, &m->impl.h3_b_post);
-    if (rc) return rc;
-    rc = h3n_pack(p, stream, &m->impl.h3n_w);
-    if (rc) return rc;
-  }
   hipLaunchKernelGGL(k_pack_lin_out, dim3(32), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, wp);
-  bias(p->lin_out_b, 4, 16, m->impl.b_post + 4 * kHidden);
+  hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, stream, p->lin_out_w, (long long)4 * kHidden, im.wmax_dev);
+  bias(p->lin_out_b, 4, 16, im.b_post + 4 * kHidden);
   DINER_LAUNCH_OK();
+  int rc = h3n_pack(p, stream, &im.hn_w, &im.hn_w_out, &im.hn_b_pre, &im.hn_b_post);
+  if (rc) return rc;
+  // The call returns once packing has completed (the caller may free or overwrite the source tensors) and the weight
+  // range is known on the host: one 4-byte read back per parameter version.
+  DINER_HIP_OK(hipMemcpyAsync(&im.wmax, im.wmax_dev, sizeof(float), hipMemcpyDeviceToHost, stream));
+  DINER_HIP_OK(hipStreamSynchronize(stream));
+  return 0;
+}
+
+extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp** out) {
+  DINER_CHECK_ARG(p && out, "mlp_create: null argument");
+  int rc = check_mlp_config(p, "mlp_create", /*poscode=*/true);
+  if (rc) return rc;
+  DinerMlp* m = new DinerMlp();
+  memset(&m->impl, 0, sizeof(m->impl));
+  m->impl.freq_factor = p->freq_factor;
+  rc = mlp_pack(p, (hipStream_t)stream_, m->impl);
+  if (rc) {                       // nothing is left behind by a failed create
+    diner_mlp_destroy(m);
+    return rc;
+  }
   *out = m;
   return 0;
 }
 
 extern "C" int diner_mlp_destroy(DinerMlp* m) {
   if (!m) return 0;
-  hipFree(m->impl.w_hoist);
-  hipFree(m->impl.w_pre);
-  hipFree(m->impl.w_post);
-  hipFree(m->impl.b_hoist);
-  hipFree(m->impl.b_pre);
-  hipFree(m->impl.b_post);
-  hipFree(m->impl.h3_w_pre);
-  hipFree(m->impl.h3_w_post);
-  hipFree(m->impl.h3_b_pre);
-  hipFree(m->impl.h3_b_post);
-  hipFree(m->impl.h3n_w);
+  float* bufs[] = {m->impl.w_hoist, m->impl.w_pre, m->impl.w_post, m->impl.b_hoist, m->impl.b_pre, m->impl.b_post,
+                   m->impl.hn_w, m->impl.hn_w_out, m->impl.hn_b_pre, m->impl.hn_b_post, m->impl.wmax_dev};
+  for (float* b : bufs)
+    if (b) hipFree(b);
   delete m;
   return 0;
 }
 
-extern "C" int diner_set_precision(int mode) {
-  DINER_CHECK_ARG(mode >= 0 && mode <= 3,
-                  "set_precision: mode must be 0 (fp32), 1 (f16x3), 2 (f16x3 n-split) or 3 (plain fp16 operands), got %d", mode);
-  g_precision = mode;
-  return 0;
+extern "C" int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs) {
+  DINER_CHECK_ARG(mlp, "mlp_weights_fit_f16x3: null handle");
+  if (max_abs) *max_abs = mlp->impl.wmax;
+  return (mlp->impl.wmax == mlp->impl.wmax && mlp->impl.wmax < 1024.0f) ? 1 : 0;
 }
-extern "C" int diner_get_precision(void) { return g_precision; }
 
 extern "C" int diner_profile_enable(int enable) {
+  std::lock_guard<std::mutex> lock(g_timer.mu);
   g_timer.enabled = enable != 0;
   return 0;
 }
 
 // Sums the recorded kernel durations since the last call (waits for the recorded events), then clears them.
 extern "C" int diner_profile_collect(double* pre_ms, double* post_ms, long long* launches, long long* points) {
+  std::lock_guard<std::mutex> lock(g_timer.mu);
   double a = 0.0, b = 0.0;
   long long pts = 0;
   const size_t n = g_timer.points.size();
@@ -772,13 +823,14 @@ extern "C" int diner_profile_collect(double* pre_ms, double* post_ms, long long*
 
 extern "C" size_t diner_field_workspace_bytes(long long n_points) {
   if (n_points <= 0) return 0;
-  return xpre_bytes(n_points, kMaxViews);     // view-averaged pre-mean activations in accumulator layout (2 KB / point)
+  // view-averaged pre-mean activations in accumulator layout (2 KB / point) + the overflow flag
+  return xpre_bytes(n_points, kMaxViews) + kFlagBytes;
 }
 
 extern "C" size_t diner_mlp_forward_workspace_bytes(long long B) {
   if (B <= 0) return 0;
   // as above plus the aligned split of the explicit zx matrix and the three projected copies of its latent rows
-  return xpre_bytes(B, kMaxViews) + (size_t)B * kMaxViews * (kLatent + kDInPad + 3 * kLatent) * sizeof(float);
+  return xpre_bytes(B, kMaxViews) + kFlagBytes + (size_t)B * kMaxViews * (kLatent + kDInPad + 3 * kLatent) * sizeof(float);
 }
 
 static int check_field_scene(const DinerScene* scene, SceneDev* sd) {
@@ -795,7 +847,7 @@ static int check_field_scene(const DinerScene* scene, SceneDev* sd) {
 }
 
 extern "C" int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays,
-                                         const float* z, int NR, int K, float* field_out, void* workspace,
+                                         const float* z, int NR, int K, int precision, float* field_out, void* workspace,
                                          void* stream) {
   DINER_CHECK_ARG(scene && mlp && rays && z && field_out && workspace, "field_from_rays: null pointer argument");
   DINER_CHECK_ARG(NR > 0 && K > 0, "field_from_rays: bad sizes NR=%d K=%d", NR, K);
@@ -810,12 +862,12 @@ extern "C" int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp
   fa.P = (long long)NR * K;
   fa.tz = scene->latent_proj;
   fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
-  return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, (hipStream_t)stream);
+  return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, precision, (hipStream_t)stream);
 }
 
 extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerMlp* mlp, const float* xyz,
-                                           const float* viewdirs, long long P, float* field_out, void* workspace,
-                                           void* stream) {
+                                           const float* viewdirs, long long P, int precision, float* field_out,
+                                           void* workspace, void* stream) {
   DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && field_out && workspace, "field_from_points: null pointer argument");
   DINER_CHECK_ARG(P > 0, "field_from_points: P must be positive");
   SceneDev sd;
@@ -829,7 +881,7 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
   fa.P = P;
   fa.tz = scene->latent_proj;
   fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
-  return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, (hipStream_t)stream);
+  return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, precision, (hipStream_t)stream);
 }
 
 extern "C" int diner_mlp_forward_f32(const DinerMlp* mlp, const float* zx, long long B, float* out, void* workspace,
@@ -838,7 +890,7 @@ extern "C" int diner_mlp_forward_f32(const DinerMlp* mlp, const float* zx, long 
   DINER_CHECK_ARG(B > 0, "mlp_forward: B must be positive");
   hipStream_t stream = (hipStream_t)stream_;
   char* ws = (char*)workspace;
-  float* lat = (float*)(ws + xpre_bytes(B, kMaxViews));
+  float* lat = (float*)(ws + xpre_bytes(B, kMaxViews) + kFlagBytes);
   float* feat = lat + (size_t)kMaxViews * B * kLatent;
   float* tz = feat + (size_t)kMaxViews * B * kDInPad;
   const long long rows = (long long)kMaxViews * B;
@@ -853,7 +905,7 @@ extern "C" int diner_mlp_forward_f32(const DinerMlp* mlp, const float* zx, long 
   fa.tz_stride = (size_t)rows * kLatent;
   fa.K = 1;
   fa.P = B;
-  return launch_field(nullptr, &mlp->impl, fa, kMaxViews, out, 1, workspace, stream);
+  return launch_field(nullptr, &mlp->impl, fa, kMaxViews, out, 1, workspace, DINER_PRECISION_FP32, stream);
 }
 
 extern "C" size_t diner_scene_proj_bytes(const DinerScene* scene) {
@@ -871,10 +923,10 @@ extern "C" int diner_scene_prepare_f32(const DinerScene* scene, const DinerMlp* 
 }
 
 extern "C" int diner_render_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z, int NR,
-                                int K, int white_bkgd, float* rgb_out, float* depth_out, float* weights_out,
+                                int K, int white_bkgd, int precision, float* rgb_out, float* depth_out, float* weights_out,
                                 float* field_ws, void* workspace, void* stream) {
   DINER_CHECK_ARG(field_ws, "render: field scratch missing");
-  int rc = diner_field_from_rays_f32(scene, mlp, rays, z, NR, K, field_ws, workspace, stream);
+  int rc = diner_field_from_rays_f32(scene, mlp, rays, z, NR, K, precision, field_ws, workspace, stream);
   if (rc) return rc;
   return diner_composite_f32(field_ws, z, rays, NR, K, white_bkgd, rgb_out, depth_out, weights_out, stream);
 }

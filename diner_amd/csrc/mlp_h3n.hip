@@ -1,16 +1,17 @@
-// f16x3 field kernels, "n-split" (feature-sliced) variant: the default (diner_set_precision(2); 3 = plain fp16 operands).
-//
-// mlp_h3.hip keeps the fp32 design: one wave = 16 (point,view) columns x all 512 features, weights streamed through
-// LDS and read by all four waves -- with fp16 MFMAs the matrix pipe is no longer the bound, the LDS fragment reads are
-// (each 16x16x32 MFMA consumes a fresh 1 KB weight fragment, four waves read the same ones).  Here the work is split the
-// other way: wave w owns output features [128 w, 128 w + 128) for ALL 64 columns of the workgroup (4 views x 16 points).
+// fp16-operand field kernels (DINER_PRECISION_F16X3: split products, three MFMAs per fp32 product; DINER_PRECISION_F16: plain
+// fp16 operands), feature-sliced ("n-split"): wave w owns output features [128 w, 128 w + 128) for ALL 64 columns of the
+// workgroup (4 views x 16 points).
+//   * every fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi (a = a_hi + a_lo, w = w_hi + w_lo, fp16 parts)
+//     on v_mfma_f32_16x16x32_f16 with fp32 accumulation; the network runs at a power-of-two scale (weights, biases x16,
+//     accumulators hold 16x the activations, the fp32 -> (hi, lo) conversion of every B operand folds the exact 1/16 back
+//     in) so that the low parts of small weights stay out of the fp16 subnormal range;
 //   * weights are wave-private: streamed straight global -> VGPR (16 KB per k32 block per wave, software-prefetched),
-//     each A fragment feeds 4 column groups x {hi,lo}: 12 MFMAs per (hi, lo) fragment pair instead of 3;
+//     each A fragment feeds 4 column groups x {hi,lo}: 12 MFMAs per (hi, lo) fragment pair;
 //   * activations are exchanged between layers through a 128 KB LDS buffer already in B-operand form (fp16 hi / lo,
-//     1/16 scale folded in): every wave converts its 128-feature slice, two barriers per layer instead of 32;
-//   * LDS traffic per MFMA drops 8x, the view mean is a register sum over the four column groups.
-// Arithmetic and scaling are those of mlp_h3.hip (same products, same accumulation order over k; results agree to fp32
-// round-off: the lin_z contribution joins the accumulation at a different point).
+//     1/16 scale folded in): every wave converts its 128-feature slice, two barriers per layer;
+//   * the view mean is a register sum over the four column groups.
+// (Round 1 also had an LDS-streamed-weights variant of the same arithmetic, mlp_h3.hip; it lost to this one on every
+// measurement -- 166.7 k vs 212.5 k rays/s, profiles/r01_v4_* vs r01_v8_* -- and was retired.)
 #include <utility>
 #include <vector>
 #include "field_common.hpp"
@@ -454,6 +455,10 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       const long long t16 = tile * 4 + wave;
       const long long p = t16 * kPtsPerWave + pt;
       if (t16 < n_t16 && q == 0 && p < pa.P) {
+        // A hidden activation beyond the fp16 range turns into inf in a B operand and reaches every raw output of the
+        // point as inf / NaN (so does a non-finite input): raise the flag that un-gates the exact-fp32 pass (mlp.hip).
+        const float probe = (res[0] - res[0]) + (res[1] - res[1]) + (res[2] - res[2]) + (res[3] - res[3]);   // 0 or NaN
+        if (pa.overflow && probe != 0.0f) *pa.overflow = 1;
         if (!pa.raw) {
           res[0] = 1.0f / (1.0f + expf(-res[0]));
           res[1] = 1.0f / (1.0f + expf(-res[1]));
@@ -481,12 +486,47 @@ __global__ void k_pack_layer_h3n(const float* __restrict__ W, int rows, int cols
   }
 }
 
+// lin_out fragments [t 16][hl 2][lane 64][8]: Wout[lane&15][32 t + 16 (j>>2) + 4 (lane>>4) + (j&3)] * scale, rows >= d_out zero
+__global__ void k_pack_lin_out_h3n(const float* __restrict__ W, int rows, int cols, float scale, _Float16* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 16384; i += gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63, hl = (i >> 9) & 1, t = i >> 10;
+    const int row = lane & 15, col = 32 * t + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+    const float w = (row < rows && col < cols) ? W[(size_t)row * cols + col] * scale : 0.0f;
+    const _Float16 h = (_Float16)w;
+    dst[i] = hl ? (_Float16)(w - (float)h) : h;
+  }
+}
+__global__ void k_scale_pad(const float* __restrict__ src, int n, int n_pad, float scale, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x)
+    dst[i] = i < n ? src[i] * scale : 0.0f;
+}
+
 }  // namespace h3n
 
-int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out) {
+// w: lin_in + 6 per-view + 4 post layers (n-split fragments); w_out: lin_out fragments; b_pre: 7 x 512 (x16); b_post: 4 x 512
+// (x16) + the lin_out bias at scale 1 (padded to 16).  The caller frees whatever was allocated when this fails.
+int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float** w_lin_out, float** b_pre, float** b_post) {
   using namespace h3n;
   const size_t halfs = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
   DINER_HIP_OK(hipMalloc(w_out, halfs * sizeof(_Float16)));
+  DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16)));
+  DINER_HIP_OK(hipMalloc(b_pre, 7 * kHidden * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(b_post, (4 * kHidden + 16) * sizeof(float)));
+  auto bias = [&](const float* b, int n, int n_pad, float scale, float* dst) {
+    hipLaunchKernelGGL(k_scale_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, scale, dst);
+  };
+  bias(p->lin_in_b, kHidden, kHidden, kScale, *b_pre);
+  for (int b = 0; b < 3; ++b) {
+    bias(p->fc0_b[b], kHidden, kHidden, kScale, *b_pre + kHidden * (1 + 2 * b));
+    bias(p->fc1_b[b], kHidden, kHidden, kScale, *b_pre + kHidden * (2 + 2 * b));
+  }
+  for (int b = 3; b < 5; ++b) {
+    bias(p->fc0_b[b], kHidden, kHidden, kScale, *b_post + 2 * kHidden * (b - 3));
+    bias(p->fc1_b[b], kHidden, kHidden, kScale, *b_post + 2 * kHidden * (b - 3) + kHidden);
+  }
+  bias(p->lin_out_b, 4, 16, 1.0f, *b_post + 4 * kHidden);
+  hipLaunchKernelGGL(k_pack_lin_out_h3n, dim3(64), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, kScale,
+                     (_Float16*)*w_lin_out);
   _Float16* wp = (_Float16*)*w_out;
   hipLaunchKernelGGL(k_pack_layer_h3n, dim3(256), dim3(256), 0, stream, p->lin_in_w, kHidden, kDIn, 2, kScale, wp);
   wp += (size_t)4 * 2 * 8192;
@@ -524,10 +564,10 @@ void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, con
   else hipLaunchKernelGGL(h3n::k_field_pre_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
 }
 
-// w: the n-split pack (post layers follow the per-view ones); w_post_h3: mlp_h3.hip's post pack, whose last stage is lin_out
-void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_post_h3, int grid, bool split, hipStream_t stream) {
+// w: the n-split pack (post layers follow the per-view ones); w_lin_out: the lin_out fragments
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out, int grid, bool split, hipStream_t stream) {
   const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
-  const _Float16* wo = (const _Float16*)w_post_h3 + (size_t)(kPostStages - 1) * 2 * kStageFloats;
+  const _Float16* wo = (const _Float16*)w_lin_out;
   h3n::PostArgsN a{pa, wn, wo};
   if (split) hipLaunchKernelGGL(h3n::k_field_post_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);
   else hipLaunchKernelGGL(h3n::k_field_post_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);

@@ -450,7 +450,7 @@ extern "C" int diner_gemm_f32(const float* A, const float* B, float* C, long lon
 }
 
 extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P,
-                                      float* feat, int* tap_row, float* tap_w, float* lat, void* stream) {
+                                      float freq_factor, float* feat, int* tap_row, float* tap_w, float* lat, void* stream) {
   DINER_CHECK_ARG(scene && xyz && viewdirs && feat && tap_row && tap_w && lat, "train_inputs: null pointer argument");
   DINER_CHECK_ARG(P > 0, "train_inputs: P must be positive");
   SceneDev sd;
@@ -463,7 +463,7 @@ extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz,
   fa.viewdirs = viewdirs;
   fa.K = 1;
   fa.P = P;
-  fa.freq_factor = 6.28f;
+  fa.freq_factor = freq_factor;
   const long long waves = (P + 15) / 16 * sd.nv;
   hipLaunchKernelGGL(k_train_inputs, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sd, fa, feat,
                      tap_row, tap_w);
@@ -548,16 +548,7 @@ TrainWs train_ws(long long P, int nv) {
   w.total = o;
   return w;
 }
-int check_train_params(const DinerMlpParams* p) {
-  DINER_CHECK_ARG(p && p->lin_in_w && p->lin_in_b && p->lin_out_w && p->lin_out_b && p->fc0_w && p->fc0_b && p->fc1_w &&
-                      p->fc1_b && p->lin_z_w && p->lin_z_b, "field_train: parameter pointers missing");
-  if (p->d_in != kDIn || p->d_latent != kLatent || p->d_hidden != kHidden || p->d_out != 4 || p->n_blocks != 5 ||
-      p->combine_layer != 3) {
-    set_error("field_train: built for d_in=55, d_latent=d_hidden=512, d_out=4, 5 blocks, combine_layer=3");
-    return DINER_E_UNSUPPORTED;
-  }
-  return 0;
-}
+int check_train_params(const DinerMlpParams* p, bool poscode) { return check_mlp_config(p, "field_train", poscode); }
 // adjoint of y = act(x) W^T + b: dW = dy^T act(x) (split-K atomics into zeroed dW), db = column sums, dx (+)= (dy W) [masked]
 int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, const float* W, float* dW, float* db,
                long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st) {
@@ -583,13 +574,13 @@ extern "C" size_t diner_field_train_workspace_bytes(long long P, int nv) {
 extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
                                              const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
   DINER_CHECK_ARG(scene && xyz && viewdirs && out && workspace && P > 0, "field_train_forward: bad arguments");
-  int rc = check_train_params(p);
+  int rc = check_train_params(p, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const TrainWs w = train_ws(P, scene->nv);
   const long long cols = P * scene->nv;
-  rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
+  rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
   if (rc) return rc;
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
                  bool accum) {
@@ -620,9 +611,9 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
                                               long long P, const float* d_out, void* workspace, float* d_latent_cl,
                                               void* stream) {
   DINER_CHECK_ARG(scene && d_out && workspace && P > 0, "field_train_backward: bad arguments");
-  int rc = check_train_params(p);
+  int rc = check_train_params(p, false);
   if (rc) return rc;
-  rc = check_train_params(grads);
+  rc = check_train_params(grads, false);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;

@@ -15,7 +15,9 @@ from . import _lib
 
 lib = _lib.load()          # ImportError when the extension is not built -- by design
 
-MAX_POINTS_PER_LAUNCH = int(os.environ.get("DINER_AMD_MAX_POINTS", 1 << 20))   # bounds the 8 KB/point workspace
+# points per field launch: bounds the 2 KB/point hand-over workspace (2 GiB at the default) without costing throughput
+# (a launch of 2^20 points is 64 tiles per CU)
+MAX_POINTS_PER_LAUNCH = int(os.environ.get("DINER_AMD_MAX_POINTS", 1 << 20))
 
 
 def _require_hip(*tensors):
@@ -112,7 +114,7 @@ class HipScene:
         s.depth = self.depth.data_ptr() if self.depth is not None else None
         s.depth_std = self.depth_std.data_ptr() if self.depth_std is not None else None
         s.normals = self.normals.data_ptr() if self.normals is not None else None
-        s.poses, s.focal, s.c = self.poses_h.data_ptr(), self.focal_h.data_ptr(), self.c_h.data_ptr()
+        s.poses_host, s.focal_host, s.c_host = self.poses_h.data_ptr(), self.focal_h.data_ptr(), self.c_h.data_ptr()
         s.std_pad_scale = self.std_pad_scale.data_ptr()
         s.img_w, s.img_h, s.feature_padding = self.img_w, self.img_h, self.feature_padding
         s.nv, s.C, s.Hf, s.Wf, s.Hs, s.Ws = self.nv, self.C, self.Hf, self.Wf, self.Hs, self.Ws
@@ -145,7 +147,7 @@ class HipMlp:
     """Packed ResnetFC weights (opaque DinerMlp handle).  Built from a state_dict-like mapping with the
     reference key names (resnetfc.py:72-127); tensors must be on the HIP device."""
 
-    def __init__(self, sd, prefix="", combine_layer=3, d_latent=512):
+    def __init__(self, sd, prefix="", combine_layer=3, d_latent=512, num_freqs=6, freq_factor=6.28, include_input=True):
         g = lambda k: _f32c(sd[prefix + k])
         n_blocks = len([k for k in sd if k.startswith(prefix + "blocks.") and k.endswith("fc_0.weight")])
         n_z = len([k for k in sd if k.startswith(prefix + "lin_z.") and k.endswith(".weight")])
@@ -165,6 +167,8 @@ class HipMlp:
         p.d_out = keep["lin_out_w"].shape[0]
         p.d_latent = lists["lin_z_w"][0].shape[1] if n_z else 0
         p.n_blocks, p.combine_layer = n_blocks, combine_layer
+        # the positional encoding that produces the 55 inputs is evaluated inside the field kernels (pixelnerf.py:15-18)
+        p.num_freqs, p.include_input, p.freq_factor = int(num_freqs), int(bool(include_input)), float(freq_factor)
         p.lin_in_w, p.lin_in_b = keep["lin_in_w"].data_ptr(), keep["lin_in_b"].data_ptr()
         p.lin_out_w, p.lin_out_b = keep["lin_out_w"].data_ptr(), keep["lin_out_b"].data_ptr()
         self._arrays = {}
@@ -173,14 +177,16 @@ class HipMlp:
             self._arrays[name] = arr
             setattr(p, name, C.cast(arr, C.POINTER(C.c_void_p)))
         self.device = keep["lin_in_w"].device
-        # f16x3 runs the network at 16x scale in fp16 hi/lo parts: weights must stay far inside the fp16 range
-        wmax = max(float(t.abs().max()) for t in list(keep.values()) + [t for l in lists.values() for t in l])
-        self.h3_ok = bool(np.isfinite(wmax) and wmax < 1024.0)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
+            # returns once the packing has completed on the stream (the sources may then be freed or updated in place)
             _lib.check(lib.diner_mlp_create(C.byref(p), _stream(), C.byref(h)))
-            torch.cuda.current_stream().synchronize()     # sources may be freed after packing
         self.handle = h
+        # the fp16-operand modes carry the weights x16 as fp16 hi/lo parts: |w| must stay below 1024.  The range was
+        # reduced on the device while packing; the library itself falls back to the exact kernels when it does not fit.
+        wmax = C.c_float()
+        self.h3_ok = lib.diner_mlp_weights_fit_f16x3(h, C.byref(wmax)) == 1
+        self.wmax = float(wmax.value)
 
     def __del__(self):
         try:
@@ -233,31 +239,18 @@ def fill_uniform(z_in, rays, noise_fill=None, seed=0):
     return out
 
 
-_requested_precision = [None]
-
-
-def _apply_precision(mlp):
-    """The library switch is process-wide; honour the requested mode unless this MLP's weights are outside the range
-    the fp16 split supports (then the exact fp32 kernels are used for it)."""
-    want = _requested_precision[0]
-    if want is None:
-        return
-    eff = want if (want == 0 or mlp.h3_ok) else 0
-    if lib.diner_get_precision() != eff:
-        _lib.check(lib.diner_set_precision(eff))
-
-
 def _workspace(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
-def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z):
-    """PixelNeRF.forward at every (ray, sample): (NR,8),(NR,K) -> (NR,K,4) [sigmoid rgb, relu sigma]."""
+def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z, precision=None):
+    """PixelNeRF.forward at every (ray, sample): (NR,8),(NR,K) -> (NR,K,4) [sigmoid rgb, relu sigma].
+    precision: PRECISION_* for this call (default: get_precision())."""
     _require_hip(rays, z)
     rays, z = _f32c(rays), _f32c(z)
     NR, K = z.shape
     scene.prepare(mlp)
-    _apply_precision(mlp)
+    prec = _precision_for(scene, precision)
     out = torch.empty(NR, K, 4, device=rays.device, dtype=torch.float32)
     if NR == 0:
         return out
@@ -267,17 +260,17 @@ def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z):
         for r0 in range(0, NR, rays_per):
             r1 = min(NR, r0 + rays_per)
             _lib.check(lib.diner_field_from_rays_f32(scene.ref, mlp.handle, _ptr(rays[r0:r1]), _ptr(z[r0:r1]),
-                                                     r1 - r0, K, _ptr(out[r0:r1]), _ptr(ws), _stream()))
+                                                     r1 - r0, K, prec, _ptr(out[r0:r1]), _ptr(ws), _stream()))
     return out
 
 
-def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs):
+def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs, precision=None):
     """PixelNeRF.forward(xyz, viewdirs): (P,3),(P,3) -> (P,4)."""
     _require_hip(xyz, viewdirs)
     xyz, viewdirs = _f32c(xyz), _f32c(viewdirs)
     P = xyz.shape[0]
     scene.prepare(mlp)
-    _apply_precision(mlp)
+    prec = _precision_for(scene, precision)
     out = torch.empty(P, 4, device=xyz.device, dtype=torch.float32)
     if P == 0:
         return out
@@ -287,7 +280,7 @@ def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs):
         for p0 in range(0, P, step):
             p1 = min(P, p0 + step)
             _lib.check(lib.diner_field_from_points_f32(scene.ref, mlp.handle, _ptr(xyz[p0:p1]), _ptr(viewdirs[p0:p1]),
-                                                       p1 - p0, _ptr(out[p0:p1]), _ptr(ws), _stream()))
+                                                       p1 - p0, prec, _ptr(out[p0:p1]), _ptr(ws), _stream()))
     return out
 
 
@@ -323,9 +316,9 @@ def composite(field, z, rays, white_bkgd, want_weights=True):
     return w, rgb, depth
 
 
-def render(scene: HipScene, mlp: HipMlp, rays, z, white_bkgd, want_weights=False):
+def render(scene: HipScene, mlp: HipMlp, rays, z, white_bkgd, want_weights=False, precision=None):
     """field + composite (NeRFRendererDGS.composite): -> weights | None, rgb, depth."""
-    field = field_from_rays(scene, mlp, rays, z)
+    field = field_from_rays(scene, mlp, rays, z, precision=precision)
     return composite(field, z, rays, white_bkgd, want_weights)
 
 
@@ -416,32 +409,42 @@ def profile_collect():
     return dict(pre_ms=a.value, post_ms=b.value, launches=n.value, points=p.value)
 
 
-PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X3_NSPLIT, PRECISION_F16 = 0, 1, 2, 3
+# ---- arithmetic of the MLP GEMMs: a per-call argument of the C ABI (DINER_PRECISION_* of include/diner_hip.h) --------
+PRECISION_FP32, PRECISION_F16X3, PRECISION_F16 = 0, 1, 2
+PRECISION_NAMES = {"fp32": PRECISION_FP32, "f32": PRECISION_FP32, "exact": PRECISION_FP32,
+                   "f16x3": PRECISION_F16X3, "f16x3n": PRECISION_F16X3, "split": PRECISION_F16X3,
+                   "f16": PRECISION_F16, "fp16": PRECISION_F16, "half": PRECISION_F16}
+_default_precision = [PRECISION_F16X3]
 
 
 def set_precision(mode):
-    """0: exact fp32 MFMA; 1: f16x3 split products, weights streamed through LDS; 2: f16x3, feature-sliced waves
-    (see include/diner_hip.h); 3: plain fp16 operands with fp32 accumulation in the same kernels (BASELINE configs[4],
-    "fp16 MLP on MFMA": ~1e-3 relative, NOT inside the 1e-4 parity bar).
-    Default: 2 (env DINER_AMD_PRECISION = fp32 | f16x3 | f16x3n | f16)."""
-    _lib.check(lib.diner_set_precision(int(mode)))
-    _requested_precision[0] = int(mode)
+    """Default `precision` of the field calls of THIS Python host (the library has no global switch; every C call carries
+    its mode).  PRECISION_FP32: exact fp32 MFMA.  PRECISION_F16X3 (default): split products on the fp16 MFMA with fp32
+    accumulation, fp32-class accuracy (3e-6 end to end against the reference; every parity test holds it to the fp32
+    bar).  PRECISION_F16: plain fp16 operands (BASELINE configs[4], "fp16 MLP on MFMA"): ~1e-3 relative, NOT inside the
+    1e-4 parity bar.  Env: DINER_AMD_PRECISION = fp32 | f16x3 | f16."""
+    if isinstance(mode, str):
+        mode = PRECISION_NAMES[mode.lower()]
+    if int(mode) not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16):
+        raise ValueError(f"diner_amd: unknown precision {mode!r}")
+    _default_precision[0] = int(mode)
 
 
 def get_precision():
-    return int(lib.diner_get_precision())
+    return _default_precision[0]
 
 
-# Default arithmetic of the MLP GEMMs: f16x3 split products (fp32-class accuracy, measured 3e-6 end to end against the
-# reference, about twice the fp32 MFMA throughput).  DINER_AMD_PRECISION=fp32 selects the exact-fp32 MFMA kernels.
-_want = os.environ.get("DINER_AMD_PRECISION", "f16x3n").lower()
-if _want in ("f16x3", "1", "split"):
-    set_precision(PRECISION_F16X3)
-elif _want in ("f16x3n", "2", "nsplit"):
-    set_precision(PRECISION_F16X3_NSPLIT)
-elif _want in ("f16", "fp16", "3", "half"):
-    set_precision(PRECISION_F16)
-elif _want in ("fp32", "f32", "0", "exact"):
-    set_precision(PRECISION_FP32)
-else:
-    raise ValueError(f"DINER_AMD_PRECISION={_want!r}: expected 'f16x3n', 'f16x3', 'f16' or 'fp32'")
+def _precision_for(scene, precision):
+    """Mode passed to the library for one call.  A scene whose projected maps exceed the 32-bit addressing of the
+    fp16-operand kernels (>= 4 GiB per map: images beyond ~2700 x 2700) is rendered by the exact kernels."""
+    prec = get_precision() if precision is None else (PRECISION_NAMES[precision.lower()] if isinstance(precision, str)
+                                                      else int(precision))
+    if prec != PRECISION_FP32 and scene.nv * scene.Hf * scene.Wf * 2048 >= (1 << 32):
+        return PRECISION_FP32
+    return prec
+
+
+_want = os.environ.get("DINER_AMD_PRECISION", "f16x3").lower()
+if _want not in PRECISION_NAMES:
+    raise ValueError(f"DINER_AMD_PRECISION={_want!r}: expected one of {sorted(PRECISION_NAMES)}")
+set_precision(_want)

@@ -7,8 +7,11 @@ RCCL on ROCm), each rank renders its range with the HIP kernels, and ONE gather 
 (16 B/ray) brings the image to rank 0.  There is no other collective on the data path: scene state and MLP weights
 are replicated (every rank runs `encode` itself).
 """
+import contextlib
+
 import torch
 
+from diner_amd import noise as _noise
 from src.util.cam_geometry import gen_rays
 
 
@@ -43,7 +46,9 @@ def predict_image(nerf, renderer, target_extrinsics, target_intrinsics, W, H, zn
                   rank=0, world=1, group=None):
     """Render the (SB) target views described by target_extrinsics (SB,4,4) / target_intrinsics (SB,3,3) of the
     scene last passed to nerf.encode().  Returns rgb (SB,3,H,W), depth (SB,1,H,W) on rank 0 (None elsewhere).
-    Same ray order (row-major pixels, centres at +0.5) and output layout as diner.py:79-92."""
+    Same ray order (row-major pixels, centres at +0.5) and output layout as diner.py:79-92.  Noise injected with
+    diner_amd.noise.inject for the whole (SB, H*W, .) ray list is handed to every batch as the matching slice (parity
+    tests); without injection the sampler draws in-kernel Philox noise."""
     SB = target_extrinsics.shape[0]
     dev = target_extrinsics.device
     znear = torch.as_tensor(znear, device=dev, dtype=torch.float32).expand(SB)
@@ -57,9 +62,13 @@ def predict_image(nerf, renderer, target_extrinsics, target_intrinsics, W, H, zn
         rays = gen_rays(target_extrinsics, target_intrinsics, W, H, znear, zfar).view(SB, H * W, 8)
         base = 0
     tiles = []
+    inj = _noise.current()
     for r0 in range(lo, hi, ray_batch_size):
-        rb = rays[:, r0 - base:min(hi, r0 + ray_batch_size) - base].contiguous()
-        out = renderer.forward(model=nerf, rays=rb)
+        r1 = min(hi, r0 + ray_batch_size)
+        rb = rays[:, r0 - base:r1 - base].contiguous()
+        ctx = contextlib.nullcontext() if inj is None else _noise.inject(*(None if t is None else t[:, r0:r1] for t in inj))
+        with ctx:
+            out = renderer.forward(model=nerf, rays=rb)
         tiles.append(torch.cat((out.fine.rgb, out.fine.depth.unsqueeze(-1)), dim=-1))      # (SB, b, 4)
     local = torch.cat(tiles, dim=1) if tiles else torch.zeros(SB, 0, 4, device=dev)
     full = gather_tiles(local.permute(1, 0, 2).reshape(hi - lo, SB * 4), H * W, rank, world, group)

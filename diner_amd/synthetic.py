@@ -65,12 +65,15 @@ def _analytic_depth(E, Kmat, W, H, radius=0.25, plane_z=0.35, plane_half=0.6):
 
 
 def make_scene(W=64, H=64, nv=4, seed=0, latent_ch=512, image_padding=64, znear=0.5, zfar=1.5,
-               bg_std_zero=False, latent=True):
+               bg_std_zero=False, latent=True, scale=1.0, std_law="dtu"):
     """Returns a dict of CPU tensors describing one object:
         src_extrinsics (NV,4,4), src_intrinsics (NV,3,3), depths / depths_std (NV,1,H,W),
         latent (NV,C,Hf,Wf) [if latent], target_extrinsics (4,4), target_intrinsics (3,3),
         image_shape (2,) = [W,H], znear, zfar, feature_padding.
     Normals are NOT included: they are derived from the depth maps by depth2normal at encode time.
+    `scale` multiplies the whole geometry (camera distance, sphere, plane): scale=1.75 with znear/zfar = 1.0/2.5 is
+    the Facescape depth range (facescape.py:19-20); std_law="facescape" uses that dataset's confidence law
+    (facescape.py:50-52: std = 1.649e-2 - 1.582e-2 * conf).
     """
     g = torch.Generator().manual_seed(seed)
     Kmat = torch.tensor([[1.2 * W, 0.0, W / 2.0], [0.0, 1.2 * W, H / 2.0], [0.0, 0.0, 1.0]])
@@ -79,16 +82,23 @@ def make_scene(W=64, H=64, nv=4, seed=0, latent_ch=512, image_padding=64, znear=
     for i, a in enumerate(angs.tolist()):
         th = math.radians(a)
         elev = 0.06 * ((-1) ** i)
-        extr.append(look_at_extrinsics((math.sin(th), elev, -math.cos(th))))
+        extr.append(look_at_extrinsics((scale * math.sin(th), scale * elev, -scale * math.cos(th))))
     extr = torch.stack(extr)
     intr = Kmat.unsqueeze(0).repeat(nv, 1, 1).clone()
-    depths = torch.stack([_analytic_depth(extr[i], intr[i], W, H) for i in range(nv)]).unsqueeze(1)
+    depths = torch.stack([_analytic_depth(extr[i], intr[i], W, H, radius=0.25 * scale, plane_z=0.35 * scale,
+                                          plane_half=0.6 * scale) for i in range(nv)]).unsqueeze(1)
     conf = torch.rand(nv, 1, H, W, generator=g) * 0.7 + 0.3
-    std = 0.0328 - 0.0257 * conf                       # dtu.py:68-70
+    if std_law == "dtu":
+        std = 0.0328 - 0.0257 * conf                   # dtu.py:68-70
+    elif std_law == "facescape":
+        std = 1.649e-2 - 1.582e-2 * conf               # facescape.py:50-52
+    else:
+        raise ValueError(f"unknown std_law {std_law!r}")
     if bg_std_zero:
         std = torch.where(depths == 0, torch.zeros_like(std), std)   # multiface.py:310 variant
     out = dict(src_extrinsics=extr, src_intrinsics=intr, depths=depths, depths_std=std,
-               target_extrinsics=look_at_extrinsics((0.03, -0.02, -1.0)), target_intrinsics=Kmat.clone(),
+               target_extrinsics=look_at_extrinsics((0.03 * scale, -0.02 * scale, -1.0 * scale)),
+               target_intrinsics=Kmat.clone(),
                image_shape=torch.tensor([float(W), float(H)]), znear=znear, zfar=zfar,
                feature_padding=image_padding / 2.0, W=W, H=H)
     if latent:

@@ -65,13 +65,14 @@ def mlp_params(mlp_module):
     return [sd[k] for k in PARAM_ORDER]
 
 
-def _param_struct(tensors):
+def _param_struct(tensors, freq_factor=6.28):
     """DinerMlpParams over 30 device tensors in PARAM_ORDER (parameters or gradient buffers); returns (struct, keep-alive)."""
     import ctypes as C
     t = dict(zip(PARAM_ORDER, tensors))
     p = _lib.DinerMlpParams()
     p.d_in, p.d_hidden, p.d_out = t["lin_in.weight"].shape[1], t["lin_in.weight"].shape[0], t["lin_out.weight"].shape[0]
     p.d_latent, p.n_blocks, p.combine_layer = t["lin_z.0.weight"].shape[1], 5, 3
+    p.num_freqs, p.include_input, p.freq_factor = 6, 1, float(freq_factor)
     p.lin_in_w, p.lin_in_b = t["lin_in.weight"].data_ptr(), t["lin_in.bias"].data_ptr()
     p.lin_out_w, p.lin_out_b = t["lin_out.weight"].data_ptr(), t["lin_out.bias"].data_ptr()
     keep = [tensors]
@@ -90,7 +91,7 @@ class FieldFunction(torch.autograd.Function):
     forward (keeps every pre-activation in `ws`), one for the backward (diner_field_train_{forward,backward}_f32)."""
 
     @staticmethod
-    def forward(ctx, scene: HipScene, xyz, viewdirs, latent, *params):
+    def forward(ctx, scene: HipScene, xyz, viewdirs, latent, freq_factor, *params):
         import ctypes as C
         _require_hip(xyz, viewdirs, latent)
         xyz, viewdirs = _f32c(xyz.detach()), _f32c(viewdirs.detach())
@@ -100,7 +101,7 @@ class FieldFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = torch.empty(int(lib.diner_field_train_workspace_bytes(P, NV)), dtype=torch.uint8, device=dev)
             out = torch.empty(P, 4, device=dev)
-            ps, keep = _param_struct(params)
+            ps, keep = _param_struct(params, freq_factor)
             _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
                                                          _ptr(ws), _stream()))
         ctx.scene, ctx.P = scene, P
@@ -124,7 +125,7 @@ class FieldFunction(torch.autograd.Function):
                 d_cl = torch.empty(nv, Hf, Wf, Cc, device=dev)
             _lib.check(lib.diner_field_train_backward_f32(ctx.scene.ref, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out),
                                                           _ptr(ws), _ptr(d_cl), _stream()))
-        return (None, None, None, d_cl.permute(0, 3, 1, 2) if d_cl is not None else None) + tuple(grads)
+        return (None, None, None, d_cl.permute(0, 3, 1, 2) if d_cl is not None else None, None) + tuple(grads)
 
 
 class CompositeFunction(torch.autograd.Function):
@@ -153,8 +154,8 @@ class CompositeFunction(torch.autograd.Function):
         return d_field, None, None, None
 
 
-def field_train(scene: HipScene, xyz, viewdirs, latent, params):
-    return FieldFunction.apply(scene, xyz, viewdirs, latent, *params)
+def field_train(scene: HipScene, xyz, viewdirs, latent, params, freq_factor=6.28):
+    return FieldFunction.apply(scene, xyz, viewdirs, latent, float(freq_factor), *params)
 
 
 def composite_train(field, z, rays, white_bkgd):

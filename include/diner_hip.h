@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DINER_ABI_VERSION 1
+#define DINER_ABI_VERSION 2
 
 #define DINER_E_INVALID     (-1)  /* bad argument (null pointer, size, unsupported configuration) */
 #define DINER_E_UNSUPPORTED (-2)  /* configuration outside what the kernels are built for        */
@@ -40,9 +40,11 @@ typedef struct DinerScene {
   const float* depth;       /* (NV, Hs, Ws)     source depth maps, 0 = background                          */
   const float* depth_std;   /* (NV, Hs, Ws)     depth standard deviation                                    */
   const float* normals;     /* (NV, 3, Hs, Ws)  normal maps (planar, as produced by depth2normal)          */
-  const float* poses;       /* HOST (NV, 4, 4)  world->camera extrinsics, row-major  -- the three camera arrays are  */
-  const float* focal;       /* HOST (NV, 2)     fx, fy                                  tiny and are copied by value  */
-  const float* c;           /* HOST (NV, 2)     cx, cy                                  into the kernel arguments     */
+  /* ---- the only HOST pointers of this struct (suffix _host): three tiny camera arrays, read on the host at call time and
+   *      copied by value into the kernel arguments (SGPRs); never dereferenced on the device ---- */
+  const float* poses_host;  /* HOST (NV, 4, 4)  world->camera extrinsics, row-major (pixelnerf.py:47)               */
+  const float* focal_host;  /* HOST (NV, 2)     fx, fy                               (pixelnerf.py:49)               */
+  const float* c_host;      /* HOST (NV, 2)     cx, cy                               (pixelnerf.py:48)               */
   const float* std_pad_scale; /* (100)          multipliers exp(e/12*ln2), e = 0..99, of the exponential std padding
                                                  (torch_helpers.py:110-120 with pad_size=100, pad_double_width=12,
                                                  image_encoder.py:185-194); computed by the host exactly as the
@@ -56,6 +58,11 @@ typedef struct DinerScene {
  * resnetfc.py:72-127.  Host or device pointers are both accepted by diner_mlp_create (flag). */
 typedef struct DinerMlpParams {
   int32_t d_in, d_latent, d_hidden, d_out, n_blocks, combine_layer;
+  /* positional encoding that produces the d_in inputs (pixelnerf.py:15-18, positional_encoding.py:12-31): the field
+   * entry points encode x_c (3 -> 3*(2F+1)) and the depth difference (1 -> 2F+1) in registers.  num_freqs must be 6
+   * and include_input non-zero (d_in = 55); freq_factor is honoured (6.28 in every shipped config). */
+  int32_t num_freqs, include_input;
+  float freq_factor;
   const float* lin_in_w;  const float* lin_in_b;       /* (d_hidden, d_in), (d_hidden)          */
   const float* lin_out_w; const float* lin_out_b;      /* (d_out, d_hidden), (d_out)            */
   const float* const* fc0_w; const float* const* fc0_b; /* n_blocks x (d_hidden,d_hidden),(d_hidden) */
@@ -70,10 +77,15 @@ const char* diner_last_error(void);
 
 /* ---- packed weights ---------------------------------------------------------------------------
  * Packs the ResnetFC parameters (DEVICE pointers) into stage-tile order on `stream`.
- * Supported: d_in=55, d_latent=512, d_hidden=512, d_out=4, n_blocks=5, combine_layer=3 (the
- * configuration of configs/train_dtu.yaml:44-50 and train_facescape.yaml), NV = 4. */
+ * Supported: d_in=55, d_latent=512, d_hidden=512, d_out=4, n_blocks=5, combine_layer=3, num_freqs=6, include_input=1
+ * (the configuration of configs/train_dtu.yaml:39-50 and train_facescape.yaml), NV = 4; anything else returns
+ * DINER_E_UNSUPPORTED before any device work.  A failed call leaves no allocation behind. */
 int diner_mlp_create(const DinerMlpParams* p, void* stream, DinerMlp** out);
 int diner_mlp_destroy(DinerMlp* mlp);
+/* Largest |weight| / |bias| over all parameters, reduced on the device at pack time (one 4-byte read back, after a
+ * stream synchronise): DINER_PRECISION_F16X3 / _F16 carry the weights x16 as fp16 and need it below 1024.
+ * Returns 1 when the f16 modes may be used with this handle, 0 when not, <0 on error; *max_abs (optional) receives the value. */
+int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs);
 
 /* ---- a1+a2+a3+a4: NeRFRendererDGS.sample_depthguided + fill_up_uniform_samples ---------------
  * (nerf_renderer.py:39-63, :65-190, :367-397; torch_helpers.py:215-223; image_encoder.py:148-223)
@@ -102,17 +114,34 @@ int diner_fill_uniform_f32(const float* z_in, const float* rays, int NR, int K, 
 size_t diner_scene_proj_bytes(const DinerScene* scene);
 int diner_scene_prepare_f32(const DinerScene* scene, const DinerMlp* mlp, float* latent_proj_out, void* stream);
 
+/* ---- arithmetic of the MLP GEMMs: a PER-CALL argument of the field entry points (no process-wide state) ---------
+ * DINER_PRECISION_FP32  exact fp32 MFMA (v_mfma_f32_16x16x4_f32), an fmaf chain per output (mlp.hip).
+ * DINER_PRECISION_F16X3 "f16x3" split products: each fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi
+ *                       on the fp16 MFMA with fp32 accumulation and power-of-two pre-scaling; ~2^-21 relative error per
+ *                       product, end-to-end results within fp32 round-off class of the reference (parity tests hold it
+ *                       to the same 1e-4 bar as FP32).  Feature-sliced kernels (mlp_h3n.hip).  Requires |w| < 1024 and
+ *                       hidden activations < 6.5e4 (weights are checked by the host; see diner_mlp_weights_fit_f16x3);
+ *                       one projected map (NV*Hf*Wf*2 KB) must stay below 4 GiB, else DINER_E_UNSUPPORTED.
+ * DINER_PRECISION_F16   plain fp16 operands (hi parts only, one MFMA per product), fp32 accumulation, same kernels:
+ *                       BASELINE configs[4] ("fp16 MLP on MFMA").  ~1e-3 relative on rendered colours: OUTSIDE the
+ *                       1e-4 parity bar, never a default.
+ * diner_mlp_forward_f32 (explicit matrices), diner_scene_prepare_f32 and the training path always use exact fp32. */
+#define DINER_PRECISION_FP32  0
+#define DINER_PRECISION_F16X3 1
+#define DINER_PRECISION_F16   2
+
 /* ---- a5+a6+a7+a8: PixelNeRF.forward at ray samples -------------------------------------------
  * (pixelnerf.py:55-145; positional_encoding.py:33-53; image_encoder.py:97-170; resnetfc.py:129-159)
  * Points are o + z*d for every (ray, sample); view directions are the ray directions.
+ *   precision  DINER_PRECISION_* (above)
  *   field_out  (NR*K, 4) = [sigmoid(r,g,b), relu(sigma)]
  *   workspace  diner_field_workspace_bytes(NR*K) bytes of device scratch */
 size_t diner_field_workspace_bytes(long long n_points);
 int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z,
-                              int NR, int K, float* field_out, void* workspace, void* stream);
+                              int NR, int K, int precision, float* field_out, void* workspace, void* stream);
 /* Same, explicit points / view directions (P,3): PixelNeRF.forward(xyz, viewdirs) (pixelnerf.py:55). */
 int diner_field_from_points_f32(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs,
-                                long long P, float* field_out, void* workspace, void* stream);
+                                long long P, int precision, float* field_out, void* workspace, void* stream);
 
 /* ---- a7 alone: ResnetFC.forward(zx, combine_dim) on an explicit (NV, B, d_latent+d_in) matrix --
  * workspace: diner_mlp_forward_workspace_bytes(B) bytes. */
@@ -128,7 +157,7 @@ int diner_composite_f32(const float* field, const float* z, const float* rays, i
 /* ---- a10: NeRFRendererDGS.composite / forward (nerf_renderer.py:286-365, :399-424) -----------
  * field + composite in one call; `field_ws` is (NR*K,4) scratch the caller provides. */
 int diner_render_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z, int NR, int K,
-                     int white_bkgd, float* rgb_out, float* depth_out, float* weights_out,
+                     int white_bkgd, int precision, float* rgb_out, float* depth_out, float* weights_out,
                      float* field_ws, void* workspace, void* stream);
 
 /* ---- stage-level entries that back the reference's small public methods ---------------------- */
@@ -177,8 +206,8 @@ int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N,
 /* Per-(view, point) MLP inputs of PixelNeRF.forward (pixelnerf.py:91-128) for explicit points xyz / viewdirs (P,3):
  *   feat (NV*P, 64) the 55 encoded inputs zero-padded, tap_row (NV*P, 4) int32 texel rows of the channels-last latent,
  *   tap_w (NV*P, 4) bilinear weights, lat (NV*P, 512) the interpolated latent (SpatialEncoder.index). */
-int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P, float* feat,
-                           int* tap_row, float* tap_w, float* lat, void* stream);
+int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P, float freq_factor,
+                           float* feat, int* tap_row, float* tap_w, float* lat, void* stream);
 /* adjoint of the latent interpolation: d_latent_cl[tap_row][c] += tap_w * d_lat[col][c] (atomic; caller zero-fills) */
 int diner_scatter_latent_grad_f32(const float* d_lat, const int* tap_row, const float* tap_w, long long cols,
                                   float* d_latent_cl, void* stream);
@@ -207,23 +236,6 @@ int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams*
                                   const float* viewdirs, long long P, float* out, void* workspace, void* stream);
 int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* params, const DinerMlpParams* grads,
                                    long long P, const float* d_out, void* workspace, float* d_latent_cl, void* stream);
-
-/* ---- arithmetic / kernel variant of the MLP GEMMs (process-wide switch) ------------------------
- * 0 (library default): exact fp32 MFMA (v_mfma_f32_16x16x4_f32), results within fp32 round-off of the reference.
- * 1: "f16x3" split products -- each fp32 product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on
- *    v_mfma_f32_16x16x32_f16 with fp32 accumulation and power-of-two pre-scaling (diner_amd/csrc/mlp_h3.hip);
- *    ~2^-21 relative error per product.  Weights are streamed through LDS and shared by the four waves.
- * 2: the same arithmetic (same products and accumulation order over k; the lin_z contribution is added at a different
- *    point, so results agree to fp32 round-off, not bit for bit) with the per-view part computed by the feature-sliced kernel of
- *    diner_amd/csrc/mlp_h3n.hip: every wave owns 128 output features of all 64 columns, weights go global ->
- *    registers, activations are exchanged through LDS as fp16 hi/lo operands.  The Python host selects this mode
- *    by default (diner_amd/ops.py).  Falls back to mode 1 when one projected map exceeds 4 GB.
- * 3: plain fp16 operands (the hi parts only: one MFMA per product) with fp32 accumulation, in the kernels of mode 2 --
- *    BASELINE configs[4] ("fp16 MLP on MFMA").  About 1e-3 relative on the rendered colours: outside the 1e-4 parity
- *    bar, never a default; 2x the rate of mode 2.
- * diner_mlp_forward_f32 (explicit matrices) always uses mode 0.  Returns <0 for an unknown mode. */
-int diner_set_precision(int mode);
-int diner_get_precision(void);
 
 /* ---- measurement aid (bench.py): per-kernel durations of the two field kernels ------------------
  * With profiling enabled every field call brackets k_field_pre / k_field_post with HIP events on the

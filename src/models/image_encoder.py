@@ -114,8 +114,11 @@ class SpatialEncoder(nn.Module):
     def _lookup_scene(self, sb, which):
         """HipScene holding only the map `which` needs (cameras are irrelevant for a raw uv lookup)."""
         t = {"latent": self.latent, "depth": self.depths, "std": self.depths_std, "normal": self.normals}[which]
-        key = (which, sb, t.data_ptr(), t._version, tuple(t.shape))
-        hit = self._scene_cache.get(which)
+        # one entry per (map, object).  The HipScene of the latent holds a channels-last COPY, so the entry is only valid
+        # for the tensor object it was built from: the key carries the tensor's identity and version, the entry keeps the
+        # tensor alive (its address cannot be recycled for another latent while cached), and forward() drops the cache.
+        key = (id(t), t.data_ptr(), t._version, tuple(t.shape))
+        hit = self._scene_cache.get((which, sb))
         if hit is None or hit[0] != key:
             nv = t.shape[1]
             eye = torch.eye(4).repeat(nv, 1, 1)
@@ -128,8 +131,8 @@ class SpatialEncoder(nn.Module):
                                  d if which == "std" else (d[:, :1] if d is not None else None),
                                  d if which == "normal" else (d[:, :1].expand(-1, 3, -1, -1) if d is not None else None),
                                  eye, one, one, torch.ones(2), self.feature_padding)
-            hit = (key, scene)
-            self._scene_cache[which] = hit
+            hit = (key, scene, t)
+            self._scene_cache[(which, sb)] = hit
         return hit[1]
 
     def _index(self, uv, which, mode):
@@ -163,6 +166,7 @@ class SpatialEncoder(nn.Module):
     def forward(self, imgs, depths, depths_std, normals):
         """imgs (SB,NV,3,H,W) -> stores self.latent (SB,NV,latent_size,Hf,Wf) and the depth / std / normal maps."""
         SB, NV, Cin, H, W = imgs.shape
+        self._scene_cache = {}                       # new maps: nothing cached for the previous ones may be served
         self.depths, self.depths_std, self.normals = depths, depths_std, normals
         self.nviews, self.nobjects = NV, SB
         x = self.pad_layer(imgs.view(SB * NV, Cin, H, W))
@@ -197,11 +201,3 @@ class SpatialEncoder(nn.Module):
         latents = [F.interpolate(l, size, mode=self.upsample_interp, align_corners=align) for l in latents]
         lat = torch.cat(latents, dim=1)
         self.latent = lat.view(SB, NV, -1, *lat.shape[-2:])
-
-    @classmethod
-    def from_conf(cls, conf):
-        return cls(conf.get_string("backbone"), pretrained=conf.get_bool("pretrained", True),
-                   num_layers=conf.get_int("num_layers", 4), index_interp=conf.get_string("index_interp", "bilinear"),
-                   index_padding=conf.get_string("index_padding", "border"),
-                   upsample_interp=conf.get_string("upsample_interp", "bilinear"),
-                   use_first_pool=conf.get_bool("use_first_pool", True))

@@ -46,7 +46,7 @@ class NeRFRendererDGS(torch.nn.Module):
         xyz = (r[:, None, :3] + z[..., None] * r[:, None, 3:6]).reshape(-1, 3)
         dirs = r[:, None, 3:6].expand(-1, K, -1).reshape(-1, 3)
         field = train.field_train(model.hip_scene(sb), xyz, dirs, model.encoder.latent[sb],
-                                  train.mlp_params(model.mlp_fine)).view(NR, K, 4)
+                                  train.mlp_params(model.mlp_fine), model.poscode.freq_factor).view(NR, K, 4)
         rgb, depth = train.composite_train(field, z, r, self.white_bkgd)
         w = ops.composite(field.detach(), z, r, self.white_bkgd, want_weights=True)[0] if want_weights else None
         return w, rgb, depth

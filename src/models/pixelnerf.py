@@ -66,17 +66,20 @@ class PixelNeRF(torch.nn.Module):
         """HipScene of object `sb` (channels-last latent copy etc.), rebuilt whenever any source tensor changed."""
         enc = self.encoder
         srcs = (enc.latent, enc.depths, enc.depths_std, enc.normals, self.poses, self.focal, self.c, self.image_shape)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in srcs)
+        key = tuple((id(t), t.data_ptr(), t._version, tuple(t.shape)) for t in srcs)
         hit = self._scenes.get(sb)
         if hit is None or hit[0] != key:
             scene = ops.HipScene(enc.latent[sb], enc.depths[sb], enc.depths_std[sb], enc.normals[sb], self.poses[sb],
                                  self.focal[sb], self.c[sb], self.image_shape, enc.feature_padding)
-            hit = (key, scene)
+            hit = (key, scene, srcs)       # the sources stay alive with the entry: their addresses cannot be recycled
             self._scenes[sb] = hit
         return hit[1]
 
     def hip_mlp(self):
-        return self.mlp_fine.hip_mlp()
+        """Packed ResnetFC weights; the handle also carries the positional encoding that feeds the MLP (the field kernels
+        evaluate it in registers)."""
+        pc = self.poscode
+        return self.mlp_fine.hip_mlp(num_freqs=pc.num_freqs, freq_factor=pc.freq_factor, include_input=pc.include_input)
 
     def needs_grad(self):
         """True when a call must be differentiable: grad mode and some parameter (or the encoded latent) wants a gradient."""
@@ -84,10 +87,12 @@ class PixelNeRF(torch.nn.Module):
                                             any(p.requires_grad for p in self.mlp_fine.parameters()))
 
     def _check_poscode(self):
+        """num_freqs / include_input fix d_in = 55 (the C ABI rejects anything else with DINER_E_UNSUPPORTED as well);
+        freq_factor is honoured by the kernels.  depthcode shares poscode's configuration (pixelnerf.py:15-16)."""
         pc = self.poscode
-        if pc.num_freqs != 6 or abs(pc.freq_factor - 6.28) > 1e-12 or not pc.include_input:
+        if pc.num_freqs != 6 or not pc.include_input:
             raise NotImplementedError("diner_amd: the fused field kernel is built for poscode num_freqs=6, "
-                                      "freq_factor=6.28, include_input=True (every shipped DINER config)")
+                                      "include_input=True (every shipped DINER config)")
 
     def forward(self, xyz, viewdirs):
         """(r, g, b, sigma) at world-space points: xyz (SB,B,3), viewdirs (SB,B,3) -> (SB,B,4) (:55-145)."""
@@ -99,8 +104,8 @@ class PixelNeRF(torch.nn.Module):
             # (diner_amd/train.py); gradients reach the MLP parameters and, through encoder.latent, the image encoder
             from diner_amd import train
             params = train.mlp_params(self.mlp_fine)
-            return torch.stack([train.field_train(self.hip_scene(sb), xyz[sb], viewdirs[sb], self.encoder.latent[sb], params)
-                                for sb in range(SB)])
+            return torch.stack([train.field_train(self.hip_scene(sb), xyz[sb], viewdirs[sb], self.encoder.latent[sb], params,
+                                                  self.poscode.freq_factor) for sb in range(SB)])
         self._check_poscode()
         mlp = self.hip_mlp()
         return torch.stack([ops.field_from_points(self.hip_scene(sb), mlp, xyz[sb], viewdirs[sb]) for sb in range(SB)])

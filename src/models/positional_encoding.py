@@ -33,8 +33,3 @@ class PositionalEncoding(torch.nn.Module):
                                       "path is PixelNeRF.forward / NeRFRendererDGS.forward (diner_amd/train.py)")
         assert x.shape[-1] == self.d_in
         return ops.posenc(x, self.num_freqs, self.freq_factor, self.include_input)
-
-    @classmethod
-    def from_conf(cls, conf, d_in=3):
-        return cls(conf.get_int("num_freqs", 6), d_in, conf.get_float("freq_factor", np.pi),
-                   conf.get_bool("include_input", True))

@@ -62,13 +62,17 @@ class ResnetFC(nn.Module):
             raise NotImplementedError("diner_amd: the fused MLP implements ReLU activations and average view fusion "
                                       "(the configuration of every shipped DINER config)")
 
-    def hip_mlp(self):
-        """HipMlp handle for the current parameter values (re-packed when any parameter changed)."""
+    def hip_mlp(self, num_freqs=6, freq_factor=6.28, include_input=True):
+        """HipMlp handle for the current parameter values (re-packed when any parameter changed).  The keyword arguments
+        describe the positional encoding of the 55 inputs (PixelNeRF passes its own; irrelevant for forward() on an
+        explicit matrix)."""
         self._check_supported()
         sd = {k: v for k, v in self.state_dict().items()}
-        key = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items()))
+        key = (tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items())),
+               int(num_freqs), float(freq_factor), bool(include_input))
         if self._hip is None or key != self._hip_key:
-            self._hip = ops.HipMlp(sd, combine_layer=self.combine_layer, d_latent=self.d_latent)
+            self._hip = ops.HipMlp(sd, combine_layer=self.combine_layer, d_latent=self.d_latent, num_freqs=num_freqs,
+                                   freq_factor=freq_factor, include_input=include_input)
             self._hip_key = key
         return self._hip
 
@@ -87,9 +91,3 @@ class ResnetFC(nn.Module):
             return ops.mlp_forward(mlp, zx)
         raise NotImplementedError(f"diner_amd: ResnetFC.forward supports (SB,NV,B,C)/combine_dim=1 and "
                                   f"(NV,B,C)/combine_dim=0, got shape {tuple(zx.shape)}, combine_dim={combine_dim}")
-
-    @classmethod
-    def from_conf(cls, conf, d_in, **kwargs):
-        return cls(d_in, n_blocks=conf.get_int("n_blocks", 5), d_hidden=conf.get_int("d_hidden", 128),
-                   beta=conf.get_float("beta", 0.0), combine_layer=conf.get_int("combine_layer", 1000),
-                   combine_type=conf.get_string("combine_type", "average"), **kwargs)

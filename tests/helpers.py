@@ -24,9 +24,9 @@ def load(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 
 
-def oracle_setup(W, H, seed, bg_std_zero=False):
+def oracle_setup(W, H, seed, bg_std_zero=False, **scene_kw):
     """-> (scene dict, oracle Scene, oracle MLPWeights, mlp state_dict, target rays (H*W,8))"""
-    sc = make_scene(W, H, seed=seed, bg_std_zero=bg_std_zero)
+    sc = make_scene(W, H, seed=seed, bg_std_zero=bg_std_zero, **scene_kw)
     normals = depth2normal(sc["depths"], sc["src_intrinsics"])
     sc["normals"] = normals
     K = sc["src_intrinsics"]

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libdiner_hip.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with include/diner_hip.h"
-    assert lib.diner_abi_version() == 1
+    assert lib.diner_abi_version() == 2
     assert isinstance(lib.diner_last_error(), bytes)
 
 
@@ -48,15 +48,37 @@ def test_argument_validation_without_gpu():
     rc = lib.diner_composite_f32(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 4, 1000, 0, C.c_void_p(8), C.c_void_p(8),
                                  None, None)
     assert rc == -1 and b"K" in lib.diner_last_error()
-    p = _lib.DinerMlpParams()
-    p.d_in, p.d_latent, p.d_hidden, p.d_out, p.n_blocks, p.combine_layer = 55, 512, 128, 4, 5, 3
+    # configurations outside what the kernels are built for are refused by the C ABI itself, before any device work
+    dummy = (C.c_float * 4)()
+    arr = (C.c_void_p * 5)(*[C.addressof(dummy)] * 5)
+
+    def params(**kw):
+        p = _lib.DinerMlpParams()
+        p.d_in, p.d_latent, p.d_hidden, p.d_out, p.n_blocks, p.combine_layer = 55, 512, 512, 4, 5, 3
+        p.num_freqs, p.include_input, p.freq_factor = 6, 1, 6.28
+        p.lin_in_w = p.lin_in_b = p.lin_out_w = p.lin_out_b = C.addressof(dummy)
+        for f in ("fc0_w", "fc0_b", "fc1_w", "fc1_b", "lin_z_w", "lin_z_b"):
+            setattr(p, f, C.cast(arr, C.POINTER(C.c_void_p)))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
     h = C.c_void_p()
-    rc = lib.diner_mlp_create(C.byref(p), None, C.byref(h))
-    assert rc == -2 and b"unsupported" in lib.diner_last_error()
+    for bad, word in ((dict(d_hidden=128), b"ResnetFC"), (dict(freq_factor=1000.0), b"freq_factor"),
+                      (dict(freq_factor=-6.28), b"freq_factor"), (dict(freq_factor=float("nan")), b"freq_factor"),
+                      (dict(num_freqs=10), b"num_freqs"), (dict(include_input=0), b"include_input")):
+        p = params(**bad)
+        rc = lib.diner_mlp_create(C.byref(p), None, C.byref(h))
+        assert rc == -2 and b"unsupported" in lib.diner_last_error() and word in lib.diner_last_error(), (bad, lib.diner_last_error())
+        assert not h.value
     with pytest.raises(RuntimeError, match="unsupported"):
         _lib.check(rc)
-    assert lib.diner_field_workspace_bytes(16) == 16 * 512 * 4
-    assert lib.diner_field_workspace_bytes(17) == 32 * 512 * 4          # whole 16-point tiles
+    assert lib.diner_field_workspace_bytes(16) == 16 * 512 * 4 + 256    # 2 KB / point + the overflow flag
+    assert lib.diner_field_workspace_bytes(17) == 32 * 512 * 4 + 256    # whole 16-point tiles
+    # the arithmetic mode is a per-call argument: an unknown one is an argument error, and there is no global switch
+    assert not hasattr(lib, "diner_set_precision") and not hasattr(lib, "diner_get_precision")
+    fields = dict(_lib.DinerScene._fields_)
+    assert {"poses_host", "focal_host", "c_host"} <= set(fields) and not {"poses", "focal", "c"} & set(fields)
 
 
 def test_state_dict_contract():

@@ -65,6 +65,41 @@ def test_renderer_forward_matches_reference():
     assert max_norm_rel(rgb[0].cpu(), g["rgb"]) < TOL and max_norm_rel(depth[0].cpu(), g["depth"]) < TOL
 
 
+def test_predict_image_matches_reference_image():
+    """Row a11: the image harness (gen_rays -> split into ray batches -> renderer.forward -> cat -> (SB,3,H,W), reference
+    diner.py:79-92) through the drop-in modules, against the reference's 64x64 image G8 -- rays generated on the device,
+    ragged ray batches (1000 does not divide 4096), injected noise sliced per batch, final layout permutation included."""
+    from diner_amd import noise
+    from diner_amd.render import predict_image
+    g = load("g8_render_cfg1.npz")
+    W, H, K, G, n_cand = (int(g[k]) for k in ("W", "H", "K", "G", "n_cand"))
+    sc, nerf, R, rays = setup_model(W, H, int(g["seed"]))
+    gen = torch.Generator().manual_seed(108)
+    nc = torch.rand(W * H, n_cand, generator=gen)
+    ng = torch.randn(W * H, G, generator=gen)
+    nf = torch.rand(W * H, K, generator=gen)
+    ren = R(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=False)
+    with noise.inject(nc.cuda()[None], ng.cuda()[None], nf.cuda()[None]):
+        rgb, depth = predict_image(nerf, ren, sc["target_extrinsics"][None].cuda(), sc["target_intrinsics"][None].cuda(),
+                                   W, H, sc["znear"], sc["zfar"], ray_batch_size=1000)
+    assert rgb.shape == (1, 3, H, W) and depth.shape == (1, 1, H, W)
+    # the reference's layout: rgb.view(SB, H, W, 3).permute(0, 3, 1, 2)   (diner.py:91-92)
+    want_rgb = T(g["rgb"]).view(1, H, W, 3).permute(0, 3, 1, 2)
+    want_d = T(g["depth"]).view(1, H, W, 1).permute(0, 3, 1, 2)
+    e_rgb = ((rgb.cpu() - want_rgb).abs().amax(1) / want_rgb.abs().max()).flatten()
+    e_d = ((depth.cpu() - want_d).abs()[:, 0] / want_d.abs().max()).flatten()
+    ok = (e_rgb < TOL) & (e_d < TOL)
+    mse = (rgb.cpu() - want_rgb).square().mean().item()
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+    print(f"predict_image vs G8: {int((~ok).sum())}/{W * H} pixels outside 1e-4 (erf-saturation rays), "
+          f"worst rgb {e_rgb.max().item():.2e}, PSNR {psnr:.1f} dB")
+    assert int((~ok).sum()) <= 0.005 * W * H and psnr > 55.0
+    # device-generated rays are the fixture's rays (row-major pixels, centres at +0.5)
+    from diner_amd import ops
+    r_dev = ops.gen_rays(sc["target_extrinsics"][None], sc["target_intrinsics"][None], W, H, sc["znear"], sc["zfar"], "cuda")
+    assert (r_dev[0].cpu() - T(g["rays"])).abs().max().item() <= 5e-7
+
+
 def test_pixelnerf_and_mlp_modules():
     g = load("g6_pixelnerf.npz")
     sc, nerf, R, rays = setup_model(int(g["W"]), int(g["H"]), int(g["seed"]))

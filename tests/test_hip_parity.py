@@ -28,12 +28,12 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=["f16x3", "f16x3n", "fp32"])
+@pytest.fixture(params=["f16x3", "fp32"])
 def precision(request, ops):
-    """All arithmetic modes / kernel variants of the MLP GEMMs are held to the same tolerances."""
+    """Both parity-grade arithmetic modes of the MLP GEMMs are held to the same tolerances (the mode is a per-call argument
+    of the C ABI; set_precision only changes the default of this Python host)."""
     prev = ops.get_precision()
-    ops.set_precision({"f16x3": ops.PRECISION_F16X3, "f16x3n": ops.PRECISION_F16X3_NSPLIT,
-                       "fp32": ops.PRECISION_FP32}[request.param])
+    ops.set_precision(request.param)
     yield request.param
     ops.set_precision(prev)
 
@@ -218,6 +218,180 @@ def test_render_cfg1_end_to_end(ops, precision):
     assert psnr > 55.0 and psnr_same > 90.0
 
 
+RENDER_FIXTURES = {
+    # name: (scene kwargs of diner_amd.synthetic.make_scene, max share of rays whose sample set may differ (erf-saturation
+    #        class only), PSNR floor of the whole 4096-ray image against the reference's, all rays included)
+    "g9_render_K128": (dict(), 0.02, 60.0),
+    "g10_render_cfg5": (dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape"), 0.02, 60.0),
+}
+
+
+def _render_fixture(name):
+    g = load(name + ".npz")
+    kw = RENDER_FIXTURES[name][0]
+    W, H, K, G, n_cand = (int(g[k]) for k in ("W", "H", "K", "G", "n_cand"))
+    sc, scene, w, msd, _ = oracle_setup(W, H, int(g["seed"]), **kw)
+    NR = g["rays"].shape[0]
+    gen = torch.Generator().manual_seed(int(g["noise_seed"]))
+    nc, ng, nf = torch.rand(NR, n_cand, generator=gen), torch.randn(NR, G, generator=gen), torch.rand(NR, K, generator=gen)
+    assert sha(nc[:64], ng[:64], nf[:64]) == str(g["in_sha"]), "seeded noise not reproducible on this host"
+    return g, sc, scene, msd, (K, G, n_cand, bool(int(g["white_bkgd"]))), (nc, ng, nf)
+
+
+@pytest.mark.parametrize("name", sorted(RENDER_FIXTURES))
+def test_render_at_metric_sample_counts(ops, precision, name):
+    """renderer.forward against the reference's output at the sample counts the metric uses: G9 = K=128 / G=48 on 4096
+    rays of the 400x300 bench scene (BASELINE configs[1..3]), G10 = K=192 / G=72, white background, Facescape depth range
+    and sigma law (configs[4]).  Three statements, the last one on ALL rays:
+      (1) with the reference's sample positions every ray matches to 1e-4 (field kernels + compositor; K=128 and 192 take
+          the two- / three-samples-per-lane paths of the compositor);
+      (2) with the HIP sampler every ray whose sample set agrees with the reference's matches to 1e-4, and every
+          disagreement involves only candidates of the erf-saturation class (likelihood < 1e-6, helpers.selection_diff);
+      (3) over all rays, disagreeing ones included: their share, the largest error and the PSNR of the image against the
+          reference's image are bounded explicitly."""
+    g, sc, scene, msd, (K, G, n_cand, white), (nc, ng, nf) = _render_fixture(name)
+    _, max_share, psnr_floor = RENDER_FIXTURES[name]
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    rays = T(g["rays"])
+    rc = rays.cuda()
+    NR = rays.shape[0]
+    ref_rgb, ref_d, ref_z = T(g["rgb"]), T(g["depth"]), T(g["z"])
+
+    def errs(rgb, depth):
+        return ((rgb.cpu() - ref_rgb).abs().max(-1).values / ref_rgb.abs().max(),
+                (depth.cpu() - ref_d).abs() / ref_d.abs().max())
+
+    # (1)
+    wts, rgb, depth = ops.render(hs, hm, rc, ref_z.cuda(), white, want_weights=True)
+    e_rgb, e_d = errs(rgb, depth)
+    print(f"{name} [{precision}] reference z: rgb {e_rgb.max().item():.2e} depth {e_d.max().item():.2e} (all {NR} rays)")
+    assert e_rgb.max().item() < TOL and e_d.max().item() < TOL
+    np.testing.assert_allclose(wts.cpu().sum(-1).numpy(), g["weights_sum"], atol=3e-5)
+    assert max_norm_rel(wts.cpu()[::16], g["weights_sub"]) < TOL
+    # (2)
+    z, zu = ops.sample_depthguided(hs, rc, K, n_cand, G, 0.05, noise=(nc.cuda(), ng.cuda(), nf.cuda()), want_unfilled=True)
+    same = torch.isclose(z.cpu(), ref_z, rtol=3e-6, atol=1e-7).all(-1)
+    zc = O.sample_coarse(rays, n_cand, nc)
+    L, _ = O.point_likelihood(scene, rays, zc)
+    tie_rays = set(int(r) for r in g["tie_rays"])      # exact likelihood ties at the cut-off: the reference's pick is
+    bad = (~same).nonzero().flatten().tolist()         # torch's unstable argsort order there, see make_golden_r2.py
+    worst = 0.0
+    for r in bad:           # candidates picked by one side only (fill / gaussian samples differ as a consequence)
+        if r in tie_rays:
+            continue
+        only = set(ref_z[r].tolist()) ^ set(z[r].cpu().tolist())
+        for zz in only:
+            i = (zc[r] == zz).nonzero().flatten()
+            if len(i):
+                worst = max(worst, float(L[r, i[0]]))
+    wts, rgb, depth = ops.render(hs, hm, rc, z, white, want_weights=False)
+    e_rgb, e_d = errs(rgb, depth)
+    n_diff = len(bad)
+    assert worst < SAT_L, "sample selection differs on a candidate with a well-defined likelihood"
+    assert e_rgb[same].max().item() < TOL and e_d[same].max().item() < TOL
+    # (3)
+    mse = (rgb.cpu() - ref_rgb).square().mean().item()
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+    print(f"{name} [{precision}] HIP sampler: {n_diff}/{NR} rays ({100.0 * n_diff / NR:.2f} %) with a different sample set "
+          f"(largest likelihood involved {worst:.1e}); agreeing rays rgb {e_rgb[same].max().item():.2e} depth "
+          f"{e_d[same].max().item():.2e}; ALL rays rgb {e_rgb.max().item():.2e} depth {e_d.max().item():.2e}; "
+          f"PSNR of the image against the reference's {psnr:.1f} dB")
+    assert n_diff <= max_share * NR
+    assert psnr >= psnr_floor
+    # a ray with a different pick replaces one sample of K in a region of vanishing likelihood: bounded colour change
+    assert e_rgb.max().item() < 0.05 and e_d.max().item() < 0.05
+
+
+def test_cfg5_fp16_mlp_psnr(ops):
+    """BASELINE configs[4] asks for an "fp16 MLP on MFMA" at K=192 with a white background: DINER_PRECISION_F16 on the G10
+    fixture.  Not inside the 1e-4 parity bar (stated, not hidden): the test states the PSNR of the fp16 image against the
+    reference's fp32 image.  north_star allows 0.05 dB on PSNR-vs-ground-truth; an image >= 50 dB from the reference's moves
+    a 30 dB PSNR-vs-GT by < 0.05 dB (|dPSNR| <= 20 log10(1 + 10^((30-50)/20)) = 0.83 dB worst case for fully correlated
+    errors, ~0.04 dB for uncorrelated ones)."""
+    g, sc, scene, msd, (K, G, n_cand, white), (nc, ng, nf) = _render_fixture("g10_render_cfg5")
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    rc = T(g["rays"]).cuda()
+    ref_rgb, ref_d = T(g["rgb"]), T(g["depth"])
+    out = {}
+    for mode in ("f16", "f16x3"):
+        _, rgb, depth = ops.render(hs, hm, rc, T(g["z"]).cuda(), white, precision=mode)
+        mse = (rgb.cpu() - ref_rgb).square().mean().item()
+        out[mode] = (10 * np.log10(1.0 / max(mse, 1e-30)), max_norm_rel(rgb.cpu(), ref_rgb), max_norm_rel(depth.cpu(), ref_d))
+        print(f"cfg5 K=192 white [{mode}]: PSNR vs the reference image {out[mode][0]:.1f} dB, rgb max-norm-rel "
+              f"{out[mode][1]:.2e}, depth {out[mode][2]:.2e}")
+    assert out["f16"][0] >= 50.0 and out["f16"][1] < 1e-2
+    assert out["f16x3"][0] >= 90.0 and out["f16x3"][1] < TOL
+
+
+def test_fp16_overflow_falls_back_to_exact_kernels(ops):
+    """Activations beyond the fp16 range (a checkpoint with large hidden values): the fp16-operand kernels raise a device
+    flag and the gated exact-fp32 pass recomputes the launch -- no inf / NaN, no host synchronisation; the result is the
+    fp32 mode's, bit for bit.  Weights beyond the range the x16 fp16 split supports select the exact kernels up front."""
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    hs = hip_scene(ops, sc)
+    pts, dirs = T(g["pts"]).cuda(), T(g["dirs"]).cuda()
+    big = {k: v.clone() for k, v in msd.items()}
+    big["lin_in.bias"] = big["lin_in.bias"] + 3.0e5 * (torch.arange(512) % 7 == 0)       # hidden activations ~3e5 > 65504
+    hm = hip_mlp(ops, big)
+    assert hm.h3_ok                                   # the weights themselves are in range (|w| < 1024): bias 3e5 is not
+    hm2 = hip_mlp(ops, {k: (v * 1.0) for k, v in msd.items()})
+    exact = ops.field_from_points(hs, hm, pts, dirs, precision="fp32")
+    for mode in ("f16x3", "f16"):
+        got = ops.field_from_points(hs, hm, pts, dirs, precision=mode)
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, exact), mode
+    # in-range network: the flag stays down and the fp16-operand result is NOT the fp32 one bit for bit (different arithmetic)
+    a, b = ops.field_from_points(hs, hm2, pts, dirs, precision="f16x3"), ops.field_from_points(hs, hm2, pts, dirs, precision="fp32")
+    assert max_norm_rel(a.cpu(), b.cpu()) < TOL_STAGE and not torch.equal(a, b)
+
+
+def test_freq_factor_is_honoured(ops, precision):
+    """PositionalEncoding.freq_factor travels with the packed-weights handle into the field kernels (it used to be a
+    hard-coded 6.28): a network evaluated with freq_factor = 3.14 matches the oracle run with 3.14."""
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    hs = hip_scene(ops, sc)
+    hm = ops.HipMlp({k: v.cuda() for k, v in msd.items()}, freq_factor=3.14)
+    pts, dirs = T(g["pts"]), T(g["dirs"])
+    want = O.mlp_forward(w, O.mlp_input(scene, pts, dirs, 6, 3.14))
+    want = torch.cat((torch.sigmoid(want[:, :3]), torch.relu(want[:, 3:])), -1)
+    got = ops.field_from_points(hs, hm, pts.cuda(), dirs.cuda()).cpu()
+    assert max_norm_rel(got, want) < TOL_STAGE
+    assert max_norm_rel(got, g["out"]) > 1e-2          # and it is not the 6.28 result
+
+
+def test_helpers_against_reference_fixture(ops):
+    """Rows f2 / f3 against outputs of the reference's OWN functions (oracle/make_golden_r2.py, G11): torch_cmap
+    (torch_helpers.py:42-75), depth2normal on maps with holes (depth2normal.py:7-87), gen_rays (cam_geometry.py:5-48)."""
+    from diner_amd import imageio
+    g = load("g11_helpers.npz")
+    # depth colour map: the reference returns float64 colours; its 8-bit image (save_image) is what gets written
+    depth = T(g["cmap_depth"])
+    for tag, (vmin, vmax) in dict(auto=(None, None), fixed=(0.25, 1.75), hi=(None, 2.0)).items():
+        want = (T(g["cmap_" + tag]) * 255 + 0.5).clamp(0, 255).to(torch.uint8)                 # (2,3,H,W)
+        for b in range(2):
+            # vmin / vmax None: per-image min / max, computed on the device like torch_cmap does per batch element
+            got = imageio.depth_to_uint8(depth[b].cuda(), vmin=vmin, vmax=vmax).cpu()          # (H,W,3)
+            assert torch.equal(got, want[b].permute(1, 2, 0)), (tag, b)
+    # depth2normal
+    for dm, Km, want in ((T(g["d2n_depth"]), T(g["d2n_K"]), T(g["d2n_normals"])),):
+        got = ops.depth2normal(dm.cuda(), Km.cuda()).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        fin = ~torch.isnan(want)
+        assert (got[fin] - want[fin]).abs().max().item() <= 2e-6
+    sc = oracle_setup(48, 40, int(g["d2n_scene_seed"]))[0]
+    got = ops.depth2normal(sc["depths"].cuda(), sc["src_intrinsics"].cuda()).cpu()
+    want = T(g["d2n_scene_normals"])
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert (got[~torch.isnan(want)] - want[~torch.isnan(want)]).abs().max().item() <= 2e-6
+    # gen_rays
+    W, H = int(g["rays_W"]), int(g["rays_H"])
+    got = ops.gen_rays(T(g["rays_E"]), T(g["rays_K"]), W, H, T(g["rays_near"]), T(g["rays_far"]), "cuda").cpu()
+    want = T(g["rays"]).view(3, H * W, 8)
+    assert (got - want).abs().max().item() <= 5e-7 and torch.equal(got[..., 6:], want[..., 6:])
+
+
 def test_ray_batch_split_invariance(ops, precision):
     """diner.py:85 splits rays into batches; results must not depend on the split (bit-exact)."""
     sc, scene, w, msd, rays = oracle_setup(32, 32, 3)
@@ -388,7 +562,7 @@ def test_edge_cases_empty_ragged_and_limits(ops, precision):
 
 
 def test_plain_fp16_mode_accuracy(ops):
-    """diner_set_precision(3): plain fp16 operands, fp32 accumulation (BASELINE configs[4], "fp16 MLP on MFMA").  This mode
+    """DINER_PRECISION_F16: plain fp16 operands, fp32 accumulation (BASELINE configs[4], "fp16 MLP on MFMA").  This mode
     is NOT inside the 1e-4 parity bar and is never the default; the test states what it delivers: max-norm relative
     error below 5e-3 on PixelNeRF.forward and on the end-to-end render with the reference's sample positions."""
     prev = ops.get_precision()

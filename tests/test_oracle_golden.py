@@ -1,6 +1,7 @@
 """CPU: the oracle restatement reproduces the golden vectors generated from the imported reference
 (oracle/make_golden.py).  Bit-exact where the reference-vs-oracle pin was bit-exact."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import diner_oracle as O
@@ -127,3 +128,23 @@ def test_g8_render_cfg1_subset():
     assert max_norm_rel(o["rgb"][same], T(g["rgb"])[sub][same]) < 1e-4
     assert max_norm_rel(o["depth"][same], T(g["depth"])[sub][same]) < 1e-4
     np.testing.assert_allclose(o["weights"].sum(-1).numpy()[same.numpy()], g["weights_sum"][sub][same.numpy()], atol=2e-5)
+
+
+@pytest.mark.parametrize("name,kw", [("g9_render_K128", dict()),
+                                     ("g10_render_cfg5", dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape"))])
+def test_g9_g10_render_at_metric_sample_counts_subset(name, kw):
+    """The oracle against the reference's renderer.forward at the sample counts the metric uses (K=128 / 48 gaussian on
+    the bench scene; K=192 / 72 gaussian, white background, Facescape range), on every 64th fixture ray."""
+    g = load(name + ".npz")
+    W, H, K, G, n_cand = (int(g[k]) for k in ("W", "H", "K", "G", "n_cand"))
+    sc, scene, w, msd, _ = oracle_setup(W, H, int(g["seed"]), **kw)
+    NR = g["rays"].shape[0]
+    gen = torch.Generator().manual_seed(int(g["noise_seed"]))
+    nc, ng, nf = torch.rand(NR, n_cand, generator=gen), torch.randn(NR, G, generator=gen), torch.rand(NR, K, generator=gen)
+    assert sha(nc[:64], ng[:64], nf[:64]) == str(g["in_sha"])
+    sub = slice(0, NR, 64)
+    o = O.render(scene, w, T(g["rays"])[sub].contiguous(), K, n_cand, G, bool(int(g["white_bkgd"])), nc[sub], ng[sub], nf[sub])
+    same = torch.isclose(o["z"], T(g["z"])[sub], rtol=3e-6, atol=1e-7).all(-1)
+    assert (~same).sum() <= 1, "sampler + fill must reproduce the reference's z (erf-saturation ties aside)"
+    assert max_norm_rel(o["rgb"][same], T(g["rgb"])[sub][same]) < 1e-4
+    assert max_norm_rel(o["depth"][same], T(g["depth"])[sub][same]) < 1e-4
