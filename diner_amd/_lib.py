@@ -94,6 +94,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: the HIP extension is not built. "
                           f"Run `python -m diner_amd.build` (needs hipcc). There is no CPU fallback.")
+    # libdiner_hip.so links against libamdhip64.so.7.  PyTorch bundles its own copy of the HIP runtime; if this library were
+    # loaded first the dynamic linker would bring in /opt/rocm's copy as a SECOND runtime next to PyTorch's, and the second
+    # one finds no device (measured: tools/diag_loadorder.py).  Importing torch first makes both share PyTorch's runtime --
+    # the one that owns the memory and streams the C ABI is handed.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

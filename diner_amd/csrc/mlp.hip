@@ -721,8 +721,7 @@ static int mlp_pack(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& i
     hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, stream, W, (long long)rows * cols, im.wmax_dev);
   };
   auto bias = [&](const float* b, int n, int n_pad, float* dst) {
-    hipLaunchKernelGGL(k_copy_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, dst);
-    hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, stream, b, (long long)n, im.wmax_dev);
+    hipLaunchKernelGGL(k_copy_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, dst);   // (biases stay fp32 in every mode)
   };
   float* wp = im.w_pre;
   pack(p->lin_in_w, kHidden, kDIn, 1, wp);

@@ -82,7 +82,7 @@ const char* diner_last_error(void);
  * DINER_E_UNSUPPORTED before any device work.  A failed call leaves no allocation behind. */
 int diner_mlp_create(const DinerMlpParams* p, void* stream, DinerMlp** out);
 int diner_mlp_destroy(DinerMlp* mlp);
-/* Largest |weight| / |bias| over all parameters, reduced on the device at pack time (one 4-byte read back, after a
+/* Largest |weight| over all weight matrices (biases stay fp32 in every mode), reduced on the device at pack time (one 4-byte read back, after a
  * stream synchronise): DINER_PRECISION_F16X3 / _F16 carry the weights x16 as fp16 and need it below 1024.
  * Returns 1 when the f16 modes may be used with this handle, 0 when not, <0 on error; *max_abs (optional) receives the value. */
 int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs);

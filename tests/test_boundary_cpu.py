@@ -188,7 +188,9 @@ def test_bench_line_contract():
     driver's contract, the roofline object and the CPU baseline object."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r01_v8_bench_line_with_cpu_baseline.json")) as f:
+    import glob
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r02*_bench_line_with_cpu_baseline.json")))[-1]
+    with open(newest) as f:
         line = json.loads(f.read())
     with open(os.path.join(root, "BASELINE.json")) as f:
         base = json.load(f)
@@ -196,9 +198,12 @@ def test_bench_line_contract():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["metric"].split(" at ")[0] in base["metric"] and line["unit"] == "rays/s"
-    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["higher_is_better"] is True and line["scaling"] == "strong" and line["vs_baseline"] is None
     assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
-    assert "configs[1]" in line["config"]["workload"]
+    # the headline line is the north_star configuration: one 800x600 frame of 480,000 rays per step, 128 samples per ray
+    assert "north_star" in line["config"]["workload"] and line["config"]["frame"] == "800x600"
+    assert line["config"]["rays_per_step"] == 480000 and line["config"]["samples_per_ray"] == 128
+    assert "fp32" in line["modes"] and line["modes"]["fp32"]["rays_per_s"] > 0
     r = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -208,8 +213,9 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["unit"] == "rays/s" and c["cores"] >= 1
-    assert abs(line["value"] - line["config"]["rays_per_step_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) \
-        < 0.01 * line["value"]
+    assert abs(line["value"] - line["config"]["rays_per_step"] / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+    # CPU baseline as SURVEY.md section 8d specifies it: >= 4096 rays, warm-up at size, >= 3 timed repeats, threads stated
+    assert len(c["repeats_s"]) >= 3 and "4096 rays" in c["sample"] and c["host_threads"] >= c["cores"]
 
 
 def test_png_writer_roundtrip(tmp_path):

@@ -58,7 +58,8 @@ def test_g3_sampler_and_fill():
         assert torch.all(z[:, 1:] >= z[:, :-1])
         if not torch.equal(z0, T(g["z_unfilled"])):
             # a host whose erf kernel differs from the pinning host's in the last bit (see selection_diff)
-            bad, worst = selection_diff(T(g["z_unfilled"]).sort(-1).values, z0.sort(-1).values, aux["L"], aux["z_cand"])
+            bad, worst = selection_diff(T(g["z_unfilled"]).sort(-1).values, z0.sort(-1).values, aux["L"], aux["z_cand"],
+                                        K - int(g["G"]))
             assert worst < SAT_L and len(bad) <= 0.02 * 512
             good = torch.ones(512, dtype=torch.bool)
             good[bad] = False
