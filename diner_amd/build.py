@@ -20,6 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-comment"]
 
 
+# per-source additions: beside MFMAs packed fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32, which -O3's SLP vectoriser forms from
+# adjacent scalar operations) are an anti-lever (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+EXTRA_FLAGS = {}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -33,6 +38,7 @@ def _digest(paths):
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -44,7 +50,7 @@ def build_variant(name, defines, verbose=False):
     objs = []
     for src in SOURCES:
         op = os.path.join(obj_dir, src + ".o")
-        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", op]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-D" + d for d in defines] + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", op]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -66,7 +72,7 @@ def build(force=False, verbose=False):
         stamp = op + ".sha"
         dig = _digest([sp] + deps)
         if force or not os.path.exists(op) or not os.path.exists(stamp) or open(stamp).read() != dig:
-            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", sp, "-o", op]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
