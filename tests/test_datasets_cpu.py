@@ -1,0 +1,64 @@
+"""CPU: batch-dict assembly from the on-disk DTU layout (row f4) against the sample dict the reference's OWN DTUDataSet produced for
+the tiny tree under tests/golden/dtu_tiny (oracle/make_golden_dtu.py ran it in the build container; it asserts bit-identity there)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLD, load
+
+TREE = os.path.join(GOLD, "dtu_tiny")
+
+
+def _dataset():
+    from diner_amd.datasets import DTUSamples
+    return DTUSamples(TREE, "val", scan_list=os.path.join(TREE, "scan_list.txt"))
+
+
+def test_dtu_sample_matches_reference_dataset():
+    g = load("g13_dtu_sample.npz")
+    ds = _dataset()
+    assert len(ds) == int(g["n"]) == 2 * 36 * 7
+    assert abs(ds.znear - float(g["znear"])) < 1e-12 and abs(ds.zfar - float(g["zfar"])) < 1e-12
+    s = ds[int(g["idx"])]
+    try:
+        import PIL  # noqa: F401
+        have_pil = True
+    except ImportError:
+        have_pil = False
+    for k in g.files:
+        if k in ("idx", "n", "znear", "zfar"):
+            continue
+        want = g[k]
+        if torch.is_tensor(s[k]):
+            got = s[k].numpy()
+            assert got.shape == want.shape and got.dtype == want.dtype, k
+            if k in ("target_rgb", "src_rgbs") and not have_pil:
+                assert np.abs(got - want).max() < 0.1          # 2x2 average instead of PIL's bicubic resampler
+            else:
+                assert np.array_equal(got, want), k
+        else:
+            assert str(s[k]) == str(want), k
+    # depth holes carry through: mask 0 and depth 0 in the same places, std map from the confidence law
+    assert torch.equal(s["src_alphas"] == 0, s["src_depths"] == 0) and (s["src_alphas"] == 0).any()
+    assert float(s["src_depth_stds"].max()) <= 3.2818e-2 + 1e-6
+
+
+def test_collate_and_encode_args():
+    from diner_amd.datasets import collate, encode_args
+    ds = _dataset()
+    b = collate([ds[17], ds[24]])
+    assert b["src_rgbs"].shape == (2, 4, 3, 256, 320) and b["target_extrinsics"].shape == (2, 4, 4)
+    assert b["sample_name"] == ["scan_tiny-2", "scan_tiny-3"]
+    a = encode_args(b)
+    assert set(a) == {"images", "depths", "depths_std", "extrinsics", "intrinsics"}
+    assert a["depths"].shape == (2, 4, 1, 256, 320) and a["intrinsics"].shape == (2, 4, 3, 3)
+    sweep = ds.get_cam_sweep_extrinsics(5)
+    assert sweep.shape == (5, 4, 4) and torch.isfinite(sweep).all()
+
+
+def test_missing_tree_is_an_error(tmp_path):
+    from diner_amd.datasets import DTUSamples
+    with pytest.raises(FileNotFoundError):
+        DTUSamples(str(tmp_path / "nope"), "val", scan_list=["x"])
