@@ -48,9 +48,9 @@ def test_dtu_sample_matches_reference_dataset():
 def test_collate_and_encode_args():
     from diner_amd.datasets import collate, encode_args
     ds = _dataset()
-    b = collate([ds[17], ds[24]])
+    b = collate([ds[17], ds[(1 * 36 + 2) * 7 + 3]])          # the tree holds the files of one (camera, light) only: both list entries
     assert b["src_rgbs"].shape == (2, 4, 3, 256, 320) and b["target_extrinsics"].shape == (2, 4, 4)
-    assert b["sample_name"] == ["scan_tiny-2", "scan_tiny-3"]
+    assert b["sample_name"] == ["scan_tiny-2", "scan_tiny-2"]
     a = encode_args(b)
     assert set(a) == {"images", "depths", "depths_std", "extrinsics", "intrinsics"}
     assert a["depths"].shape == (2, 4, 1, 256, 320) and a["intrinsics"].shape == (2, 4, 3, 3)
