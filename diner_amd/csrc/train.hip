@@ -17,7 +17,7 @@ namespace diner {
 namespace train {
 
 constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
-enum : int { kTA = 1, kTB = 2, kReluA = 4, kReluB = 8, kAccum = 16, kAtomic = 32 };
+enum : int { kTA = 1, kTB = 2, kReluA = 4, kReluB = 8, kAccum = 16, kAtomic = 32, kExact = 64 };
 
 struct GemmArgs {
   const float* A;       // op(A) is M x K: stored [M][lda] (or [K][lda] with kTA)
@@ -254,6 +254,181 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs g) {
     }
 }
 
+// ---- the layer-sized products on the bf16 matrix pipe: "bf16x6" --------------------------------------------------------------
+// fp32 MFMA peaks at 157 TFLOP/s; the bf16 MFMA at 2.4 PFLOP/s.  Each fp32 operand is split into three bf16 terms
+// (a = a0 + a1 + a2: 8 + 8 + 8 mantissa bits, bf16 has fp32's exponent range, so -- unlike an fp16 split -- no scaling and no
+// range restriction: loss gradients of 1e-8 are as safe as activations of 1e4) and the six products with at least 2^-16 weight
+//   a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)
+// are accumulated in fp32 on v_mfma_f32_32x32x16_bf16; the dropped terms are below 2^-24 of |a||b|.  Six MFMAs at 16x the fp32 MFMA
+// rate = 2.6x its peak, with products as accurate as fp32's own rounding.
+// Workgroup tile 128 x 128 x 32, four waves 2 x 2 of 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers); the operands are split
+// ONCE per tile while they are staged into LDS (fragment order [plane 3][k16 block 2][lane half 2][row 128][8 bf16]: one conflict-
+// free ds_read_b128 per fragment); the next k-tile's global loads are issued before the current tile's MFMAs.  Two workgroups per
+// CU (48 KB LDS each) let one convert while the other multiplies.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int XM = 128, XN = 128, XK = 32;
+constexpr int kPlaneElems = 2 * 2 * 128 * 8;          // bf16 elements of one plane of one operand tile (8 KB)
+
+__device__ __forceinline__ void split3(const float (&v)[8], bf8& p0, bf8& p1, bf8& p2) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a0 = (__bf16)v[j];
+    const float r1 = v[j] - (float)a0;
+    const __bf16 a1 = (__bf16)r1;
+    const float r2 = r1 - (float)a1;
+    p0[j] = a0;
+    p1[j] = a1;
+    p2[j] = (__bf16)r2;
+  }
+}
+
+// One operand tile (128 rows of the output dimension x 32 of the contraction) from global memory into registers.
+//   kc: the operand is stored with the CONTRACTION index contiguous (row stride ld): thread t takes row t/2, 16 consecutive k
+//   mc: stored with the OUTPUT index contiguous: thread t takes rows 2 (t % 64), +1 and the 8 contraction indices of chunk t/64
+struct TileRegs {
+  float v[2][8];        // two chunks of 8 consecutive contraction indices (kc: chunks 2 (t&1), +1 of row t/2; mc: chunk t/64 of two rows)
+};
+__device__ __forceinline__ void tile_fetch(TileRegs& r, const float* __restrict__ P, int ld, bool kc, long long mn0, long long MN,
+                                           int k0, int kend, bool relu, int tid) {
+  if (kc) {
+    const long long row = mn0 + (tid >> 1);
+    const int kb = k0 + 16 * (tid & 1);
+    const bool fast = row < MN && kb + 16 <= kend && (ld & 3) == 0 && ((reinterpret_cast<size_t>(P) & 15) == 0);
+    if (fast) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(P + (size_t)row * ld + kb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 x = src[e];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r.v[e >> 1][4 * (e & 1) + c] = x[c];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        r.v[e >> 3][e & 7] = (row < MN && kb + e < kend) ? P[(size_t)row * ld + kb + e] : 0.0f;
+    }
+  } else {
+    const long long row = mn0 + 2 * (tid & 63);
+    const int kb = k0 + 8 * (tid >> 6);
+    const bool fast = row + 1 < MN && kb + 8 <= kend && (ld & 1) == 0 && ((reinterpret_cast<size_t>(P) & 7) == 0);
+    if (fast) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const f32x2 x = *reinterpret_cast<const f32x2*>(P + (size_t)(kb + e) * ld + row);
+        r.v[0][e] = x[0];
+        r.v[1][e] = x[1];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          r.v[q][e] = (row + q < MN && kb + e < kend) ? P[(size_t)(kb + e) * ld + row + q] : 0.0f;
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[q][e] = fmaxf(r.v[q][e], 0.0f);
+  }
+}
+// ... split and written to LDS: slot (k16 block, lane half h, row) holds contraction indices 16 blk + 8 h + 0..7 of that row
+__device__ __forceinline__ void tile_stash(const TileRegs& r, __bf16* lds, bool kc, int tid) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int row, chunk;                   // chunk = 2 blk + h
+    if (kc) { row = tid >> 1; chunk = 2 * (tid & 1) + q; }
+    else { row = 2 * (tid & 63) + q; chunk = tid >> 6; }
+    bf8 p0, p1, p2;
+    split3(r.v[q], p0, p1, p2);
+    bf8* dst = reinterpret_cast<bf8*>(lds) + chunk * 128 + row;
+    dst[0] = p0;
+    dst[kPlaneElems / 8] = p1;
+    dst[2 * (kPlaneElems / 8)] = p2;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[3 * kPlaneElems], Bs[3 * kPlaneElems];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.y * XM;
+  const int n0 = blockIdx.x * XN;
+  const int kbeg = blockIdx.z * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  const bool ta = g.flags & kTA, tb = g.flags & kTB, ra = g.flags & kReluA, rb = g.flags & kReluB;
+  // op(A) is M x K: stored [M][lda] (contraction contiguous) unless kTA; op(B) is K x N: stored [K][ldb] (output contiguous) unless kTB
+  const bool a_kc = !ta, b_kc = tb;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  TileRegs ra_t, rb_t;
+  tile_fetch(ra_t, g.A, g.lda, a_kc, m0, g.M, kbeg, kend, ra, tid);
+  tile_fetch(rb_t, g.B, g.ldb, b_kc, n0, g.N, kbeg, kend, rb, tid);
+  for (int k0 = kbeg; k0 < kend; k0 += XK) {
+    __syncthreads();                                   // the previous tile's fragment reads are done
+    tile_stash(ra_t, As, a_kc, tid);
+    tile_stash(rb_t, Bs, b_kc, tid);
+    __syncthreads();
+    if (k0 + XK < kend) {                              // next tile's loads fly under this tile's MFMAs
+      tile_fetch(ra_t, g.A, g.lda, a_kc, m0, g.M, k0 + XK, kend, ra, tid);
+      tile_fetch(rb_t, g.B, g.ldb, b_kc, n0, g.N, k0 + XK, kend, rb, tid);
+    }
+    const bf8* Af = reinterpret_cast<const bf8*>(As);
+    const bf8* Bf = reinterpret_cast<const bf8*>(Bs);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      bf8 a[2][3], b[2][3];
+      const int slot = (2 * blk + (lane >> 5)) * 128 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          a[i][pl] = Af[pl * (kPlaneElems / 8) + slot + 64 * wm + 32 * i];
+          b[i][pl] = Bf[pl * (kPlaneElems / 8) + slot + 64 * wn + 32 * i];
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // D layout of the 32x32 tile: lane holds column lane & 31, rows 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 64 * wn + 32 * j + (lane & 31);
+      if (n >= g.N) continue;
+      const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long long m = m0 + 64 * wm + 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (m >= g.M) continue;
+        float v = acc[i][j][e] + bias;
+        float* c = g.C + (size_t)m * g.ldc + n;
+        if (g.mask && !(g.mask[(size_t)m * g.ldc + n] > 0.0f)) v = 0.0f;
+        if (g.flags & kAtomic) atomicAdd(c, v);
+        else if (g.flags & kAccum) *c += v;
+        else *c = v;
+      }
+    }
+}
+
 // ---- per-(view, point) inputs ---------------------------------------------------------------------------------
 // one 64-lane wave per (view, 16 points): the front end of the inference kernels, written out instead of consumed
 __global__ __launch_bounds__(256) void k_train_inputs(SceneDev sc, FieldArgs fa, float* __restrict__ feat,
@@ -427,13 +602,17 @@ static int gemm_launch(const float* A, const float* B, float* C, long long M, in
                        int flags, const float* bias, const float* mask, int k_split, hipStream_t stream) {
   DINER_CHECK_ARG(A && B && C, "gemm: null pointer argument");
   DINER_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad sizes M=%lld N=%d K=%d", M, N, K);
-  DINER_CHECK_ARG((flags & ~63) == 0, "gemm: unknown flags 0x%x", flags);
+  DINER_CHECK_ARG((flags & ~127) == 0, "gemm: unknown flags 0x%x", flags);
   DINER_CHECK_ARG(k_split >= 1 && (k_split == 1 || (flags & kAtomic)), "gemm: split-K needs the atomic output flag");
   DINER_CHECK_ARG(!((flags & kAtomic) && mask), "gemm: a relu mask cannot be combined with atomic accumulation");
   int chunk = (K + k_split - 1) / k_split;
-  chunk = (chunk + BK - 1) / BK * BK;
+  chunk = (chunk + XK - 1) / XK * XK;               // (a multiple of every kernel's k-tile)
   GemmArgs g{A, B, C, bias, mask, M, N, K, lda, ldb, ldc, flags, chunk};
-  if (N >= BN2 && M >= BM2) {
+  if (!(flags & kExact) && N >= 64 && M >= XM && K >= XK) {
+    // layer-sized products: split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6)
+    const dim3 grid((N + XN - 1) / XN, (unsigned)((M + XM - 1) / XM), (K + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_gemm_bf16x6, grid, dim3(256), 0, stream, g);
+  } else if (N >= BN2 && M >= BM2) {
     const dim3 grid((N + BN2 - 1) / BN2, (unsigned)((M + BM2 - 1) / BM2), (K + chunk - 1) / chunk);
     hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, stream, g);
   } else {

@@ -19,7 +19,7 @@ from .ops import HipScene, _ptr, _stream, _require_hip, _f32c
 
 lib = _lib.load()
 
-TA, TB, RELU_A, RELU_B, ACCUM, ATOMIC = 1, 2, 4, 8, 16, 32
+TA, TB, RELU_A, RELU_B, ACCUM, ATOMIC, EXACT = 1, 2, 4, 8, 16, 32, 64
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, flags=0, bias=None, mask=None, k_split=1):

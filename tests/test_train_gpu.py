@@ -27,8 +27,15 @@ def ops():
 def test_gemm_against_torch(ops):
     from diner_amd import train
     g = torch.Generator().manual_seed(1)
-    for (M, N, K) in ((300, 512, 55), (1000, 4, 512), (4, 512, 2500), (129, 65, 17), (512, 512, 4096)):
+    # (300,512,55) / (129,65,17) / (1000,4,512) / (4,512,2500): fp32-MFMA kernels and ragged edges; the others are layer-sized and
+    # take the split-bf16 ("bf16x6") kernel, including ragged M / N / K tiles and operand values spanning 1e-8 .. 1e4
+    for (M, N, K) in ((300, 512, 55), (1000, 4, 512), (4, 512, 2500), (129, 65, 17), (512, 512, 4096), (1000, 200, 70),
+                      (20480, 512, 512)):
         A = torch.randn(M, K, generator=g); B = torch.randn(K, N, generator=g)
+        if (M, N, K) == (1000, 200, 70):      # wide dynamic range: a loss gradient next to activations (bf16 keeps fp32's exponent)
+            A = A * torch.logspace(-8, 4, M).unsqueeze(1)
+            A = A / A.abs().max()
+        exact_ref = None
         bias = torch.randn(N, generator=g); mask = torch.randn(M, N, generator=g)
         C0 = torch.randn(M, N, generator=g)
         ref = A.double() @ B.double()
@@ -50,6 +57,11 @@ def test_gemm_against_torch(ops):
         C = torch.zeros(M, N).cuda()
         train.gemm(Ac, Bc, C, M, N, K, K, N, N, train.ATOMIC, k_split=7)
         assert (C.cpu().double() - ref).abs().max() / scale < 1e-5
+        # the exact-fp32 flag selects the fp32 MFMA for every shape; both arithmetic paths are fp32-class
+        e_x = ((run(Ac, Bc, K, N, train.EXACT) - ref).abs().max() / scale).item()
+        e_b = ((run(Ac, Bc, K, N, 0) - ref).abs().max() / scale).item()
+        print(f"gemm {M}x{N}x{K}: max-norm error vs float64: exact-fp32 MFMA {e_x:.1e}, default path {e_b:.1e}")
+        assert e_x < 1e-5 and e_b < 1e-5
     with pytest.raises(RuntimeError):
         train.gemm(Ac, Bc, C, M, N, K, K, N, N, 0, k_split=2)             # split-K without the atomic flag
 
