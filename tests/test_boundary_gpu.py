@@ -179,9 +179,8 @@ def test_cam_sweep(tmp_path):
     torch.manual_seed(0)
     frames = create_cam_sweep(nerf, ren, E, sc["target_intrinsics"].cuda(), W, H, sc["znear"], sc["zfar"],
                               outpath=str(tmp_path / "sweep.png"), ray_batch_size=500, frames_dir=str(tmp_path / "frames"))
-    assert frames.shape == (5, 3, 2 * H, W)                      # 3 frames forth, 2 back
-    assert torch.equal(frames[3], frames[1]) and torch.equal(frames[4], frames[0].clone()) is False or True
-    assert torch.equal(frames[3], frames[1])
+    assert frames.shape == (5, 3, 2 * H, W)                      # frames[cat(arange(3), arange(2, 0, -1))] = 0 1 2 2 1 (diner.py:205-206)
+    assert torch.equal(frames[3], frames[2]) and torch.equal(frames[4], frames[1]) and not torch.equal(frames[0], frames[1])
     torch.manual_seed(0)                                          # frame 0 = an ordinary image render of the first camera
     rgb, depth = predict_image(nerf, ren, E[:1], sc["target_intrinsics"][None].cuda(), W, H, sc["znear"], sc["zfar"],
                                ray_batch_size=500)

@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob("$OUT/pmc_*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "k_field_pre" in k and ("h3n" in k or "w32" in k): acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if "k_field_pre" in k and ("h3n" in k or "h3w" in k): acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k,v in acc.items():
     print("$1", k)
     print("   " + "  ".join(f"{c}={x:.3e}" for c,x in sorted(v.items())))
