@@ -135,7 +135,7 @@ def main():
         rays = ops.gen_rays(tgt_E, tgt_K, W, H, sc["znear"], sc["zfar"], dev, ray0=lo, n_rays=hi - lo)[0]
         for r0 in range(0, hi - lo, args.ray_batch):
             r = rays[r0:r0 + args.ray_batch]
-            z = ops.sample_depthguided(scene, r, K, n_cand, G, 0.05, noise=None, seed=seed * 1000003 + lo + r0)
+            z = ops.sample_depthguided(scene, r, K, n_cand, G, 0.05, noise=None, seed=seed, ray_index0=lo + r0)   # one key per frame
             _, rgb, depth = ops.render(scene, mlp, r, z, white_bkgd=white, want_weights=False, precision=precision)
             out[r0:r0 + args.ray_batch, :3] = rgb
             out[r0:r0 + args.ray_batch, 3] = depth

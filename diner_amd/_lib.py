@@ -35,8 +35,8 @@ SIGNATURES = {
     "diner_mlp_weights_fit_f16x3": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "diner_sample_depthguided_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "diner_fill_uniform_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
+                                               C.c_uint64, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_fill_uniform_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_longlong,
                                          C.c_void_p, C.c_void_p]),
     "diner_scene_proj_bytes": (C.c_size_t, [C.POINTER(DinerScene)]),
     "diner_scene_prepare_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p]),

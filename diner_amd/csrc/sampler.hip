@@ -30,6 +30,7 @@ struct SamplerArgs {
   float* z_out;
   float* z_unfilled;
   uint64_t seed;
+  uint32_t ray_key0;       // index of rays[0] in the caller's ray list: the in-kernel noise of ray i is keyed by ray_key0 + i
   int NR, n_cand, K, G;
   float depth_diff_max;
 };
@@ -104,7 +105,7 @@ __device__ __forceinline__ void fill_and_sort(float* s, int K, int n2, float nea
     const float step = __fdiv_rn(__fsub_rn(far, near), (float)m);             // :388
     for (int j = lane; j < K; j += kWave) {
       if (s[j] == 0.0f) {
-        const float u = noise_row ? noise_row[j] : rng_uniform(seed, 2u, (uint32_t)ray, (uint32_t)j);
+        const float u = noise_row ? noise_row[j] : rng_uniform(seed, 2u, (uint32_t)ray, (uint32_t)j);      // (`ray` here: the noise key of the ray)
         float z = __fadd_rn(near, __fmul_rn((float)j, step));                 // :389
         z = __fadd_rn(z, __fmul_rn(u, step));                                 // :390
         s[j] = z;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kRaysPerBlock* kWave) void k_sample_depthguided(Sce
     float lk = 0.0f, z = 0.0f;
     if (i < n_cand) {
       const float un = a.noise_coarse ? a.noise_coarse[(size_t)ray * n_cand + i]
-                                      : rng_uniform(a.seed, 0u, (uint32_t)ray, (uint32_t)i);
+                                      : rng_uniform(a.seed, 0u, a.ray_key0 + (uint32_t)ray, (uint32_t)i);
       const float t = __fadd_rn(a.t_base[i], __fmul_rn(un, jitter));            // :57
       z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));    // :60
       const float px = __fadd_rn(ox, __fmul_rn(z, dx));                         // :96
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(kRaysPerBlock* kWave) void k_sample_depthguided(Sce
     float zg = 0.0f;
     if (has_surface) {
       const float n = a.noise_gauss ? a.noise_gauss[(size_t)ray * G + g]
-                                    : rng_normal(a.seed, 1u, (uint32_t)ray, (uint32_t)g);
+                                    : rng_normal(a.seed, 1u, a.ray_key0 + (uint32_t)ray, (uint32_t)g);
       zg = __fadd_rn(__fmul_rn(n, sd), mean);                                    // :188
     }
     S[want + g] = zg;
@@ -269,14 +270,14 @@ __global__ __launch_bounds__(kRaysPerBlock* kWave) void k_sample_depthguided(Sce
 
   int n2 = 2;
   while (n2 < K) n2 <<= 1;
-  fill_and_sort(S, K, n2, near, far, a.noise_fill ? a.noise_fill + (size_t)ray * K : nullptr, a.seed, ray, lane);
+  fill_and_sort(S, K, n2, near, far, a.noise_fill ? a.noise_fill + (size_t)ray * K : nullptr, a.seed, (int)(a.ray_key0 + (uint32_t)ray), lane);
   if (live)
     for (int j = lane; j < K; j += kWave) a.z_out[(size_t)ray * K + j] = S[j];
 }
 
 __global__ __launch_bounds__(kRaysPerBlock* kWave) void k_fill_uniform(const float* z_in, const float* rays, int NR, int K,
                                                                         const float* noise_fill, uint64_t seed,
-                                                                        float* z_out) {
+                                                                        uint32_t ray_key0, float* z_out) {
   __shared__ float sS[kRaysPerBlock][kMaxK];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray_raw = blockIdx.x * kRaysPerBlock + wave;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kRaysPerBlock* kWave) void k_fill_uniform(const flo
   int n2 = 2;
   while (n2 < K) n2 <<= 1;
   fill_and_sort(S, K, n2, rays[(size_t)ray * 8 + 6], rays[(size_t)ray * 8 + 7],
-                noise_fill ? noise_fill + (size_t)ray * K : nullptr, seed, ray, lane);
+                noise_fill ? noise_fill + (size_t)ray * K : nullptr, seed, (int)(ray_key0 + (uint32_t)ray), lane);
   if (live)
     for (int j = lane; j < K; j += kWave) z_out[(size_t)ray * K + j] = S[j];
 }
@@ -300,20 +301,21 @@ using namespace diner;
 extern "C" int diner_sample_depthguided_f32(const DinerScene* scene, const float* rays, int NR, int n_cand, int K,
                                             int G, float depth_diff_max, const float* t_base,
                                             const float* noise_coarse, const float* noise_gauss,
-                                            const float* noise_fill, uint64_t seed, float* z_out, float* z_unfilled,
-                                            void* stream) {
+                                            const float* noise_fill, uint64_t seed, long long ray_index0, float* z_out,
+                                            float* z_unfilled, void* stream) {
   DINER_CHECK_ARG(scene && rays && t_base && z_out, "sample_depthguided: null pointer argument");
   DINER_CHECK_ARG(NR > 0, "sample_depthguided: NR must be positive (got %d)", NR);
   DINER_CHECK_ARG(n_cand > 0 && n_cand <= kMaxCand, "sample_depthguided: n_cand=%d outside [1,%d]", n_cand, kMaxCand);
   DINER_CHECK_ARG(K > 0 && K <= kMaxK, "sample_depthguided: n_samples=%d outside [1,%d]", K, kMaxK);
   DINER_CHECK_ARG(G >= 0 && G <= K, "sample_depthguided: need 0 <= n_gaussian <= n_samples (got %d, %d)", G, K);
+  DINER_CHECK_ARG(ray_index0 >= 0, "sample_depthguided: ray_index0 must not be negative");
   SceneDev sd;
   int rc = make_scene_dev(scene, &sd);
   if (rc) return rc;
   DINER_CHECK_ARG(scene->depth && scene->depth_std && scene->normals && scene->std_pad_scale,
                   "sample_depthguided: scene depth/std/normal maps missing");
-  SamplerArgs a{rays, t_base, noise_coarse, noise_gauss, noise_fill, z_out, z_unfilled, seed, NR, n_cand, K, G,
-                depth_diff_max};
+  SamplerArgs a{rays, t_base, noise_coarse, noise_gauss, noise_fill, z_out, z_unfilled, seed, (uint32_t)ray_index0, NR, n_cand, K,
+                G, depth_diff_max};
   const int blocks = (NR + kRaysPerBlock - 1) / kRaysPerBlock;
   hipLaunchKernelGGL(k_sample_depthguided, dim3(blocks), dim3(kRaysPerBlock * kWave), 0, (hipStream_t)stream, sd, a);
   DINER_LAUNCH_OK();
@@ -321,12 +323,12 @@ extern "C" int diner_sample_depthguided_f32(const DinerScene* scene, const float
 }
 
 extern "C" int diner_fill_uniform_f32(const float* z_in, const float* rays, int NR, int K, const float* noise_fill,
-                                      uint64_t seed, float* z_out, void* stream) {
+                                      uint64_t seed, long long ray_index0, float* z_out, void* stream) {
   DINER_CHECK_ARG(z_in && rays && z_out, "fill_uniform: null pointer argument");
   DINER_CHECK_ARG(NR > 0 && K > 0 && K <= kMaxK, "fill_uniform: bad sizes NR=%d K=%d", NR, K);
   const int blocks = (NR + kRaysPerBlock - 1) / kRaysPerBlock;
   hipLaunchKernelGGL(k_fill_uniform, dim3(blocks), dim3(kRaysPerBlock * kWave), 0, (hipStream_t)stream, z_in, rays, NR,
-                     K, noise_fill, seed, z_out);
+                     K, noise_fill, seed, (uint32_t)ray_index0, z_out);
   DINER_LAUNCH_OK();
   return 0;
 }

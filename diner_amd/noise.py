@@ -26,3 +26,22 @@ def inject(coarse, gauss, fill):
         yield
     finally:
         _state.noise = prev
+
+
+# ---- production noise: one key per frame ---------------------------------------------------------------------------------------
+# The in-kernel Philox noise of ray i of a call is keyed by (seed, ray_index0 + i).  A caller that renders a frame in batches or
+# shards (diner_amd.render.predict_image, bench.py) sets ONE seed for the frame and tells every renderer.forward call where its
+# rays sit in the frame's ray list; the frame then does not depend on the batching.  Without a key each call draws its own seed
+# from torch's global CPU generator (the reference's behaviour: noise depends on the call sequence).
+def frame_key():
+    return getattr(_state, "key", None)
+
+
+@contextlib.contextmanager
+def keyed(seed, ray_index0=0):
+    prev = frame_key()
+    _state.key = (int(seed), int(ray_index0))
+    try:
+        yield
+    finally:
+        _state.key = prev

@@ -199,9 +199,10 @@ class HipMlp:
 
 # ---------------------------------------------------------------------------------------------------------
 def sample_depthguided(scene: HipScene, rays, n_samples, n_candidates, n_gaussian, depth_diff_max=0.05,
-                       noise=None, seed=0, want_unfilled=False):
+                       noise=None, seed=0, want_unfilled=False, ray_index0=0):
     """rays (NR,8) -> ascending z (NR,K) [, unfilled z with zeros].  noise = (coarse, gauss, fill) or None
-    (in-kernel Philox keyed by `seed`)."""
+    (in-kernel Philox keyed by (`seed`, ray_index0 + i): pass the index of rays[0] in the frame's ray list and one seed per
+    frame, and the frame does not depend on how its rays are batched or sharded)."""
     _require_hip(rays)
     rays = _f32c(rays)
     NR = rays.shape[0]
@@ -221,11 +222,11 @@ def sample_depthguided(scene: HipScene, rays, n_samples, n_candidates, n_gaussia
         _lib.check(lib.diner_sample_depthguided_f32(
             scene.ref, _ptr(rays), NR, int(n_candidates), K, G, float(depth_diff_max),
             _ptr(_t_base(int(n_candidates), rays.device)), _ptr(nc), _ptr(ng), _ptr(nf),
-            C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(z), _ptr(zu), _stream()))
+            C.c_uint64(int(seed) & (2 ** 64 - 1)), int(ray_index0), _ptr(z), _ptr(zu), _stream()))
     return (z, zu) if want_unfilled else z
 
 
-def fill_uniform(z_in, rays, noise_fill=None, seed=0):
+def fill_uniform(z_in, rays, noise_fill=None, seed=0, ray_index0=0):
     _require_hip(z_in, rays, noise_fill)
     z_in, rays = _f32c(z_in), _f32c(rays)
     NR, K = z_in.shape
@@ -235,7 +236,7 @@ def fill_uniform(z_in, rays, noise_fill=None, seed=0):
     nf = _f32c(noise_fill) if noise_fill is not None else None
     with torch.cuda.device(rays.device):
         _lib.check(lib.diner_fill_uniform_f32(_ptr(z_in), _ptr(rays), NR, K, _ptr(nf),
-                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(out), _stream()))
+                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), int(ray_index0), _ptr(out), _stream()))
     return out
 
 

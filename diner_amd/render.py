@@ -43,12 +43,14 @@ def gather_tiles(local, n_total, rank, world, group=None):
 
 @torch.no_grad()
 def predict_image(nerf, renderer, target_extrinsics, target_intrinsics, W, H, znear, zfar, ray_batch_size=8192,
-                  rank=0, world=1, group=None):
+                  rank=0, world=1, group=None, seed=None):
     """Render the (SB) target views described by target_extrinsics (SB,4,4) / target_intrinsics (SB,3,3) of the
     scene last passed to nerf.encode().  Returns rgb (SB,3,H,W), depth (SB,1,H,W) on rank 0 (None elsewhere).
     Same ray order (row-major pixels, centres at +0.5) and output layout as diner.py:79-92.  Noise injected with
     diner_amd.noise.inject for the whole (SB, H*W, .) ray list is handed to every batch as the matching slice (parity
-    tests); without injection the sampler draws in-kernel Philox noise."""
+    tests); without injection the sampler draws in-kernel Philox noise keyed by (`seed`, position of the ray in the frame):
+    the image does not depend on ray_batch_size or on the number of ranks.  `seed` None: drawn from torch's global CPU
+    generator on rank 0 and, with more than one rank, broadcast (8 bytes) so that all shards belong to the same frame."""
     SB = target_extrinsics.shape[0]
     dev = target_extrinsics.device
     znear = torch.as_tensor(znear, device=dev, dtype=torch.float32).expand(SB)
@@ -61,13 +63,20 @@ def predict_image(nerf, renderer, target_extrinsics, target_intrinsics, W, H, zn
     else:                          # host tensors (gloo tests): the reference's torch ops
         rays = gen_rays(target_extrinsics, target_intrinsics, W, H, znear, zfar).view(SB, H * W, 8)
         base = 0
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([seed], dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
+            dist.broadcast(t, src=0, group=group)
+            seed = int(t.item())
     tiles = []
     inj = _noise.current()
     for r0 in range(lo, hi, ray_batch_size):
         r1 = min(hi, r0 + ray_batch_size)
         rb = rays[:, r0 - base:r1 - base].contiguous()
         ctx = contextlib.nullcontext() if inj is None else _noise.inject(*(None if t is None else t[:, r0:r1] for t in inj))
-        with ctx:
+        with ctx, _noise.keyed(seed, r0):
             out = renderer.forward(model=nerf, rays=rb)
         tiles.append(torch.cat((out.fine.rgb, out.fine.depth.unsqueeze(-1)), dim=-1))      # (SB, b, 4)
     local = torch.cat(tiles, dim=1) if tiles else torch.zeros(SB, 0, 4, device=dev)

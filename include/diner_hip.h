@@ -91,7 +91,9 @@ int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs);
  * (nerf_renderer.py:39-63, :65-190, :367-397; torch_helpers.py:215-223; image_encoder.py:148-223)
  *   rays         (NR, 8)  [o(3), d(3), near, far]
  *   t_base       (n_cand) the stratification offsets torch.linspace(0, 1-1/n_cand, n_cand)
- *   noise_*      explicit noise (parity mode) or NULL -> counter-based Philox4x32-10 keyed by `seed`
+ *   noise_*      explicit noise (parity mode) or NULL -> counter-based Philox4x32-10 keyed by (`seed`, ray_index0 + i) for ray i of
+ *                the call: ray_index0 = index of rays[0] in the caller's ray list, so that a frame rendered with one seed does not
+ *                depend on how its rays are split into batches or sharded across GPUs (the reference's noise depends on both)
  *                noise_coarse (NR,n_cand) U[0,1); noise_gauss (NR,G) N(0,1); noise_fill (NR,K) U[0,1)
  *                indexed by the SORTED column of the empty slot
  *   z_out        (NR, K)  ascending z per ray
@@ -100,11 +102,11 @@ int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs);
 int diner_sample_depthguided_f32(const DinerScene* scene, const float* rays, int NR, int n_cand, int K, int G,
                                  float depth_diff_max, const float* t_base,
                                  const float* noise_coarse, const float* noise_gauss, const float* noise_fill,
-                                 uint64_t seed, float* z_out, float* z_unfilled, void* stream);
+                                 uint64_t seed, long long ray_index0, float* z_out, float* z_unfilled, void* stream);
 
 /* Stage-level entry for tests: fill_up_uniform_samples alone (nerf_renderer.py:367-397). */
 int diner_fill_uniform_f32(const float* z_in, const float* rays, int NR, int K, const float* noise_fill,
-                           uint64_t seed, float* z_out, void* stream);
+                           uint64_t seed, long long ray_index0, float* z_out, void* stream);
 
 /* ---- per-scene preparation: hoist of the three lin_z projections (resnetfc.py:153-155) ---------
  * lin_z[b] is linear and bilinear/border weights sum to 1, so lin_z[b](interp(latent)) == interp(lin_z[b](latent)):

@@ -22,6 +22,13 @@ def _seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
+def _key(sb=0):
+    """(seed, ray_index0) of this call's in-kernel noise: the frame key set by the image harness (one seed per frame + the
+    position of this ray batch in the frame, diner_amd.noise.keyed), else a fresh seed from torch's global generator."""
+    k = _noise.frame_key()
+    return (k[0] + 0x9E3779B97F4A7C15 * sb, k[1]) if k is not None else (_seed(), 0)
+
+
 class NeRFRendererDGS(torch.nn.Module):
     def __init__(self, n_samples=40, n_depth_candidates=1000, n_gaussian=15, eval_batch_size=100000, white_bkgd=True):
         super().__init__()
@@ -76,8 +83,9 @@ class NeRFRendererDGS(torch.nn.Module):
         out = []
         for sb in range(SB):
             nz = None if inj is None else tuple(None if t is None else t[sb] for t in inj)
+            seed, r0 = _key(sb)
             _, zu = ops.sample_depthguided(model.hip_scene(sb), rays[sb], n_samples, n_candidates, n_gaussian,
-                                           depth_diff_max, noise=nz, seed=_seed(), want_unfilled=True)
+                                           depth_diff_max, noise=nz, seed=seed, want_unfilled=True, ray_index0=r0)
             out.append(zu)
         return torch.stack(out)
 
@@ -85,9 +93,12 @@ class NeRFRendererDGS(torch.nn.Module):
         """zeros in z (SB,NR,K) -> stratified samples of [near, far]; returns ascending z (:367-397)."""
         SB = rays.shape[0]
         inj = _noise.current()
-        return torch.stack([ops.fill_uniform(z_samples[sb], rays[sb],
-                                             None if inj is None or inj[2] is None else inj[2][sb], seed=_seed())
-                            for sb in range(SB)])
+        out = []
+        for sb in range(SB):
+            seed, r0 = _key(sb)
+            out.append(ops.fill_uniform(z_samples[sb], rays[sb], None if inj is None or inj[2] is None else inj[2][sb],
+                                        seed=seed, ray_index0=r0))
+        return torch.stack(out)
 
     def composite(self, model, rays, z_samp):
         """-> weights (SB,B,K), rgb (SB,B,3), depth (SB,B)   (:286-365)."""
@@ -116,8 +127,9 @@ class NeRFRendererDGS(torch.nn.Module):
         for sb in range(SB):
             scene = model.hip_scene(sb)
             nz = None if inj is None else tuple(None if t is None else t[sb] for t in inj)
+            seed, r0 = _key(sb)
             z = ops.sample_depthguided(scene, rays[sb], self.n_samples, self.n_depth_candidates, self.n_gaussian,
-                                       0.05, noise=nz, seed=_seed())
+                                       0.05, noise=nz, seed=seed, ray_index0=r0)
             if training:
                 w, rgb, depth = self._render_train(model, sb, rays[sb], z, want_weights)
             else:

@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu():
     from diner_amd import _lib
     lib = _lib.load()
     # null scene / bad sizes are rejected before any device call
-    rc = lib.diner_sample_depthguided_f32(None, None, 0, 1000, 64, 24, 0.05, None, None, None, None, 0, None, None, None)
+    rc = lib.diner_sample_depthguided_f32(None, None, 0, 1000, 64, 24, 0.05, None, None, None, None, 0, 0, None, None, None)
     assert rc == -1 and b"null" in lib.diner_last_error()
     rc = lib.diner_composite_f32(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 4, 1000, 0, C.c_void_p(8), C.c_void_p(8),
                                  None, None)

@@ -13,8 +13,11 @@ class _FakeRenderer:
     """Deterministic per-ray stand-in for NeRFRendererDGS.forward (the sharding logic must not care what it is)."""
 
     def forward(self, model, rays):
+        from diner_amd import noise
+        seed, r0 = noise.frame_key()          # the harness keys every batch: (frame seed, position of the batch in the frame)
+        pos = (r0 + torch.arange(rays.shape[1], dtype=torch.float32)).expand(rays.shape[0], -1)
         rgb = torch.stack((rays[..., 3], rays[..., 4] * 2, rays[..., 5] * 3), dim=-1)
-        depth = rays[..., 3] + rays[..., 4] - rays[..., 5]
+        depth = rays[..., 3] + rays[..., 4] - rays[..., 5] + (seed % 1000) * 1e-3 + pos * 1e-2
         return DotMap(fine=DotMap(rgb=rgb, depth=depth))
 
 
@@ -34,8 +37,15 @@ def _worker(rank, world, port, W, H, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     E = torch.stack([look_at_extrinsics((0.1, 0.0, -1.0)), look_at_extrinsics((-0.2, 0.05, -1.0))])
     K = torch.tensor([[1.2 * W, 0, W / 2], [0, 1.2 * W, H / 2], [0, 0, 1.0]]).repeat(2, 1, 1)
-    rgb, depth = predict_image(None, _FakeRenderer(), E, K, W, H, 0.5, 1.5, ray_batch_size=37, rank=rank, world=world)
+    rgb, depth = predict_image(None, _FakeRenderer(), E, K, W, H, 0.5, 1.5, ray_batch_size=37, rank=rank, world=world, seed=4242)
+    # without an explicit seed rank 0 draws one and broadcasts it: both shards of the frame carry the same (seed % 1000) offset
+    torch.manual_seed(100 + rank)             # different generators on the two ranks
+    rgb_b, depth_b = predict_image(None, _FakeRenderer(), E, K, W, H, 0.5, 1.5, ray_batch_size=50, rank=rank, world=world)
     if rank == 0:
+        pos = torch.arange(H * W, dtype=torch.float32).view(1, 1, H, W) * 1e-2
+        geo = depth[:, :1] - 0.242 - pos                         # what the fake renderer computes from the rays alone
+        off = depth_b[:, :1] - pos - geo
+        assert float(off.max() - off.min()) < 1e-4, "the two ranks rendered their shards with different frame seeds"
         q.put((rgb, depth))
     else:
         assert rgb is None and depth is None
@@ -49,7 +59,7 @@ def test_sharded_render_equals_single_process():
     W, H = 23, 17                                   # 391 rays: not divisible by 2 -> padded gather path
     E = torch.stack([look_at_extrinsics((0.1, 0.0, -1.0)), look_at_extrinsics((-0.2, 0.05, -1.0))])
     K = torch.tensor([[1.2 * W, 0, W / 2], [0, 1.2 * W, H / 2], [0, 0, 1.0]]).repeat(2, 1, 1)
-    rgb1, d1 = predict_image(None, _FakeRenderer(), E, K, W, H, 0.5, 1.5, ray_batch_size=50)
+    rgb1, d1 = predict_image(None, _FakeRenderer(), E, K, W, H, 0.5, 1.5, ray_batch_size=50, seed=4242)
     assert rgb1.shape == (2, 3, H, W) and d1.shape == (2, 1, H, W)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
