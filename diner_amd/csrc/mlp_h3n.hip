@@ -24,7 +24,12 @@ constexpr float kScale = 16.0f, kInvScale = 1.0f / 16.0f;
 constexpr int kSlice = 8;                 // accumulator row tiles per wave (128 features)
 constexpr int kGroups = 4;                // column groups = source views
 constexpr int kBHalfs = 16 * kGroups * 2 * 64 * 8;      // B buffer: [t 16][g 4][hl 2][lane 64] h8 = 128 KB
-constexpr size_t kLdsBytes = (size_t)kBHalfs * 2 + 4 * 16 * 32;   // + taps exchange (4 groups x 16 columns x 32 B)
+constexpr int kSrcStride = 9;                           // floats per lane in the feature-source exchange (odd: conflict-free reads)
+constexpr size_t kTapsBytes = 4 * 16 * 32;              // taps exchange (4 groups x 16 columns x 32 B)
+constexpr size_t kFeatTabBytes = 64 * 16;               // input-feature recipe per (q, slot), see FeatRec
+constexpr size_t kFeatSrcBytes = 256 * kSrcStride * 4;  // per lane: x_c (3), R d (3), dd, 0
+constexpr size_t kLdsBytes = (size_t)kBHalfs * 2 + kTapsBytes + kFeatTabBytes + kFeatSrcBytes;
+constexpr size_t kLdsBytesPost = (size_t)kBHalfs * 2;
 
 // LDS operand buffer addressing: a per-lane byte address kept in one register + immediate offsets (the ds offset
 // field holds 16 bits, so the 128 KB buffer is reached from two bases 64 KB apart).  The bases are made opaque at
@@ -51,10 +56,103 @@ struct TapRec {            // per column: 4 tap offsets (float4 units into a pro
   float w[4];
 };
 
+// How lane quarter q makes its slot-th MLP input (input index f = 16 (slot / 4) + 4 q + slot % 4, field_common.hpp input_feature):
+// value = sin ? sin_posenc(fma(src, freq, phase)) : src, with src one of the eight per-lane sources {x_c, R d, dd, 0}.
+// The records sit in LDS, written once per workgroup; with them the 16 inputs of a lane cost ~30 instructions each instead of the
+// ~190 of input_feature's compare / divide / select chains on a lane-varying f (14.7 k of the kernel's 268 k clocks per tile,
+// profiles/r02_kernel_experiments.md) -- same operations on the same operands, so the inputs are bit-identical.
+struct FeatRec {
+  int src;        // index into the lane's source exchange
+  float freq;     // freq_factor * 2^k                               (positional_encoding.py:18)
+  float phase;    // 0 or fp32(pi / 2)                               (:30)
+  int sin;        // 1: encoded, 0: the source itself
+};
+__device__ __forceinline__ FeatRec feat_recipe(int f, float freq_factor) {
+  FeatRec r{7, 0.0f, 0.0f, 0};
+  int j = -1;
+  if (f < 3) r.src = f;
+  else if (f < 39) { j = (f - 3) / 3; r.src = (f - 3) - 3 * j; }
+  else if (f < 42) r.src = 3 + (f - 39);
+  else if (f == 42) r.src = 6;
+  else if (f < kDIn) { j = f - 43; r.src = 6; }
+  if (j >= 0) {
+    r.freq = __fmul_rn(freq_factor, (float)(1 << (j >> 1)));
+    r.phase = (j & 1) ? 1.57079637050628662109375f : 0.0f;
+    r.sin = 1;
+  }
+  return r;
+}
+
+// field_common.hpp field_frontend with the table-driven inputs (rays + z or xyz point sources; explicit inputs pass through)
+__device__ __forceinline__ void frontend_h3n(const SceneDev& sc, const FieldArgs& a, int v, int q, int lane, long long p,
+                                             const FeatRec* __restrict__ tab, float* __restrict__ src, Taps& taps,
+                                             float (&feat)[16]) {
+  if (a.direct_feat) {
+    field_frontend(sc, a, v, q, p, taps, feat);
+    return;
+  }
+  float px, py, pz, dx, dy, dz;
+  load_point(a, p, px, py, pz, dx, dy, dz);
+  float xc[3], vd[3];
+  world_to_cam(sc.R[v], sc.t[v], px, py, pz, xc[0], xc[1], xc[2]);           // pixelnerf.py:91-93
+  vd[0] = rot_row(sc.R[v] + 0, dx, dy, dz);                                  // :100
+  vd[1] = rot_row(sc.R[v] + 3, dx, dy, dz);
+  vd[2] = rot_row(sc.R[v] + 6, dx, dy, dz);
+  const float u = project_axis(xc[0], xc[2], sc.focal[v][0], sc.c[v][0], sc.img_w);   // :105-108
+  const float w = project_axis(xc[1], xc[2], sc.focal[v][1], sc.c[v][1], sc.img_h);
+  const int ix = nearest_border(u, sc.Ws), iy = nearest_border(w, sc.Hs);    // nearest depth tap (:114-116)
+  const float dd = __fsub_rn(sc.depth[(size_t)v * sc.Hs * sc.Ws + (size_t)iy * sc.Ws + ix], xc[2]);
+  float* mine = src + lane * kSrcStride;             // read back by this lane only: program order, no barrier
+  mine[0] = xc[0]; mine[1] = xc[1]; mine[2] = xc[2];
+  mine[3] = vd[0]; mine[4] = vd[1]; mine[5] = vd[2];
+  mine[6] = dd;    mine[7] = 0.0f;
+#pragma unroll
+  for (int sl = 0; sl < 16; ++sl) {
+    const FeatRec r = tab[q * 16 + sl];
+    const float x = mine[r.src];
+    const float e = sin_posenc(__fmaf_rn(x, r.freq, r.phase));               // addcmul is fused, positional_encoding.py:46
+    feat[sl] = r.sin ? e : x;
+  }
+  bilinear_taps(sc, v, u, w, taps);
+}
+
 struct Args {
   FieldArgs fa;
   const _Float16* w;       // n-split packed weights: lin_in, then per block b<3: fc_0, fc_1
   const float* b;          // biases x16: lin_in, then per block: fc_0, fc_1  (7 x 512)
+  unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
+};
+
+// Phase timer of the per-view kernel (DINER_HN_PROF builds only; tools/prof_phases.sh): mark(i) books the shader clocks since the
+// previous mark on phase i.  Costs an s_memtime + s_waitcnt lgkmcnt(0) per mark, so the phase sums are slightly pessimistic.
+struct Prof {
+#ifdef DINER_HN_PROF
+  unsigned long long last, acc[20], t0, r0;
+  __device__ __forceinline__ void begin() {
+#pragma unroll
+    for (int i = 0; i < 20; ++i) acc[i] = 0;
+    t0 = last = __builtin_readcyclecounter();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    acc[i] += now - last;
+    last = now;
+  }
+  __device__ __forceinline__ void end(unsigned long long* out, int lane) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 20; ++i) atomicAdd(out + i, acc[i]);
+      atomicAdd(out + 24, __builtin_readcyclecounter() - t0);
+      atomicAdd(out + 25, __builtin_amdgcn_s_memrealtime() - r0);
+      atomicAdd(out + 26, 1ull);
+    }
+  }
+#else
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void end(unsigned long long*, int) {}
+#endif
 };
 
 // packed weights of one layer with KT k32 blocks: [w 4][t KT][mo 8][hl 2][lane 64][8]
@@ -95,19 +193,20 @@ struct NoSide {
 //     right after its last use in the second half (576 MFMA cycles before the next use);
 //   * the side task gets a slot per quarter-step, so its VALU / VMEM work is spread between the MFMAs.
 // LO = false: plain fp16 operands (hi parts only, one MFMA per product; diner_set_precision(3)).
-template <int KT, int R, bool LO, class Side>
-__device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
-                                     f32x4 (&acc)[kSlice][kGroups], Side& side) {
-  constexpr int NH = 2 * KT;
+#ifndef DINER_HN_EARLYA
+#define DINER_HN_EARLYA 1
+#endif
+// The weight ring of one GEMM.  start() issues the first R-1 half-steps; it is called BEFORE the hidden state is published
+// (the barriers in between wait on LDS traffic only, not on vmcnt), so the first fragments arrive while the conversion runs.
+template <int KT, int R, bool LO>
+struct ARing {
+  typedef const __attribute__((address_space(1))) char* gptr;      // stays a global (not flat) access through the asm
   h8 a[R][8];                            // half-step ring (static indices after unrolling)
-  h8 bb[kGroups][2];                     // B of the current k32 block: [g][hl]
   // scalar base (advanced 8 KB per half-step and kept opaque so the addresses are not all materialised up front)
   // + per-lane 32-bit offset + immediate: no address registers per load
-  typedef const __attribute__((address_space(1))) char* gptr;      // stays a global (not flat) access through the asm
-  B.opaque();
-  gptr abase = (gptr)(reinterpret_cast<const char*>(layer) + (size_t)wave * KT * 16384 + 4096);
-  const unsigned avoff = lane * 16;
-  auto load_a2 = [&](h8 (&dst)[8], int pair) {      // fragments 2 pair, 2 pair + 1 of the half-step at abase
+  gptr abase;
+  unsigned avoff;
+  __device__ __forceinline__ void load_a2(h8 (&dst)[8], int pair) {      // fragments 2 pair, 2 pair + 1 of the half-step at abase
 #ifdef DINER_HN_NO_A          // ablation: price the weight stream
     asm volatile("" : "+v"(dst[2 * pair]), "+v"(dst[2 * pair + 1]));
 #else
@@ -117,7 +216,29 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
       if (LO || (i & 1) == 0) dst[i] = *(const __attribute__((address_space(1))) h8*)(abase + avoff + (i * 1024 - 4096));
     if (pair == 3) abase += 8192;
 #endif
-  };
+  }
+  __device__ __forceinline__ void start(const _Float16* __restrict__ layer, int wave, int lane) {
+    constexpr int NH = 2 * KT;
+    abase = (gptr)(reinterpret_cast<const char*>(layer) + (size_t)wave * KT * 16384 + 4096);
+    avoff = lane * 16;
+#if defined(DINER_HN_NO_A) || defined(DINER_HN_NO_B)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[r][i] = *(reinterpret_cast<const h8*>(layer) + (r * 8 + i) * 64 + lane);
+#endif
+    static_for<(R - 1 < NH ? R - 1 : NH)>([&](auto H) {
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) load_a2(a[decltype(H)::value], pr);
+    });
+  }
+};
+
+template <int KT, int R, bool LO, class Side>
+__device__ __forceinline__ void gemm(ARing<KT, R, LO>& ring, LdsB B, f32x4 (&acc)[kSlice][kGroups], Side& side) {
+  constexpr int NH = 2 * KT;
+  h8 bb[kGroups][2];                     // B of the current k32 block: [g][hl]
+  B.opaque();
   auto load_b = [&](int t, int g) {
 #ifdef DINER_HN_NO_B          // ablation: price the LDS operand reads
     asm volatile("" : "+v"(bb[g][0]), "+v"(bb[g][1]));
@@ -128,16 +249,8 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
   };
 #if defined(DINER_HN_NO_A) || defined(DINER_HN_NO_B)
 #pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[r][i] = *(reinterpret_cast<const h8*>(layer) + (r * 8 + i) * 64 + lane);
-#pragma unroll
   for (int g = 0; g < kGroups; ++g) bb[g][0] = bb[g][1] = *B.at(0, g, 0);
 #endif
-  static_for<(R - 1 < NH ? R - 1 : NH)>([&](auto H) {
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) load_a2(a[decltype(H)::value], pr);
-  });
 #pragma unroll
   for (int g = 0; g < kGroups; ++g) load_b(0, g);
   static_for<NH * kGroups>([&](auto Q) {
@@ -145,11 +258,11 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
     constexpr int h = qi >> 2, g = qi & 3;
     constexpr int t = h >> 1, half = h & 1;
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (h + R - 1 < NH) load_a2(a[(h + R - 1) % R], g);
+    if constexpr (h + R - 1 < NH) ring.load_a2(ring.a[(h + R - 1) % R], g);
     if constexpr (half == 1 && g > 0 && t + 1 < KT) load_b(t + 1, g - 1);       // previous quarter's group is free
     if constexpr (half == 0 && g == 0 && t > 0) load_b(t, kGroups - 1);         // ... and the last one of block t-1
     side.template run<h, g>();
-    h8 (&ac)[8] = a[h % R];
+    h8 (&ac)[8] = ring.a[h % R];
 #pragma unroll
     for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][0]);
     if constexpr (LO) {
@@ -165,18 +278,52 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
   });
   side.finish();
 }
+// start + run in one go (no publish in front of it)
+template <int KT, int R, bool LO, class Side>
+__device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
+                                     f32x4 (&acc)[kSlice][kGroups], Side& side) {
+  ARing<KT, R, LO> ring;
+  ring.start(layer, wave, lane);
+  gemm<KT, R, LO>(ring, B, acc, side);
+}
 
+#ifndef DINER_HN_MIXCVT
+#define DINER_HN_MIXCVT 1
+#endif
+// relu(x) * scale of eight accumulator values -> fp16 hi parts and lo parts (x * scale - hi), packed as MFMA B operands.
 __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float scale, h8& h, h8& l) {
+#if DINER_HN_MIXCVT
+  // Four instructions per value pair instead of ~7: v_fma_mix{lo,hi}_f16 rounds fma(x, scale, 0) to fp16 into one half of a register
+  // (scale folded in, the pair packed for free), and a second one forms fma(x, scale, -hi) with hi read back as an fp16 source -- the
+  // same two roundings as cvt(x * scale) and cvt(x * scale - float(hi)) (x * scale and the difference are exact in fp32), so the
+  // operands are bit-identical to the plain-C path below.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hp, lp;
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    // relu as an integer max on the bit pattern (negative floats, -0 included, are negative integers); a NaN keeps propagating
+    const float x0 = __int_as_float(max(__float_as_int(jp < 2 ? lo4[2 * jp] : hi4[2 * jp - 4]), 0));
+    const float x1 = __int_as_float(max(__float_as_int(jp < 2 ? lo4[2 * jp + 1] : hi4[2 * jp - 3]), 0));
+    unsigned hh, ll;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "s"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "s"(scale));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "s"(scale), "v"(hh));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "s"(scale), "v"(hh));
+    hp[jp] = hh;
+    lp[jp] = ll;
+  }
+  h = __builtin_bit_cast(h8, hp);
+  l = __builtin_bit_cast(h8, lp);
+#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    // relu as an integer max on the bit pattern (negative floats, -0 included, are negative integers): one v_max_i32
-    // instead of fmaxf's canonicalise + max pair; a NaN keeps propagating like torch.relu's
     const float x = j < 4 ? lo4[j] : hi4[j - 4];
     const float v = __int_as_float(max(__float_as_int(x), 0)) * scale;
     const _Float16 hh = (_Float16)v;
     h[j] = hh;
     l[j] = (_Float16)(v - (float)hh);
   }
+#endif
 }
 
 // publish relu(acc)/16 of this wave's 128-feature slice as B operands (k32 blocks 4w .. 4w+3) for all 4 column groups
@@ -191,11 +338,51 @@ __device__ __forceinline__ void publish(LdsB B, int wave, int lane, const f32x4 
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
       h8 h, l;
+#ifdef DINER_HN_PUB_NOCVT        // ablation: LDS writes only
+      h = __builtin_bit_cast(h8, acc[2 * tl][g]);
+      l = __builtin_bit_cast(h8, acc[2 * tl + 1][g]);
+#else
       split8(acc[2 * tl][g], acc[2 * tl + 1][g], kInvScale, h, l);
+#endif
       const int t = 4 * wave + tl;
+#ifdef DINER_HN_PUB_NOWRITE      // ablation: conversion only
+      asm volatile("" :: "v"(h), "v"(l));
+#else
       *B.at(t, g, 0) = h;
       if constexpr (LO) *B.at(t, g, 1) = l;
+#endif
     }
+}
+
+// hidden state -> B operands, then the GEMM of `layer` on them: barrier, publish, barrier, GEMM, with the weight ring started first
+template <int R, bool LO, class Side, class Between>
+__device__ __forceinline__ void publish_gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
+                                             const f32x4 (&src)[kSlice][kGroups], f32x4 (&acc)[kSlice][kGroups], Side& side,
+                                             Between&& between, Prof& pf, int ph) {
+  ARing<16, R, LO> ring;
+#if DINER_HN_EARLYA
+  ring.start(layer, wave, lane);
+#endif
+  __syncthreads();                                // everybody finished reading the previous B
+  pf.mark(ph);
+  publish<LO>(B, wave, lane, src);
+  pf.mark(ph + 1);
+  __syncthreads();
+  pf.mark(ph + 2);
+  between();                                      // bias of the accumulators the GEMM adds into
+#if !DINER_HN_EARLYA
+  ring.start(layer, wave, lane);
+#endif
+  gemm<16, R, LO>(ring, B, acc, side);
+  pf.mark(ph + 3);
+}
+
+// Tell the register allocator that a block of accumulators lives in the AGPR half of the file at this point (no code).
+__device__ __forceinline__ void pin_acc(f32x4 (&acc)[kSlice][kGroups]) {
+#pragma unroll
+  for (int mo = 0; mo < kSlice; ++mo)
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) asm volatile("" : "+a"(acc[mo][g]));
 }
 
 __device__ __forceinline__ void set_bias(f32x4 (&acc)[kSlice][kGroups], const float* __restrict__ bias, int wave, int q) {
@@ -222,11 +409,21 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
 #define DINER_HN_G0DEPTH 8
 #endif
 
+#ifndef DINER_HN_GSPLIT          // 1: a block's lin_z gather is spread over both GEMMs of the block before it; 0: all of it on fc_1
+#define DINER_HN_GSPLIT 0
+#endif
+
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
-// (g, mo) of 4 taps each.  As a GEMM side task one unit's taps are requested per half-step, one per quarter-step, and
-// blended / added GD - 1 half-steps later (the additions commute with the GEMM's accumulation into the same registers).
-template <int GD>
+// (g, mo) of 4 taps each; this object does units [U0, U0 + NU).  As a GEMM side task the NU units are spread over the GEMM's 128
+// quarter-steps (SP = 128 / NU slots per unit: taps requested in slots 0, SP/4, 2 SP/4, 3 SP/4), and a unit is blended / added in
+// the last slot of unit + GD - 1 (the additions commute with the GEMM's accumulation into the same registers; during a fc_0
+// GEMM, which accumulates into the other register block, xs was already published and is free to change).
+// Why spread over two GEMMs: the per-CU vector-memory path (64 B/clk) carries 1 MB of weights per GEMM (16.4 k cycles of the
+// GEMM's 24.6 k MFMA cycles) and a block's taps are another 0.5 MB -- on one GEMM that path is full.
+template <int GD, int U0 = 0, int NU = 32>
 struct GatherSide {
+  static constexpr int SP = 128 / NU;
+  static_assert(NU == 32 || NU == 16, "one or two quarter-steps per tap");
   const float* __restrict__ tz;
   const TapRec* __restrict__ taps_lds;     // [g 4][col 16]
   int wave, q, pt;
@@ -255,24 +452,26 @@ struct GatherSide {
     xs[mo][g] += v;
     asm volatile("" : "+a"(xs[mo][g]));
   }
-  // half-step H: quarter 0 requests unit H's taps (ring slot H % GD), quarter 2 blends unit H - GD + 1
+  // quarter-step s = 4 H + G of the GEMM
   template <int H, int G>
   __device__ __forceinline__ void run() {
 #ifndef DINER_HN_NO_GATHER
-    // one tap per quarter-step (a smoother request stream for the vector-memory path: +2 % over four at once), the
-    // blend of unit H - GD + 1 in the last quarter, four quarter-steps after its last tap was requested (GD >= 2)
-    static_assert(GD >= 2, "the blend of a unit comes one half-step after its last tap request");
-    if constexpr (G == 3 && H - GD + 1 >= 0 && H - GD + 1 < 32) blend<(H - GD + 1 >= 0 ? H - GD + 1 : 0)>();
-    if constexpr (H < 32) issue_tap<(H < 32 ? H : 0), G>();
+    // one tap per slot (a smoother request stream for the vector-memory path: +2 % over four at once), the blend of unit
+    // u - GD + 1 in the last slot of unit u, at least SP quarter-steps after its last tap was requested (GD >= 2)
+    static_assert(GD >= 2, "the blend of a unit comes one unit after its last tap request");
+    constexpr int s = 4 * H + G, u = s / SP, slot = s % SP;
+    if constexpr (slot == SP - 1 && u - GD + 1 >= 0 && u - GD + 1 < NU) blend<U0 + (u - GD + 1 >= 0 ? u - GD + 1 : 0)>();
+    if constexpr (u < NU && slot % (SP / 4) == 0) issue_tap<U0 + (u < NU ? u : 0), slot / (SP / 4)>();
 #endif
   }
   __device__ __forceinline__ void finish() {
 #ifndef DINER_HN_NO_GATHER
-    static_for<GD - 1>([&](auto I) { blend<33 - GD + decltype(I)::value>(); });
+    static_for<GD - 1>([&](auto I) { blend<U0 + NU + 1 - GD + decltype(I)::value>(); });
 #endif
   }
   // stand-alone (no GEMM to hide under): block 0
   __device__ __forceinline__ void all() {
+    static_assert(NU == 32 && U0 == 0, "");
     static_for<32>([&](auto H) {
       run<decltype(H)::value, 0>();
       run<decltype(H)::value, 1>();
@@ -288,23 +487,66 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   h8* B = reinterpret_cast<h8*>(smem);
   TapRec* taps_lds = reinterpret_cast<TapRec*>(reinterpret_cast<char*>(smem) + (size_t)kBHalfs * 2);
+  FeatRec* feat_tab = reinterpret_cast<FeatRec*>(reinterpret_cast<char*>(taps_lds) + kTapsBytes);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, pt = lane & 15;
+  float* feat_src = reinterpret_cast<float*>(reinterpret_cast<char*>(feat_tab) + kFeatTabBytes) + wave * 64 * kSrcStride;
   const FieldArgs& fa = a.fa;
+  if (threadIdx.x < 64) {      // recipe of (q, slot) = (threadIdx.x / 16, threadIdx.x % 16)
+    const int sl = threadIdx.x & 15;
+    feat_tab[threadIdx.x] = feat_recipe(16 * (sl >> 2) + 4 * (threadIdx.x >> 4) + (sl & 3), fa.freq_factor);
+  }
+  __syncthreads();
   const LdsB Bl = LdsB::make(B, lane);
   const long long n_tiles = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
   const _Float16* w_in = a.w;                                   // [4][2][8][2][64][8]  = 4 * 2 * 16 KB
   const _Float16* w_blk = a.w + (size_t)4 * 2 * 8192;           // then 6 layers of 4 * 16 * 16 KB
   constexpr size_t kLayerHalfs = (size_t)4 * 16 * 8192;
 
+  Prof pf;
+  pf.begin();
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     long long p = tile * kPtsPerWave + pt;
     if (p >= fa.P) p = fa.P - 1;
     Taps taps;
     float feat[16];
-    field_frontend(sc, fa, /*view=*/wave, q, p, taps, feat);
+#ifdef DINER_HN_PROF_FRONT       // the frontend in four timed pieces (same arithmetic as field_frontend, rays + z source only)
+    {
+      float px, py, pz, dx, dy, dz;
+      load_point(fa, p, px, py, pz, dx, dy, dz);
+      asm volatile("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(dx), "+v"(dy), "+v"(dz));
+      pf.mark(15);
+      float xc[3], vd[3];
+      const int v = wave;
+      world_to_cam(sc.R[v], sc.t[v], px, py, pz, xc[0], xc[1], xc[2]);
+      vd[0] = rot_row(sc.R[v] + 0, dx, dy, dz);
+      vd[1] = rot_row(sc.R[v] + 3, dx, dy, dz);
+      vd[2] = rot_row(sc.R[v] + 6, dx, dy, dz);
+      const float u = project_axis(xc[0], xc[2], sc.focal[v][0], sc.c[v][0], sc.img_w);
+      const float w = project_axis(xc[1], xc[2], sc.focal[v][1], sc.c[v][1], sc.img_h);
+      const int ix = nearest_border(u, sc.Ws), iy = nearest_border(w, sc.Hs);
+      float dd = __fsub_rn(sc.depth[(size_t)v * sc.Hs * sc.Ws + (size_t)iy * sc.Ws + ix], xc[2]);
+      asm volatile("" : "+v"(dd));
+      pf.mark(16);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          feat[4 * m + r] = input_feature(16 * m + 4 * q + r, xc, vd, dd, fa.freq_factor);
+          asm volatile("" : "+v"(feat[4 * m + r]));
+        }
+      pf.mark(17);
+      bilinear_taps(sc, v, u, w, taps);
+      asm volatile("" : "+v"(taps.w[0]), "+v"(taps.w[3]));
+      pf.mark(18);
+    }
+#else
+    frontend_h3n(sc, fa, /*view=*/wave, q, lane, p, feat_tab, feat_src, taps, feat);
+#endif
+    pf.mark(0);
     __syncthreads();                              // previous tile's readers of B / taps are done
+    pf.mark(1);
     {   // publish lin_in B operands (scale 1) for column group `wave` and this column's taps
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -329,51 +571,76 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
         taps_lds[wave * 16 + pt] = r;
       }
     }
+    pf.mark(2);
     __syncthreads();
+    pf.mark(3);
     f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
     set_bias(xs, a.b, wave, q);
     {
       NoSide none;
       gemm<2, 2, LO>(w_in, Bl, wave, lane, xs, none);
+      pf.mark(4);
       GatherSide<DINER_HN_G0DEPTH> g0{fa.tz, taps_lds, wave, q, pt, xs};  // lin_z[0]: nothing long enough to hide under yet
       g0.all();
+      pf.mark(5);
     }
     for (int b = 0; b < 3; ++b) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
-      __syncthreads();                            // everybody finished reading the previous B
-      publish<LO>(Bl, wave, lane, xs);
-      __syncthreads();
-      set_bias(ns, bias, wave, q);
+#if DINER_HN_GSPLIT
+      {   // first half of the next block's lin_z gather rides on fc_0 (xs is published; ns is what this GEMM accumulates into)
+        const _Float16* w0 = w_blk + (size_t)(2 * b) * kLayerHalfs;
+        __syncthreads();                          // everybody finished reading the previous B
+        pf.mark(6);
+        publish<LO>(Bl, wave, lane, xs);
+        pf.mark(7);
+        __syncthreads();
+        pf.mark(8);
+        set_bias(ns, bias, wave, q);
+        if (b < 2) {
+          GatherSide<DINER_HN_GDEPTH, 0, 16> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
+          gemm<16, DINER_HN_RING0, LO>(w0, Bl, wave, lane, ns, gs);
+        } else {
+          NoSide none;
+          gemm<16, DINER_HN_RING0, LO>(w0, Bl, wave, lane, ns, none);
+        }
+        pf.mark(9);
+      }
+#else
       {
         NoSide none;
-        gemm<16, DINER_HN_RING0, LO>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
+        publish_gemm<DINER_HN_RING0, LO>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none,
+                                         [&] { set_bias(ns, bias, wave, q); }, pf, 6);
       }
+#endif
+      const _Float16* w1 = w_blk + (size_t)(2 * b + 1) * kLayerHalfs;
       __syncthreads();
+      pf.mark(10);
       publish<LO>(Bl, wave, lane, ns);
+      pf.mark(11);
       __syncthreads();
+      pf.mark(12);
       add_bias(xs, bias + kHidden, wave, q);
       if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
+#if DINER_HN_GSPLIT
+        GatherSide<DINER_HN_GDEPTH, 16, 16> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
+#else
         GatherSide<DINER_HN_GDEPTH> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
-        gemm<16, DINER_HN_RING, LO>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, gs);
+#endif
+        gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, gs);
       } else {
         NoSide none;
-        gemm<16, DINER_HN_RING, LO>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
+        gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, none);
       }
+      pf.mark(13);
     }
     // view mean = mean over the four column groups; hand-over at scale 1 in accumulator layout (row tile 8 w + mo)
     f32x4* out = reinterpret_cast<f32x4*>(fa.xpre) + (size_t)tile * (kTiles * 64) + lane;
 #pragma unroll
     for (int mo = 0; mo < kSlice; ++mo)
       out[(8 * wave + mo) * 64] = (((xs[mo][0] + xs[mo][1]) + xs[mo][2]) + xs[mo][3]) * (0.25f * kInvScale);
+    pf.mark(14);
   }
-}
-
-// Tell the register allocator that a block of accumulators lives in the AGPR half of the file at this point (no code).
-__device__ __forceinline__ void pin_acc(f32x4 (&acc)[kSlice][kGroups]) {
-#pragma unroll
-  for (int mo = 0; mo < kSlice; ++mo)
-#pragma unroll
-    for (int g = 0; g < kGroups; ++g) asm volatile("" : "+a"(acc[mo][g]));
+  pf.end(a.prof, lane);
 }
 
 struct PostArgsN {
@@ -408,21 +675,18 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       for (int mo = 0; mo < kSlice; ++mo) xs[mo][g] = in[(8 * wave + mo) * 64] * kScale;
     }
     NoSide none;
+    Prof pf;                                      // not reported for this kernel
+    pf.begin();
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
       const float* bias = pa.b_post + 2 * kHidden * b;
-      __syncthreads();                            // everybody finished reading the previous B
-      publish<LO>(Bl, wave, lane, xs);
-      __syncthreads();
-      set_bias(ns, bias, wave, q);
-      pin_acc(xs);                                // the residual stream stays in registers across the fc_0 GEMM
-      gemm<16, DINER_HN_RING0, LO>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, ns, none);
+      publish_gemm<DINER_HN_RING0, LO>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
+        set_bias(ns, bias, wave, q);
+        pin_acc(xs);                              // the residual stream stays in registers across the fc_0 GEMM
+      }, pf, 0);
       pin_acc(xs);
-      __syncthreads();
-      publish<LO>(Bl, wave, lane, ns);
-      __syncthreads();
-      add_bias(xs, bias + kHidden, wave, q);
-      gemm<16, DINER_HN_RING, LO>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, xs, none);
+      publish_gemm<DINER_HN_RING, LO>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
+                                      [&] { add_bias(xs, bias + kHidden, wave, q); }, pf, 4);
     }
     // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
     __syncthreads();
@@ -559,9 +823,29 @@ int h3n_set_attributes() {
 // split = true: f16x3 split products (hi and lo parts, three MFMAs per product); false: plain fp16 operands
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
                     hipStream_t stream) {
-  h3n::Args a{fa, (const _Float16*)w, b};
+  h3n::Args a{fa, (const _Float16*)w, b, nullptr};
+#ifdef DINER_HN_PROF
+  static unsigned long long* prof = nullptr;
+  if (!prof) hipMalloc(&prof, 32 * sizeof(unsigned long long));
+  hipMemsetAsync(prof, 0, 32 * sizeof(unsigned long long), stream);
+  a.prof = prof;
+#endif
   if (split) hipLaunchKernelGGL(h3n::k_field_pre_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
   else hipLaunchKernelGGL(h3n::k_field_pre_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
+#ifdef DINER_HN_PROF
+  unsigned long long h[32];
+  static const char* fnames[4] = {"  load_point", "  project + depth tap", "  features", "  bilinear taps"};
+  hipStreamSynchronize(stream);
+  hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+  static const char* names[15] = {"frontend", "sync", "lin_in publish", "sync", "lin_in gemm", "gather 0", "fc_0 sync A", "fc_0 publish",
+                                  "fc_0 sync B", "fc_0 gemm", "fc_1 sync A", "fc_1 publish", "fc_1 sync B", "fc_1 gemm(+gather)", "store"};
+  const double waves = (double)h[26], tot = (double)h[24];
+  fprintf(stderr, "[h3n prof] waves %.0f  clocks/wave %.0f  shader MHz %.0f  (P=%lld)\n", waves, tot / waves,
+          tot / ((double)h[25] / 100.0), fa.P);
+  for (int i = 0; i < 15; ++i) fprintf(stderr, "[h3n prof]   %-20s %6.2f %%  %10.0f clk/wave\n", names[i], 100.0 * h[i] / tot, h[i] / waves);
+  for (int i = 15; i < 19; ++i)
+    if (h[i]) fprintf(stderr, "[h3n prof]   %-20s %6.2f %%  %10.0f clk/wave\n", fnames[i - 15], 100.0 * h[i] / tot, h[i] / waves);
+#endif
 }
 
 // w: the n-split pack (post layers follow the per-view ones); w_lin_out: the lin_out fragments
@@ -569,8 +853,8 @@ void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out,
   const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
   const _Float16* wo = (const _Float16*)w_lin_out;
   h3n::PostArgsN a{pa, wn, wo};
-  if (split) hipLaunchKernelGGL(h3n::k_field_post_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);
-  else hipLaunchKernelGGL(h3n::k_field_post_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, a);
+  if (split) hipLaunchKernelGGL(h3n::k_field_post_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
+  else hipLaunchKernelGGL(h3n::k_field_post_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
 }
 
 }  // namespace diner
