@@ -25,10 +25,15 @@ constexpr int kSlice = 8;                 // accumulator row tiles per wave (128
 constexpr int kGroups = 4;                // column groups = source views
 constexpr int kBHalfs = 16 * kGroups * 2 * 64 * 8;      // B buffer: [t 16][g 4][hl 2][lane 64] h8 = 128 KB
 constexpr int kSrcStride = 9;                           // floats per lane in the feature-source exchange (odd: conflict-free reads)
-constexpr size_t kTapsBytes = 4 * 16 * 32;              // taps exchange (4 groups x 16 columns x 32 B)
+constexpr size_t kTapRecBytes = 4 * 16 * 32;            // taps exchange (4 groups x 16 columns x 32 B)
+constexpr size_t kTapIdxBytes = 4 * 16 * 16;            // + per column: where its four taps sit in the view's distinct-row list
+constexpr size_t kURowBytes = 4 * 16 * 4 + 256;         // + the distinct rows of each view (<= 16 kept) and their count
+constexpr size_t kTapsBytes = kTapRecBytes + kTapIdxBytes + kURowBytes;
+constexpr size_t kStageBytes = 4 * 2 * 1024;            // de-duplicated gather: per wave two staging slots of 16 rows x 64 B
 constexpr size_t kFeatTabBytes = 64 * 16;               // input-feature recipe per (q, slot), see FeatRec
 constexpr size_t kFeatSrcBytes = 256 * kSrcStride * 4;  // per lane: x_c (3), R d (3), dd, 0
-constexpr size_t kLdsBytes = (size_t)kBHalfs * 2 + kTapsBytes + kFeatTabBytes + kFeatSrcBytes;
+constexpr size_t kLdsBytes = (size_t)kBHalfs * 2 + kTapsBytes + kFeatTabBytes + kFeatSrcBytes + kStageBytes;
+static_assert(kLdsBytes <= 160 * 1024, "LDS of one CU");
 constexpr size_t kLdsBytesPost = (size_t)kBHalfs * 2;
 
 // LDS operand buffer addressing: a per-lane byte address kept in one register + immediate offsets (the ds offset
@@ -287,34 +292,8 @@ __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B,
   gemm<KT, R, LO>(ring, B, acc, side);
 }
 
-#ifndef DINER_HN_MIXCVT
-#define DINER_HN_MIXCVT 1
-#endif
 // relu(x) * scale of eight accumulator values -> fp16 hi parts and lo parts (x * scale - hi), packed as MFMA B operands.
 __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float scale, h8& h, h8& l) {
-#if DINER_HN_MIXCVT
-  // Four instructions per value pair instead of ~7: v_fma_mix{lo,hi}_f16 rounds fma(x, scale, 0) to fp16 into one half of a register
-  // (scale folded in, the pair packed for free), and a second one forms fma(x, scale, -hi) with hi read back as an fp16 source -- the
-  // same two roundings as cvt(x * scale) and cvt(x * scale - float(hi)) (x * scale and the difference are exact in fp32), so the
-  // operands are bit-identical to the plain-C path below.
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 hp, lp;
-#pragma unroll
-  for (int jp = 0; jp < 4; ++jp) {
-    // relu as an integer max on the bit pattern (negative floats, -0 included, are negative integers); a NaN keeps propagating
-    const float x0 = __int_as_float(max(__float_as_int(jp < 2 ? lo4[2 * jp] : hi4[2 * jp - 4]), 0));
-    const float x1 = __int_as_float(max(__float_as_int(jp < 2 ? lo4[2 * jp + 1] : hi4[2 * jp - 3]), 0));
-    unsigned hh, ll;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "s"(scale));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "s"(scale));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "s"(scale), "v"(hh));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "s"(scale), "v"(hh));
-    hp[jp] = hh;
-    lp[jp] = ll;
-  }
-  h = __builtin_bit_cast(h8, hp);
-  l = __builtin_bit_cast(h8, lp);
-#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float x = j < 4 ? lo4[j] : hi4[j - 4];
@@ -323,7 +302,6 @@ __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float
     h[j] = hh;
     l[j] = (_Float16)(v - (float)hh);
   }
-#endif
 }
 
 // publish relu(acc)/16 of this wave's 128-feature slice as B operands (k32 blocks 4w .. 4w+3) for all 4 column groups
@@ -409,69 +387,207 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
 #define DINER_HN_G0DEPTH 8
 #endif
 
-#ifndef DINER_HN_GSPLIT          // 1: a block's lin_z gather is spread over both GEMMs of the block before it; 0: all of it on fc_1
-#define DINER_HN_GSPLIT 0
+#ifndef DINER_HN_DEDUP           // 1: views whose 16 points touch <= 16 distinct texel rows fetch each row once (through LDS)
+#define DINER_HN_DEDUP 0
 #endif
 
+// What the gather needs from LDS, written by the frontend of each tile (wave g = view g writes its own group's part).
+struct TapShare {
+  const TapRec* taps;          // [g 4][col 16]   row offsets and blend weights of a column's four taps
+  const unsigned* tapidx;      // [g 4][col 16][4] byte offset (64 * index) of tap k's row in the view's list of distinct rows
+  const unsigned* urows;       // [g 4][16]        the view's distinct rows (valid when ucount[g] <= 16)
+  const int* ucount;           // [g 4]            number of distinct rows of the view
+  char* stage;                 // this wave's staging area: [slot 2][row 16][64 B]
+};
+
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
-// (g, mo) of 4 taps each; this object does units [U0, U0 + NU).  As a GEMM side task the NU units are spread over the GEMM's 128
-// quarter-steps (SP = 128 / NU slots per unit: taps requested in slots 0, SP/4, 2 SP/4, 3 SP/4), and a unit is blended / added in
-// the last slot of unit + GD - 1 (the additions commute with the GEMM's accumulation into the same registers; during a fc_0
-// GEMM, which accumulates into the other register block, xs was already published and is free to change).
-// Why spread over two GEMMs: the per-CU vector-memory path (64 B/clk) carries 1 MB of weights per GEMM (16.4 k cycles of the
-// GEMM's 24.6 k MFMA cycles) and a block's taps are another 0.5 MB -- on one GEMM that path is full.
-template <int GD, int U0 = 0, int NU = 32>
+// (g, mo) of 4 taps each.  As a GEMM side task one unit is started per half-step and blended / added GD - 1 half-steps later
+// (the additions commute with the GEMM's accumulation into the same registers).
+//
+// Two ways to get a unit's 16 columns x 4 taps x 64 B (16 features):
+//   * direct: every lane (q, column) loads its own 16 B of each tap -- four wave-wide loads, 4 KB through the vector-memory path
+//     whatever the taps are;
+//   * de-duplicated (view has <= 16 distinct rows in this tile, 88 % of the views of the benchmark frame -- consecutive samples
+//     of a ray project onto the same few texels, tools/tap_reuse.py): lane (row = lane / 4, c = lane % 4) loads 16 B of distinct
+//     row `row` ONCE (one wave-wide load, 1 KB), parks it in LDS, and the lanes then read their four taps from there.  The
+//     vector-memory path (64 B/clk per CU) is what bounds this kernel -- a GEMM streams 1 MB of weights through it in the 24.6 k
+//     clocks its MFMAs take, and a block's taps were another 0.5 MB -- while LDS has bandwidth to spare.
+// LDS operations of one wave execute in order, so write -> read of the staging area needs no barrier.
+// The choice is per tile (DEDUP: all four views qualify, 85 % of the benchmark frame's tiles), so that either side task is
+// straight-line code inside its GEMM.
+// one IEEE fp32 multiply / add as an opaque single instruction (see GatherSide::blend_step)
+__device__ __forceinline__ float mul1(float a, float b) {
+  float d;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float add1(float a, float b) {
+  float d;
+  asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+template <int GD, bool DEDUP, bool SIDE = true>
 struct GatherSide {
-  static constexpr int SP = 128 / NU;
-  static_assert(NU == 32 || NU == 16, "one or two quarter-steps per tap");
   const float* __restrict__ tz;
-  const TapRec* __restrict__ taps_lds;     // [g 4][col 16]
-  int wave, q, pt;
+  TapShare sh;
+  int wave, q, pt, lane;
   f32x4 (&xs)[kSlice][kGroups];
+  unsigned urow_off[kGroups];              // DEDUP: byte offset of this lane's distinct row (lane / 4, clamped) in the map
   f32x4 r[GD][4];
+  // This column's tap rows and blend weights per view, read from LDS one unit before the view's first unit: an LDS read
+  // right in front of its use (a tap offset per load, the weights per blend) parks the wave for the LDS latency with one MFMA
+  // in flight -- ~100 clocks in every quarter-step, which was most of what the side task cost.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 off4[kGroups];
+  f32x4 w4[kGroups];
+  template <int g>
+  __device__ __forceinline__ void prefetch() {
+    off4[g] = *reinterpret_cast<const u32x4*>(sh.taps[g * 16 + pt].off);
+    w4[g] = *reinterpret_cast<const f32x4*>(sh.taps[g * 16 + pt].w);
+  }
+
+  __device__ __forceinline__ GatherSide(const float* tz_, const TapShare& sh_, int wave_, int q_, int pt_, int lane_,
+                                        f32x4 (&xs_)[kSlice][kGroups])
+      : tz(tz_), sh(sh_), wave(wave_), q(q_), pt(pt_), lane(lane_), xs(xs_) {
+    prefetch<0>();
+    if constexpr (DEDUP) {
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        const int u = min(lane >> 2, sh.ucount[g] - 1);        // rows past the count: any valid one
+        urow_off[g] = sh.urows[g * 16 + u] * 2048u + (unsigned)((32 * wave + (lane & 3)) * 16);
+      }
+    }
+  }
+  // all four views of the tile have at most 16 distinct rows (wave-uniform; call after the barrier that publishes the taps)
+  static __device__ __forceinline__ bool tile_qualifies(const TapShare& sh) {
+#if DINER_HN_DEDUP
+    const int n = max(max(sh.ucount[0], sh.ucount[1]), max(sh.ucount[2], sh.ucount[3]));
+    return __builtin_amdgcn_readfirstlane(n) <= 16;
+#else
+    return false;
+#endif
+  }
   template <int U, int KTAP>       // one of the unit's four taps (the GEMM side task spreads them over the quarter-steps)
   __device__ __forceinline__ void issue_tap() {
     constexpr int g = U >> 3, mo = U & 7;
-    const unsigned off = taps_lds[g * 16 + pt].off[KTAP];
     const char* base = reinterpret_cast<const char*>(tz);          // scalar base + 32-bit lane offset + immediate
-    const unsigned lane_off = (32 * wave + q) * 16;
-    r[U % GD][KTAP] = *reinterpret_cast<const f32x4*>(base + (off * 2048u + lane_off) + mo * 64);
+    if constexpr (DEDUP) {
+      if constexpr (KTAP == 0) r[U % GD][0] = *reinterpret_cast<const f32x4*>(base + urow_off[g] + mo * 64);
+    } else {
+#ifdef DINER_HN_G_NOLOAD        // ablation: the side task without its loads
+      asm volatile("" : "+v"(r[U % GD][KTAP]));
+#else
+      const unsigned off = off4[g][KTAP];
+      const unsigned lane_off = (32 * wave + q) * 16;
+      r[U % GD][KTAP] = *reinterpret_cast<const f32x4*>(base + (off * 2048u + lane_off) + mo * 64);
+#endif
+    }
+  }
+  template <int U>                 // de-duplicated: the loaded rows go to LDS ...
+  __device__ __forceinline__ void stage() {
+    constexpr int g = U >> 3;
+    if constexpr (DEDUP) *reinterpret_cast<f32x4*>(sh.stage + (U & 1) * 1024 + lane * 16) = r[U % GD][0];
+  }
+  template <int U>                 // ... and come back as this lane's four taps
+  __device__ __forceinline__ void fetch() {
+    constexpr int g = U >> 3;
+    if constexpr (DEDUP) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 bo = *reinterpret_cast<const u32x4*>(sh.tapidx + (g * 16 + pt) * 4);
+      const char* mine = sh.stage + (U & 1) * 1024 + q * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[U % GD][k] = *reinterpret_cast<const f32x4*>(mine + bo[k]);
+    }
+  }
+  // The blend of a unit, one tap per quarter-step (K = 0..3) so that its vector-ALU work sits between the MFMAs of four
+  // quarter-steps instead of stalling the matrix pipe in one burst; same operations in the same order as
+  // (t0 w0 + t1 w1 + t2 w2 + t3 w3) * 16.
+  f32x4 bw, bv;
+  template <int U, int K>
+  __device__ __forceinline__ void blend_step() {
+    constexpr int g = U >> 3, mo = U & 7;
+    const f32x4 (&t)[4] = r[U % GD];
+#ifdef DINER_HN_G_NOBLEND       // ablation: the loads without the arithmetic
+    asm volatile("" :: "v"(t[K]));
+    return;
+#endif
+    if constexpr (K == 0) {
+      bw = w4[g];
+      // Keep w an opaque register value.  Without this the hipcc 7.2 build of an earlier version of this kernel returned
+      // wrong sums when the blend read its weights from LDS inside the GEMM (standalone it was fine;
+      // -amdgpu-waitcnt-forcezero, an extra s_waitcnt or this empty asm all cured it; LDS / VMEM return order checked in
+      // tools/ubench/{lds,vm}_order; see DESIGN.md "A hazard worth recording").
+      asm volatile("" : "+v"(bw));
+    }
+    if constexpr (SIDE) {
+      // Inside a GEMM: single-lane-width multiplies and adds only.  The compiler turns float4 arithmetic into v_pk_mul_f32 /
+      // v_pk_add_f32, and a packed-fp32 instruction does not overlap with the wave's MFMAs: each one costs a whole MFMA slot
+      // (+16 clocks, tools/ubench/mfma_valu.hip), ~450 of them per GEMM; v_mul_f32 / v_add_f32 issue in the MFMAs' shadow.
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float p = mul1(t[K][i], bw[K]);
+        bv[i] = K == 0 ? p : add1(bv[i], p);
+      }
+      if constexpr (K == 3) {
+        asm volatile("" : "+a"(xs[mo][g]));      // keep the accumulator file assignment: read, add, write back
+        f32x4 acc = xs[mo][g];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = add1(acc[i], mul1(bv[i], kScale));
+        xs[mo][g] = acc;
+        asm volatile("" : "+a"(xs[mo][g]));
+      }
+    } else {
+      if constexpr (K == 0) bv = t[0] * bw[0];
+      else bv = bv + t[K] * bw[K];
+      if constexpr (K == 3) {
+        const f32x4 v = bv * kScale;
+        asm volatile("" : "+a"(xs[mo][g]));
+        xs[mo][g] += v;
+        asm volatile("" : "+a"(xs[mo][g]));
+      }
+    }
   }
   template <int U>
   __device__ __forceinline__ void blend() {
-    constexpr int g = U >> 3, mo = U & 7;
-    f32x4 w = *reinterpret_cast<const f32x4*>(taps_lds[g * 16 + pt].w);
-    // Keep w an opaque register value.  Without this the hipcc 7.2 build of an earlier version of this kernel returned
-    // wrong sums when the blend read its weights from LDS inside the GEMM (standalone it was fine;
-    // -amdgpu-waitcnt-forcezero, an extra s_waitcnt or this empty asm all cured it; LDS / VMEM return order checked in
-    // tools/ubench/{lds,vm}_order; see DESIGN.md "A hazard worth recording").
-    asm volatile("" : "+v"(w));
-    const f32x4 (&t)[4] = r[U % GD];
-    const f32x4 v = (t[0] * w[0] + t[1] * w[1] + t[2] * w[2] + t[3] * w[3]) * kScale;
-    asm volatile("" : "+a"(xs[mo][g]));      // keep the accumulator file assignment: read, add, write back
-    xs[mo][g] += v;
-    asm volatile("" : "+a"(xs[mo][g]));
+    blend_step<U, 0>();
+    blend_step<U, 1>();
+    blend_step<U, 2>();
+    blend_step<U, 3>();
   }
-  // quarter-step s = 4 H + G of the GEMM
+  // half-step H: unit H's taps are requested, one per quarter-step, and unit V = H - GD + 1 is blended, one tap per quarter-step
+  // (de-duplicated: the one load in quarter 0; unit V is staged in quarter 0, fetched in quarter 1 and blended in quarter 3)
   template <int H, int G>
   __device__ __forceinline__ void run() {
 #ifndef DINER_HN_NO_GATHER
-    // one tap per slot (a smoother request stream for the vector-memory path: +2 % over four at once), the blend of unit
-    // u - GD + 1 in the last slot of unit u, at least SP quarter-steps after its last tap was requested (GD >= 2)
-    static_assert(GD >= 2, "the blend of a unit comes one unit after its last tap request");
-    constexpr int s = 4 * H + G, u = s / SP, slot = s % SP;
-    if constexpr (slot == SP - 1 && u - GD + 1 >= 0 && u - GD + 1 < NU) blend<U0 + (u - GD + 1 >= 0 ? u - GD + 1 : 0)>();
-    if constexpr (u < NU && slot % (SP / 4) == 0) issue_tap<U0 + (u < NU ? u : 0), slot / (SP / 4)>();
+    static_assert(GD >= 2, "the blend of a unit comes one half-step after its last tap request");
+    constexpr int V = H - GD + 1;
+    if constexpr (V >= 0 && V < 32) {
+      constexpr int VV = (V >= 0 && V < 32 ? V : 0);
+      if constexpr (DEDUP) {
+        if constexpr (G == 0) stage<VV>();
+        if constexpr (G == 1) fetch<VV>();
+        if constexpr (G == 3) blend<VV>();
+      } else {
+        blend_step<VV, G>();                 // tap G of unit V was requested in quarter G of half-step V: one half-step ago (GD = 2)
+      }
+    }
+    if constexpr (H < 32) issue_tap<(H < 32 ? H : 0), G>();
+    if constexpr (G == 1 && (H & 7) == 7 && H < 31) prefetch<(H < 31 ? (H + 1) >> 3 : 0)>();
 #endif
   }
   __device__ __forceinline__ void finish() {
 #ifndef DINER_HN_NO_GATHER
-    static_for<GD - 1>([&](auto I) { blend<U0 + NU + 1 - GD + decltype(I)::value>(); });
+    static_for<GD - 1>([&](auto I) {
+      constexpr int V = 33 - GD + decltype(I)::value;
+      stage<V>();
+      fetch<V>();
+      blend<V>();
+    });
 #endif
   }
   // stand-alone (no GEMM to hide under): block 0
   __device__ __forceinline__ void all() {
-    static_assert(NU == 32 && U0 == 0, "");
     static_for<32>([&](auto H) {
       run<decltype(H)::value, 0>();
       run<decltype(H)::value, 1>();
@@ -492,6 +608,11 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, pt = lane & 15;
   float* feat_src = reinterpret_cast<float*>(reinterpret_cast<char*>(feat_tab) + kFeatTabBytes) + wave * 64 * kSrcStride;
+  unsigned* tapidx_lds = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(taps_lds) + kTapRecBytes);
+  unsigned* urows_lds = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tapidx_lds) + kTapIdxBytes);
+  int* ucount_lds = reinterpret_cast<int*>(urows_lds + 4 * 16);
+  const TapShare share{taps_lds, tapidx_lds, urows_lds, ucount_lds,
+                       reinterpret_cast<char*>(smem) + (size_t)kBHalfs * 2 + kTapsBytes + kFeatTabBytes + kFeatSrcBytes + wave * 2048};
   const FieldArgs& fa = a.fa;
   if (threadIdx.x < 64) {      // recipe of (q, slot) = (threadIdx.x / 16, threadIdx.x % 16)
     const int sl = threadIdx.x & 15;
@@ -511,39 +632,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
     if (p >= fa.P) p = fa.P - 1;
     Taps taps;
     float feat[16];
-#ifdef DINER_HN_PROF_FRONT       // the frontend in four timed pieces (same arithmetic as field_frontend, rays + z source only)
-    {
-      float px, py, pz, dx, dy, dz;
-      load_point(fa, p, px, py, pz, dx, dy, dz);
-      asm volatile("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(dx), "+v"(dy), "+v"(dz));
-      pf.mark(15);
-      float xc[3], vd[3];
-      const int v = wave;
-      world_to_cam(sc.R[v], sc.t[v], px, py, pz, xc[0], xc[1], xc[2]);
-      vd[0] = rot_row(sc.R[v] + 0, dx, dy, dz);
-      vd[1] = rot_row(sc.R[v] + 3, dx, dy, dz);
-      vd[2] = rot_row(sc.R[v] + 6, dx, dy, dz);
-      const float u = project_axis(xc[0], xc[2], sc.focal[v][0], sc.c[v][0], sc.img_w);
-      const float w = project_axis(xc[1], xc[2], sc.focal[v][1], sc.c[v][1], sc.img_h);
-      const int ix = nearest_border(u, sc.Ws), iy = nearest_border(w, sc.Hs);
-      float dd = __fsub_rn(sc.depth[(size_t)v * sc.Hs * sc.Ws + (size_t)iy * sc.Ws + ix], xc[2]);
-      asm volatile("" : "+v"(dd));
-      pf.mark(16);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          feat[4 * m + r] = input_feature(16 * m + 4 * q + r, xc, vd, dd, fa.freq_factor);
-          asm volatile("" : "+v"(feat[4 * m + r]));
-        }
-      pf.mark(17);
-      bilinear_taps(sc, v, u, w, taps);
-      asm volatile("" : "+v"(taps.w[0]), "+v"(taps.w[3]));
-      pf.mark(18);
-    }
-#else
     frontend_h3n(sc, fa, /*view=*/wave, q, lane, p, feat_tab, feat_src, taps, feat);
-#endif
     pf.mark(0);
     __syncthreads();                              // previous tile's readers of B / taps are done
     pf.mark(1);
@@ -570,48 +659,50 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
         }
         taps_lds[wave * 16 + pt] = r;
       }
+#if DINER_HN_DEDUP
+      {   // distinct rows among this view's 64 taps: lane (q, column) speaks for tap q of its column
+        const unsigned o01 = q & 1 ? (unsigned)(taps.off[1] >> 9) : (unsigned)(taps.off[0] >> 9);
+        const unsigned o23 = q & 1 ? (unsigned)(taps.off[3] >> 9) : (unsigned)(taps.off[2] >> 9);
+        const unsigned mine = q & 2 ? o23 : o01;
+        int first = lane;                                   // lowest lane with the same row
+#pragma unroll
+        for (int j = 63; j >= 0; --j) first = (unsigned)__builtin_amdgcn_readlane((int)mine, j) == mine ? j : first;
+        const unsigned long long heads = __ballot(first == lane);
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(heads >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)heads, 0));
+        const int index = __shfl(below, first, 64);         // position of my row in the list = heads below my head
+        tapidx_lds[(wave * 16 + pt) * 4 + q] = (unsigned)(index & 15) * 64u;
+        if (first == lane && below < 16) urows_lds[wave * 16 + below] = mine;
+        if (lane == 0) ucount_lds[wave] = __popcll(heads);
+      }
+#endif
     }
     pf.mark(2);
     __syncthreads();
     pf.mark(3);
     f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
     set_bias(xs, a.b, wave, q);
+    const bool tile_dedup = GatherSide<2, true>::tile_qualifies(share);
     {
       NoSide none;
       gemm<2, 2, LO>(w_in, Bl, wave, lane, xs, none);
       pf.mark(4);
-      GatherSide<DINER_HN_G0DEPTH> g0{fa.tz, taps_lds, wave, q, pt, xs};  // lin_z[0]: nothing long enough to hide under yet
-      g0.all();
+      // lin_z[0]: nothing long enough to hide under yet
+      if (tile_dedup) {
+        GatherSide<DINER_HN_G0DEPTH, true, false> g0(fa.tz, share, wave, q, pt, lane, xs);
+        g0.all();
+      } else {
+        GatherSide<DINER_HN_G0DEPTH, false, false> g0(fa.tz, share, wave, q, pt, lane, xs);
+        g0.all();
+      }
       pf.mark(5);
     }
     for (int b = 0; b < 3; ++b) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
-#if DINER_HN_GSPLIT
-      {   // first half of the next block's lin_z gather rides on fc_0 (xs is published; ns is what this GEMM accumulates into)
-        const _Float16* w0 = w_blk + (size_t)(2 * b) * kLayerHalfs;
-        __syncthreads();                          // everybody finished reading the previous B
-        pf.mark(6);
-        publish<LO>(Bl, wave, lane, xs);
-        pf.mark(7);
-        __syncthreads();
-        pf.mark(8);
-        set_bias(ns, bias, wave, q);
-        if (b < 2) {
-          GatherSide<DINER_HN_GDEPTH, 0, 16> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
-          gemm<16, DINER_HN_RING0, LO>(w0, Bl, wave, lane, ns, gs);
-        } else {
-          NoSide none;
-          gemm<16, DINER_HN_RING0, LO>(w0, Bl, wave, lane, ns, none);
-        }
-        pf.mark(9);
-      }
-#else
       {
         NoSide none;
         publish_gemm<DINER_HN_RING0, LO>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none,
                                          [&] { set_bias(ns, bias, wave, q); }, pf, 6);
       }
-#endif
       const _Float16* w1 = w_blk + (size_t)(2 * b + 1) * kLayerHalfs;
       __syncthreads();
       pf.mark(10);
@@ -620,12 +711,11 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       __syncthreads();
       pf.mark(12);
       add_bias(xs, bias + kHidden, wave, q);
-      if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
-#if DINER_HN_GSPLIT
-        GatherSide<DINER_HN_GDEPTH, 16, 16> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
-#else
-        GatherSide<DINER_HN_GDEPTH> gs{fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs};
-#endif
+      if (b < 2 && tile_dedup) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
+        GatherSide<DINER_HN_GDEPTH, true> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, share, wave, q, pt, lane, xs);
+        gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, gs);
+      } else if (b < 2) {
+        GatherSide<DINER_HN_GDEPTH, false> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, share, wave, q, pt, lane, xs);
         gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, gs);
       } else {
         NoSide none;
