@@ -236,10 +236,9 @@ __device__ __forceinline__ void load_point(const FieldArgs& a, long long p, floa
 
 // bilinear / border taps of view v on the padded feature map at normalised image position (u, w)
 // (image_encoder.py:112-123)
-__device__ __forceinline__ void bilinear_taps(const SceneDev& sc, int v, float u, float w, Taps& taps) {
-  const int Wf = sc.Wf, Hf = sc.Hf;
-  const float su = __fmul_rn(u, __fdiv_rn(__fsub_rn((float)Wf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Wf));
-  const float sv = __fmul_rn(w, __fdiv_rn(__fsub_rn((float)Hf, __fmul_rn(sc.feature_padding, 2.0f)), (float)Hf));
+__device__ __forceinline__ void bilinear_taps(int Wf, int Hf, float feature_padding, int v, float u, float w, Taps& taps) {
+  const float su = __fmul_rn(u, __fdiv_rn(__fsub_rn((float)Wf, __fmul_rn(feature_padding, 2.0f)), (float)Wf));
+  const float sv = __fmul_rn(w, __fdiv_rn(__fsub_rn((float)Hf, __fmul_rn(feature_padding, 2.0f)), (float)Hf));
   const float fx = clip_border(unnormalize(su, Wf), Wf), fy = clip_border(unnormalize(sv, Hf), Hf);
   const float x0f = floorf(fx), y0f = floorf(fy);
   const float wx = fx - x0f, wy = fy - y0f;
@@ -254,6 +253,9 @@ __device__ __forceinline__ void bilinear_taps(const SceneDev& sc, int v, float u
   taps.w[1] = (1.0f - wy) * wx;
   taps.w[2] = wy * (1.0f - wx);
   taps.w[3] = wy * wx;
+}
+__device__ __forceinline__ void bilinear_taps(const SceneDev& sc, int v, float u, float w, Taps& taps) {
+  bilinear_taps(sc.Wf, sc.Hf, sc.feature_padding, v, u, w, taps);
 }
 
 // Everything per (sample point, view) that precedes the MLP: world->camera transform, projection, nearest depth tap,
