@@ -17,7 +17,8 @@ namespace diner {
 namespace train {
 
 constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
-enum : int { kTA = 1, kTB = 2, kReluA = 4, kReluB = 8, kAccum = 16, kAtomic = 32, kExact = 64 };
+enum : int { kTA = 1, kTB = 2, kReluA = 4, kReluB = 8, kAccum = 16, kAtomic = 32, kExact = 64,
+             kNoXcdOrder = 128 /* internal: plain blockIdx tile order (A/B measurement, DINER_TRAIN_NO_XCD=1) */ };
 
 struct GemmArgs {
   const float* A;       // op(A) is M x K: stored [M][lda] (or [K][lda] with kTA)
@@ -271,6 +272,11 @@ constexpr int XM = 128, XN = 128, XK = 32;
 constexpr int kPlaneElems = 2 * 2 * 128 * 8;          // bf16 elements of one plane of one operand tile (8 KB)
 
 __device__ __forceinline__ void split3(const float (&v)[8], bf8& p0, bf8& p1, bf8& p2) {
+#ifdef DINER_BF16X6_NOSPLIT      // ablation (wrong results): what the on-the-fly split costs
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p0[j] = p1[j] = p2[j] = (__bf16)v[j];
+  return;
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const __bf16 a0 = (__bf16)v[j];
@@ -355,9 +361,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) __bf16 As[3 * kPlaneElems], Bs[3 * kPlaneElems];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const long long m0 = (long long)blockIdx.y * XM;
-  const int n0 = blockIdx.x * XN;
-  const int kbeg = blockIdx.z * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by their linear id, so the (up to four) N-tiles that share
+  // a 128-row block of A -- consecutive ids -- would land on different XCDs and each pull that block through its own L2.  Remap:
+  // the workgroups of XCD x take the x-th eighth of the tile list, in order, so tiles that share operands run on one XCD at
+  // about the same time (split-K: the 16 tiles of a K chunk share both operand slices).
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    if (!(g.flags & kNoXcdOrder) && (total & 7) == 0) {
+      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const unsigned logical = (lin & 7) * (total >> 3) + (lin >> 3);
+      bx = logical % gridDim.x;
+      by = (logical / gridDim.x) % gridDim.y;
+      bz = logical / (gridDim.x * gridDim.y);
+    }
+  }
+  const long long m0 = (long long)by * XM;
+  const int n0 = bx * XN;
+  const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
   const bool ta = g.flags & kTA, tb = g.flags & kTB, ra = g.flags & kReluA, rb = g.flags & kReluB;
   // op(A) is M x K: stored [M][lda] (contraction contiguous) unless kTA; op(B) is K x N: stored [K][ldb] (output contiguous) unless kTB
   const bool a_kc = !ta, b_kc = tb;
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + 64 * wn + 32 * j + (lane & 31);
       if (n >= g.N) continue;
-      const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
+      const float bias = (g.bias && bz == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const long long m = m0 + 64 * wm + 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
@@ -607,9 +628,12 @@ static int gemm_launch(const float* A, const float* B, float* C, long long M, in
   DINER_CHECK_ARG(!((flags & kAtomic) && mask), "gemm: a relu mask cannot be combined with atomic accumulation");
   int chunk = (K + k_split - 1) / k_split;
   chunk = (chunk + XK - 1) / XK * XK;               // (a multiple of every kernel's k-tile)
+  static const bool no_xcd = [] { const char* e = getenv("DINER_TRAIN_NO_XCD"); return e && *e == '1'; }();
+  if (no_xcd) flags |= kNoXcdOrder;
   GemmArgs g{A, B, C, bias, mask, M, N, K, lda, ldb, ldc, flags, chunk};
-  if (!(flags & kExact) && N >= 64 && M >= XM && K >= XK) {
-    // layer-sized products: split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6)
+  if (!(flags & kExact)) {
+    // split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6); ragged and skinny shapes (lin_out: N = 4,
+    // its adjoints: K = 4 / M = 4) ride along zero-padded -- a partly empty 128 x 128 tile is still faster than the fp32 kernels
     const dim3 grid((N + XN - 1) / XN, (unsigned)((M + XM - 1) / XM), (K + chunk - 1) / chunk);
     hipLaunchKernelGGL(k_gemm_bf16x6, grid, dim3(256), 0, stream, g);
   } else if (N >= BN2 && M >= BM2) {
@@ -733,8 +757,13 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
                long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st) {
   DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
   DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
-  long long split = M / 1024;
-  split = split < 1 ? 1 : (split > 32 ? 32 : split);
+  // split-K so that the 16 output tiles of a 512 x 512 weight gradient become 500-1000 workgroups of >= 15 k-tiles each (measured:
+  // 128 / 512 / 2048-ray steps 5.70 / 15.6 / 53.1 ms with M / 1024 capped at 32, 5.07 / 14.5 / 51.8 ms with M / 480 capped at 64);
+  // DINER_TRAIN_WGRAD_ROWS / _CAP override (measurement aid)
+  static const long long rows_per_chunk = [] { const char* e = getenv("DINER_TRAIN_WGRAD_ROWS"); return e ? atoll(e) : 480LL; }();
+  static const long long cap = [] { const char* e = getenv("DINER_TRAIN_WGRAD_CAP"); return e ? atoll(e) : 64LL; }();
+  long long split = M / rows_per_chunk;
+  split = split < 1 ? 1 : (split > cap ? cap : split);
   int rc = gemm_launch(dy, x, dW, N, K, M, ldy, ldx, K, kTA | kAtomic | (relu_in ? kReluB : 0), nullptr, nullptr, (int)split, st);
   if (rc) return rc;
   long long gy = (M + 255) / 256;

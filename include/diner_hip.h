@@ -202,10 +202,10 @@ int diner_colormap_u8(const float* x, long long n, const unsigned char* lut_u8, 
  * General fp32 GEMM on the matrix cores, C (M x N, row stride ldc) = op(A) (M x K) . op(B) (K x N), row-major:
  *   flags: 1 A is stored K x M, 2 B is stored N x K (torch Linear weights: y = x W^T), 4 / 8 relu applied to A / B while
  *   loading, 16 C += result, 32 atomicAdd into C (required for k_split > 1: weight gradients reduce over ~1e4 rows),
- *   64 exact fp32 MFMA products for every shape.  Without flag 64, layer-sized products (M >= 128, N >= 64, K >= 32) run as
- *   "bf16x6": each fp32 operand is split into three bf16 terms and the six products above 2^-24 are accumulated in fp32 on the
- *   bf16 MFMA (2.6x the fp32 MFMA peak; bf16 has fp32's exponent range, so no scaling and no range limits) -- products as
- *   accurate as fp32 rounding itself; smaller products always use the fp32 MFMA;
+ *   64 exact fp32 MFMA products.  Without flag 64 the product runs as "bf16x6": each fp32 operand is split into three bf16
+ *   terms and the six products above 2^-24 are accumulated in fp32 on the bf16 MFMA (2.6x the fp32 MFMA peak; bf16 has fp32's
+ *   exponent range, so no scaling and no range limits) -- products as accurate as fp32 rounding itself (ragged and skinny
+ *   shapes ride along in zero-padded 128 x 128 x 32 tiles);
  *   bias (N) added to every row, mask (M x N, stride ldc): C = 0 where mask <= 0 (relu adjoint). */
 int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc, int flags,
                    const float* bias, const float* mask, int k_split, void* stream);

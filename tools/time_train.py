@@ -7,7 +7,8 @@ from diner_amd import ops
 sc, nerf, R, rays = setup_model(64, 64, 0)
 nerf.train()
 nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
-for NR in (128, 512, 2048):
+SIZES = [int(a) for a in sys.argv[1:]] or [128, 512, 2048]
+for NR in SIZES:
     K, G = 40, 15
     r = rays[torch.linspace(0, rays.shape[0] - 1, NR).long()].cuda()[None]
     ren = R(n_samples=K, n_depth_candidates=1000, n_gaussian=G, white_bkgd=True)
