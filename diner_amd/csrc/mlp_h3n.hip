@@ -200,8 +200,10 @@ struct NoSide {
 #ifndef DINER_HN_EARLYA
 #define DINER_HN_EARLYA 1
 #endif
-// The weight ring of one GEMM.  start() issues the first R-1 half-steps; it is called BEFORE the hidden state is published
-// (the barriers in between wait on LDS traffic only, not on vmcnt), so the first fragments arrive while the conversion runs.
+// The weight ring of one GEMM.  start() issues the first R-1 half-steps; on the fc_0 GEMMs it is called BEFORE the hidden state
+// is published (the barriers in between wait on LDS traffic only, not on vmcnt), so the first fragments arrive while the
+// conversion runs.  (On the fc_1 GEMMs every way of doing the same -- ring started ahead of the gather / no-gather branch, or
+// only in the no-gather arm with its own publish -- made the allocator spill 30-130 registers inside the GEMM: not done.)
 template <int KT, int R, bool LO>
 struct ARing {
   typedef const __attribute__((address_space(1))) char* gptr;      // stays a global (not flat) access through the asm
@@ -629,6 +631,7 @@ struct PostArgsN {
   PostArgs pa;
   const _Float16* w;        // n-split packed fc_0 / fc_1 of blocks 3, 4 (4 layers of 4 * 16 * 16 KB)
   const _Float16* w_out;    // lin_out fragments [t 16][hl 2][lane 64][8] (rows >= 4 zero), x16
+  unsigned long long* prof; // DINER_HN_PROF builds: phase counters, else unused
 };
 
 // Blocks 3-4 + lin_out + output activations on the view-averaged hidden state, same feature-sliced scheme: a
@@ -646,6 +649,8 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
   const long long n_tiles = (n_t16 + 3) / 4;
   constexpr size_t kLayerHalfs = (size_t)4 * 16 * 8192;
 
+  Prof pf;
+  pf.begin();
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
 #pragma unroll
@@ -657,8 +662,8 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       for (int mo = 0; mo < kSlice; ++mo) xs[mo][g] = in[(8 * wave + mo) * 64] * kScale;
     }
     NoSide none;
-    Prof pf;                                      // not reported for this kernel
-    pf.begin();
+    pin_acc(xs);
+    pf.mark(8);
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
       const float* bias = pa.b_post + 2 * kHidden * b;
@@ -674,6 +679,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     __syncthreads();
     publish<LO>(Bl, wave, lane, xs);
     __syncthreads();
+    pf.mark(9);
     {
       typedef const __attribute__((address_space(1))) h8* gh8;
       gh8 wo = (gh8)(reinterpret_cast<const h8*>(a.w_out) + lane);
@@ -697,6 +703,8 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
         }
       }
       f32x4 res = ((o[0] + o[1]) + (o[2] + o[3])) * kInvScale;
+      asm volatile("" : "+v"(res));
+      pf.mark(10);
       res += *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 4 * q);       // lin_out bias kept at scale 1
       const long long t16 = tile * 4 + wave;
       const long long p = t16 * kPtsPerWave + pt;
@@ -714,7 +722,9 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
         reinterpret_cast<f32x4*>(pa.out)[p] = res;
       }
     }
+    pf.mark(11);
   }
+  pf.end(a.prof, lane);
 }
 
 // layer packing: [w 4][t KT][mo 8][hl 2][lane 64][8]: W[128 w + 16 mo + (lane&15)][32 t + 16 (j>>2) + 4 (lane>>4) + (j&3)] * scale
@@ -834,9 +844,26 @@ void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, con
 void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out, int grid, bool split, hipStream_t stream) {
   const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
   const _Float16* wo = (const _Float16*)w_lin_out;
-  h3n::PostArgsN a{pa, wn, wo};
+  h3n::PostArgsN a{pa, wn, wo, nullptr};
+#ifdef DINER_HN_PROF
+  static unsigned long long* prof = nullptr;
+  if (!prof) hipMalloc(&prof, 32 * sizeof(unsigned long long));
+  hipMemsetAsync(prof, 0, 32 * sizeof(unsigned long long), stream);
+  a.prof = prof;
+#endif
   if (split) hipLaunchKernelGGL(h3n::k_field_post_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
   else hipLaunchKernelGGL(h3n::k_field_post_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
+#ifdef DINER_HN_PROF
+  unsigned long long h[32];
+  hipStreamSynchronize(stream);
+  hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+  static const char* names[12] = {"fc_0 sync A", "fc_0 publish", "fc_0 sync B", "fc_0 gemm", "fc_1 sync A", "fc_1 publish", "fc_1 sync B",
+                                  "fc_1 gemm", "hand-over load", "lin_out publish", "lin_out MFMAs", "epilogue"};
+  const double waves = (double)h[26], tot = (double)h[24];
+  fprintf(stderr, "[h3n prof post] waves %.0f  clocks/wave %.0f  shader MHz %.0f  (P=%lld)\n", waves, tot / waves,
+          tot / ((double)h[25] / 100.0), pa.P);
+  for (int i = 0; i < 12; ++i) fprintf(stderr, "[h3n prof post]   %-20s %6.2f %%  %10.0f clk/wave\n", names[i], 100.0 * h[i] / tot, h[i] / waves);
+#endif
 }
 
 }  // namespace diner
