@@ -200,9 +200,10 @@ struct NoSide {
 #ifndef DINER_HN_EARLYA
 #define DINER_HN_EARLYA 1
 #endif
-// The weight ring of one GEMM.  start() issues the first R-1 half-steps; on the fc_0 GEMMs it is called BEFORE the hidden state
-// is published (the barriers in between wait on LDS traffic only, not on vmcnt), so the first fragments arrive while the
-// conversion runs.  (On the fc_1 GEMMs every way of doing the same -- ring started ahead of the gather / no-gather branch, or
+// The weight ring of one GEMM.  start() issues the first R-1 half-steps; on the per-view kernel's fc_0 GEMMs it is called BEFORE
+// the hidden state is published (the barriers in between wait on LDS traffic only, not on vmcnt), so the first fragments arrive
+// while the conversion runs -- neutral there (61.58 M vs 61.71 M clocks per wave); in the post kernel the same costs 5 % (the
+// loads issued in front of the barrier hold the wave for ~4 k clocks, profiles/r02c_phase_timer_post_kernel.txt), so not there.  (On the fc_1 GEMMs every way of doing the same -- ring started ahead of the gather / no-gather branch, or
 // only in the no-gather arm with its own publish -- made the allocator spill 30-130 registers inside the GEMM: not done.)
 template <int KT, int R, bool LO>
 struct ARing {
@@ -334,14 +335,12 @@ __device__ __forceinline__ void publish(LdsB B, int wave, int lane, const f32x4 
 }
 
 // hidden state -> B operands, then the GEMM of `layer` on them: barrier, publish, barrier, GEMM, with the weight ring started first
-template <int R, bool LO, class Side, class Between>
+template <int R, bool LO, bool EARLY, class Side, class Between>
 __device__ __forceinline__ void publish_gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
                                              const f32x4 (&src)[kSlice][kGroups], f32x4 (&acc)[kSlice][kGroups], Side& side,
                                              Between&& between, Prof& pf, int ph) {
   ARing<16, R, LO> ring;
-#if DINER_HN_EARLYA
-  ring.start(layer, wave, lane);
-#endif
+  if constexpr (EARLY) ring.start(layer, wave, lane);
   __syncthreads();                                // everybody finished reading the previous B
   pf.mark(ph);
   publish<LO>(B, wave, lane, src);
@@ -349,9 +348,7 @@ __device__ __forceinline__ void publish_gemm(const _Float16* __restrict__ layer,
   __syncthreads();
   pf.mark(ph + 2);
   between();                                      // bias of the accumulators the GEMM adds into
-#if !DINER_HN_EARLYA
-  ring.start(layer, wave, lane);
-#endif
+  if constexpr (!EARLY) ring.start(layer, wave, lane);
   gemm<16, R, LO>(ring, B, acc, side);
   pf.mark(ph + 3);
 }
@@ -597,7 +594,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
       {
         NoSide none;
-        publish_gemm<DINER_HN_RING0, LO>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none,
+        publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYA != 0>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none,
                                          [&] { set_bias(ns, bias, wave, q); }, pf, 6);
       }
       const _Float16* w1 = w_blk + (size_t)(2 * b + 1) * kLayerHalfs;
@@ -667,15 +664,17 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
       const float* bias = pa.b_post + 2 * kHidden * b;
-      publish_gemm<DINER_HN_RING0, LO>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
+      publish_gemm<DINER_HN_RING0, LO, false>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
         set_bias(ns, bias, wave, q);
         pin_acc(xs);                              // the residual stream stays in registers across the fc_0 GEMM
       }, pf, 0);
       pin_acc(xs);
-      publish_gemm<DINER_HN_RING, LO>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
+      publish_gemm<DINER_HN_RING, LO, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
                                       [&] { add_bias(xs, bias + kHidden, wave, q); }, pf, 4);
     }
     // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
+    // (requesting its 32 weight fragments before the publish moves 4 k clocks from here into the publish and the next tile's
+    // hand-over load: measured, no net gain)
     __syncthreads();
     publish<LO>(Bl, wave, lane, xs);
     __syncthreads();
