@@ -85,6 +85,9 @@ __global__ void k_pack_lin_out(const float* __restrict__ W, int rows, int cols, 
     dst[i] = (row < rows && col < cols) ? W[(size_t)row * cols + col] : 0.0f;
   }
 }
+__global__ void k_add_vec(const float* __restrict__ src, int n, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = dst[i] + src[i];
+}
 __global__ void k_copy_pad(const float* __restrict__ src, int n, int n_pad, float* __restrict__ dst) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x)
     dst[i] = i < n ? src[i] : 0.0f;
@@ -723,18 +726,26 @@ static int mlp_pack(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& i
   auto bias = [&](const float* b, int n, int n_pad, float* dst) {
     hipLaunchKernelGGL(k_copy_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, dst);   // (biases stay fp32 in every mode)
   };
+  for (int b = 0; b < 3; ++b) bias(p->lin_z_b[b], kHidden, kHidden, im.b_hoist + kHidden * b);
   float* wp = im.w_pre;
   pack(p->lin_in_w, kHidden, kDIn, 1, wp);
   wp += 4 * kStageFloats;
   bias(p->lin_in_b, kHidden, kHidden, im.b_pre);
   for (int b = 0; b < 3; ++b) {
     pack(p->lin_z_w[b], kHidden, kLatent, 8, im.w_hoist + (size_t)b * kStagesPerLayer * kStageFloats);
-    bias(p->lin_z_b[b], kHidden, kHidden, im.b_hoist + kHidden * b);
     pack(p->fc0_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
     pack(p->fc1_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
     float* bb = im.b_pre + kHidden * (1 + 2 * b);
     bias(p->fc0_b[b], kHidden, kHidden, bb);
-    bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
+    // x_(b+1) = x_b + fc_1(..) + b1[b] + interp(lin_z[b+1](latent) + bz[b+1]): the two constants of blocks 0 and 1 travel together
+    // in the projected map of the NEXT block (the interpolation weights sum to one), so the per-view kernels have no separate
+    // fc_1 bias pass for those blocks -- a read-modify-write of a whole accumulator block per GEMM in the feature-sliced kernel
+    if (b < 2) {
+      DINER_HIP_OK(hipMemsetAsync(bb + kHidden, 0, kHidden * sizeof(float), stream));
+      hipLaunchKernelGGL(k_add_vec, dim3(2), dim3(256), 0, stream, p->fc1_b[b], kHidden, im.b_hoist + kHidden * (b + 1));
+    } else {
+      bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
+    }
   }
   wp = im.w_post;
   for (int b = 3; b < 5; ++b) {

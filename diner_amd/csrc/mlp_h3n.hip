@@ -604,11 +604,12 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       pf.mark(11);
       __syncthreads();
       pf.mark(12);
-      add_bias(xs, bias + kHidden, wave, q);
-      if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute)
+      pin_acc(xs);
+      if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute); this block's fc_1
+                       // bias comes with it (folded into the projected map's bias when the weights are packed, mlp.hip)
         GatherSide<DINER_HN_GDEPTH> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
         gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, gs);
-      } else {
+      } else {         // (block 2's fc_1 bias is added by the post kernel)
         NoSide none;
         gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, none);
       }
@@ -656,7 +657,10 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       if (t16 >= n_t16) t16 = n_t16 - 1;
       const f32x4* in = reinterpret_cast<const f32x4*>(pa.xpre) + (size_t)t16 * (kTiles * 64) + lane;
 #pragma unroll
-      for (int mo = 0; mo < kSlice; ++mo) xs[mo][g] = in[(8 * wave + mo) * 64] * kScale;
+      for (int mo = 0; mo < kSlice; ++mo) {     // + block 2's fc_1 bias (x16), which the per-view kernel leaves to this one
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 16 + 128 * wave + 16 * mo + 4 * q);
+        xs[mo][g] = in[(8 * wave + mo) * 64] * kScale + b2;
+      }
     }
     NoSide none;
     pin_acc(xs);
@@ -766,20 +770,23 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
   DINER_HIP_OK(hipMalloc(w_out, halfs * sizeof(_Float16)));
   DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16)));
   DINER_HIP_OK(hipMalloc(b_pre, 7 * kHidden * sizeof(float)));
-  DINER_HIP_OK(hipMalloc(b_post, (4 * kHidden + 16) * sizeof(float)));
+  DINER_HIP_OK(hipMalloc(b_post, (5 * kHidden + 16) * sizeof(float)));
   auto bias = [&](const float* b, int n, int n_pad, float scale, float* dst) {
     hipLaunchKernelGGL(k_scale_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, scale, dst);
   };
   bias(p->lin_in_b, kHidden, kHidden, kScale, *b_pre);
   for (int b = 0; b < 3; ++b) {
     bias(p->fc0_b[b], kHidden, kHidden, kScale, *b_pre + kHidden * (1 + 2 * b));
-    bias(p->fc1_b[b], kHidden, kHidden, kScale, *b_pre + kHidden * (2 + 2 * b));
+    // the fc_1 biases are not added by the per-view kernel: those of blocks 0 and 1 travel in the next block's projected map (see
+    // mlp_pack), block 2's is added by the post kernel to the view mean it takes over (the mean of x + b is mean(x) + b)
+    bias(p->fc1_b[b], kHidden, kHidden, 0.0f, *b_pre + kHidden * (2 + 2 * b));
   }
   for (int b = 3; b < 5; ++b) {
     bias(p->fc0_b[b], kHidden, kHidden, kScale, *b_post + 2 * kHidden * (b - 3));
     bias(p->fc1_b[b], kHidden, kHidden, kScale, *b_post + 2 * kHidden * (b - 3) + kHidden);
   }
   bias(p->lin_out_b, 4, 16, 1.0f, *b_post + 4 * kHidden);
+  bias(p->fc1_b[2], kHidden, kHidden, kScale, *b_post + 4 * kHidden + 16);
   hipLaunchKernelGGL(k_pack_lin_out_h3n, dim3(64), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, kScale,
                      (_Float16*)*w_lin_out);
   _Float16* wp = (_Float16*)*w_out;

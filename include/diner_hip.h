@@ -36,7 +36,10 @@ extern "C" {
 typedef struct DinerScene {
   const float* latent_cl;   /* (NV, Hf, Wf, C)  feature map, CHANNELS-LAST (re-laid-out once per encode) */
   const float* latent_proj; /* (3, NV, Hf, Wf, C) lin_z[b](latent)+bias, written by diner_scene_prepare_f32; the field
-                               entry points gather from these maps (resnetfc.py:153-155 hoisted out of the sample loop) */
+                               entry points gather from these maps (resnetfc.py:153-155 hoisted out of the sample loop).
+                               Maps 1 and 2 also carry the fc_1 bias of the block before them (the two constants are added to
+                               the residual stream at the same point): opaque to the caller, valid for the MLP handle that
+                               prepared them */
   const float* depth;       /* (NV, Hs, Ws)     source depth maps, 0 = background                          */
   const float* depth_std;   /* (NV, Hs, Ws)     depth standard deviation                                    */
   const float* normals;     /* (NV, 3, Hs, Ws)  normal maps (planar, as produced by depth2normal)          */
