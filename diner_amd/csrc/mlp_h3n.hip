@@ -9,7 +9,12 @@
 //     each A fragment feeds 4 column groups x {hi,lo}: 12 MFMAs per (hi, lo) fragment pair;
 //   * activations are exchanged between layers through a 128 KB LDS buffer already in B-operand form (fp16 hi / lo,
 //     1/16 scale folded in): every wave converts its 128-feature slice, two barriers per layer;
-//   * the view mean is a register sum over the four column groups.
+//   * the view mean is a register sum over the four column groups;
+//   * no bias pass on the residual stream in the per-view kernel: the fc_1 biases of blocks 0 and 1 travel in the bias of the next
+//     block's projected map (mlp.hip, mlp_pack), block 2's is added by the post kernel to the view mean it takes over.
+// Measuring stick: -DDINER_HN_PROF builds book shader clocks per phase of the tile loop (tools/prof_phases.sh); what was learnt
+// with it is in profiles/r02_kernel_experiments.md (round 2c) -- in short: no LDS read right in front of its use inside a GEMM,
+// no packed-fp32 arithmetic between MFMAs, nothing lane-varying in the front end's control flow.
 // (Round 1 also had an LDS-streamed-weights variant of the same arithmetic, mlp_h3.hip; it lost to this one on every
 // measurement -- 166.7 k vs 212.5 k rays/s, profiles/r01_v4_* vs r01_v8_* -- and was retired.)
 #include <utility>
@@ -396,6 +401,11 @@ __device__ __forceinline__ float add1(float a, float b) {
   asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
 // (g, mo) of 4 taps each.  As a GEMM side task (SIDE) one unit's taps are requested per half-step, one per quarter-step, and
@@ -427,7 +437,7 @@ struct GatherSide {
   template <int g>
   __device__ __forceinline__ void prefetch() {
     off4[g] = *reinterpret_cast<const u32x4*>(taps_lds[g * 16 + pt].off);
-    w4[g] = *reinterpret_cast<const f32x4*>(taps_lds[g * 16 + pt].w);
+    w4[g] = *reinterpret_cast<const f32x4*>(taps_lds[g * 16 + pt].w) * kScale;      // the accumulators hold 16 x the activations
   }
   template <int U, int KTAP>       // one of the unit's four taps (the GEMM side task spreads them over the quarter-steps)
   __device__ __forceinline__ void issue_tap() {
@@ -440,7 +450,7 @@ struct GatherSide {
     r[U % GD][KTAP] = *reinterpret_cast<const f32x4*>(base + (off4[g][KTAP] * 2048u + lane_off) + mo * 64);
 #endif
   }
-  // tap K's share of the blend: same operations in the same order as (t0 w0 + t1 w1 + t2 w2 + t3 w3) * 16
+  // tap K's share of the blend sum_k t_k (16 w_k)
   template <int U, int K>
   __device__ __forceinline__ void blend_step() {
     constexpr int g = U >> 3, mo = U & 7;
@@ -457,27 +467,25 @@ struct GatherSide {
       // tools/ubench/{lds,vm}_order; see DESIGN.md "A hazard worth recording").
       asm volatile("" : "+v"(bw));
     }
+    // sum_k t_k (16 w_k) as one multiply and three fused multiply-adds per value (the exact-fp32 kernels keep the reference's
+    // separate roundings; this arithmetic mode is within 1e-6 of them either way)
     if constexpr (SIDE) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float p = mul1(t[K][i], bw[K]);
-        bv[i] = K == 0 ? p : add1(bv[i], p);
-      }
+      for (int i = 0; i < 4; ++i) bv[i] = K == 0 ? mul1(t[0][i], bw[0]) : fma1(t[K][i], bw[K], bv[i]);
       if constexpr (K == 3) {
         asm volatile("" : "+a"(xs[mo][g]));      // keep the accumulator file assignment: read, add, write back
         f32x4 acc = xs[mo][g];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = add1(acc[i], mul1(bv[i], kScale));
+        for (int i = 0; i < 4; ++i) acc[i] = add1(acc[i], bv[i]);
         xs[mo][g] = acc;
         asm volatile("" : "+a"(xs[mo][g]));
       }
     } else {
       if constexpr (K == 0) bv = t[0] * bw[0];
-      else bv = bv + t[K] * bw[K];
+      else bv = __builtin_elementwise_fma(t[K], (f32x4){bw[K], bw[K], bw[K], bw[K]}, bv);
       if constexpr (K == 3) {
-        const f32x4 v = bv * kScale;
         asm volatile("" : "+a"(xs[mo][g]));
-        xs[mo][g] += v;
+        xs[mo][g] += bv;
         asm volatile("" : "+a"(xs[mo][g]));
       }
     }
