@@ -175,6 +175,14 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
         assert len(idx) > 1500
         spills = [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
         assert not spills, f"{m.group(1)}: {len(spills)} scratch accesses inside the GEMM span, e.g. {spills[:3]}"
+        # second guard (round 2c): no packed-fp32 arithmetic between MFMAs.  v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 do not
+        # overlap with the wave's MFMAs (each costs a whole MFMA slot, tools/ubench/mfma_valu.hip); the in-GEMM gather blend is
+        # written in single-width instructions for that reason, and a change that lets the compiler re-vectorise it shows up here
+        packed = [i for i, l in enumerate(body) if re.match(r"\s*v_pk_(mul|add|fma)_f32", l)]
+        import bisect
+        inside = [i for i in packed if 0 < bisect.bisect(idx, i) < len(idx)
+                  and i - idx[bisect.bisect(idx, i) - 1] < 30 and idx[bisect.bisect(idx, i)] - i < 30]
+        assert len(inside) <= 4, f"{m.group(1)}: {len(inside)} packed-fp32 instructions inside MFMA streams"
     # the post kernel (blocks 3-4 + lin_out) has no front end: no scratch at all, and its MFMAs stay interleaved with
     # the operand loads (an optimiser that sinks the accumulation chains below the loads shows up as spills)
     for m in post:
