@@ -12,7 +12,10 @@ re-implementing PIL's fixed-point bicubic resampler would be the only way to sta
 IO outside the hot path.  Without PIL the images are decoded by the package's PNG reader and averaged 2x2 (stated in the
 returned dict as `rgb_resample`).
 
-Not built: the Facescape / Multiface classes (same schema, different file trees) and the Lightning DataModule.
+`FacescapeSamples` does the same for the Facescape capture layout (reference src/data/facescape.py): view selection into the
+cached sample list ("metas"), the sample dict, the sweep path.
+
+Not built: the Multiface class (same schema, another file tree) and the Lightning DataModule.
 """
 import os
 from itertools import product
@@ -128,6 +131,177 @@ class DTUSamples:
         from .sweep import sweep_extrinsics
         E = self.cam_dict["extrinsics"]
         return sweep_extrinsics(E[11], E[24], E[18], nframes)
+
+
+class FacescapeSamples:
+    """Sample dicts from a Facescape tree  root/<subject>/<frame 01..20>/{cameras.json, 3dlmks.npy, view_<id>/{rgba_colorcalib.png,
+    depth_TransMVSNet.png, depth_TransMVSNet_conf.png}}  (facescape.py:18-61).
+
+    The sample list is the reference's: per scan, four ideal reference directions at (+-range_hor, +-range_vert) around the frontal
+    axis (0, -1, 0), slid in azimuth by multiples of slide_step within +-slide_range; the four cameras nearest to each direction are
+    the candidates of that source slot (the first one is used unless random_ref_views); every camera inside the pyramid spanned by the
+    four nearest cameras that is not itself one of them is a target (facescape.py:75-207).  The list is cached as JSON next to the
+    split files, in the reference's file name and format, and loaded from there when present."""
+    znear, zfar = 1.0, 2.5
+    RGBA_FNAME = "rgba_colorcalib.png"
+    DEPTH_FNAME = "depth_TransMVSNet.png"
+
+    def __init__(self, root, stage, range_hor=45, range_vert=30, slide_range=40, slide_step=20.0, random_ref_views=False,
+                 depth_fname=None, split_dir="assets/data_splits/facescape"):
+        self.data_dir = Path(root)
+        if not self.data_dir.exists():
+            raise FileNotFoundError(root)
+        self.stage, self.range_hor, self.range_vert = stage, range_hor, range_vert
+        self.slide_range, self.slide_step, self.random_ref_views = slide_range, slide_step, random_ref_views
+        if depth_fname is not None:
+            self.DEPTH_FNAME = depth_fname
+        self.DEPTH_STD_FNAME = self.DEPTH_FNAME.replace(".png", "_conf.png")
+        self.split_dir = Path(split_dir)
+        self.nsource = 4
+        self.metas = self._metas()
+
+    @staticmethod
+    def conf2std(x):                       # facescape.py:50-52
+        return -1.582e-2 * x + 1.649e-2
+
+    @staticmethod
+    def viewdir(i):
+        return f"view_{int(i):05d}"
+
+    @staticmethod
+    def read_rgba(path, symmetric_range=False, bg=1.0):
+        """-> rgb (3,H,W) in [0,1] (or [-1,1]) with the background (alpha < 0.5) painted `bg`, alpha (1,H,W) (facescape.py:54-62)."""
+        a = torch.from_numpy(np.ascontiguousarray(formats.read_png(str(path)))).permute(2, 0, 1).float() / 255.0
+        rgb, alpha = a[:3].clone(), a[3:4].clone()
+        if symmetric_range:
+            rgb = rgb * 2 - 1
+        rgb.permute(1, 2, 0)[alpha[0] < 0.5] = bg
+        return rgb, alpha
+
+    @staticmethod
+    def read_depth(path):
+        """uint16 PNG x 1e-4 -> (1,H,W) float32 (facescape.py:64-69)."""
+        return torch.from_numpy(formats.read_png(str(path)).astype(np.int32)).float()[None] * 1e-4
+
+    # ---- sample list ------------------------------------------------------------------------------------------------------------
+    def _meta_path(self):
+        return self.split_dir / (f"{self.stage}_{self.range_hor}_{self.range_vert}" +
+                                 (f"_{self.slide_range}" if self.slide_range != 0 else "") + ".txt")
+
+    def _metas(self):
+        import json
+        mp = self._meta_path()
+        if mp.exists():
+            with open(mp) as f:
+                return json.load(f)
+        val_subjects = [f"{int(i):03d}" for i in np.atleast_1d(np.loadtxt(self.split_dir / "publishable_list_v1.txt", delimiter=","))]
+        train_subjects = sorted(d.name for d in self.data_dir.iterdir() if d.name not in val_subjects)
+        subjects = train_subjects if self.stage == "train" else val_subjects
+        metas = []
+        for subject, frame in product(subjects, range(1, 21)):
+            scan = self.data_dir / subject / f"{frame:02d}"
+            try:
+                metas += self._scan_metas(scan, first_idx=len(metas))
+            except (FileNotFoundError, OSError, KeyError, ValueError):      # the reference skips scans it cannot read
+                continue
+        with open(mp, "w") as f:
+            json.dump(metas, f, indent="\t")
+        return metas
+
+    def _scan_metas(self, scan, first_idx):
+        import json
+        if not (scan / "3dlmks.npy").exists():
+            raise FileNotFoundError(scan / "3dlmks.npy")
+        with open(scan / "cameras.json") as f:
+            cam_dict = json.load(f)
+
+        def usable(i):
+            v = scan / self.viewdir(i)
+            return ((v / self.RGBA_FNAME).exists() and (v / self.DEPTH_FNAME).exists()
+                    and float(self.read_depth(v / self.DEPTH_FNAME).max()) <= self.zfar)
+        cam_ids = np.array([i for i in sorted(cam_dict.keys()) if usable(i)])          # ids are strings, sorted as strings
+        E = np.array([cam_dict[k]["extrinsics"] for k in cam_ids]).astype(np.float32)
+        centre = -E[:, :3, :3].transpose(0, 2, 1) @ E[:, :3, -1:]
+        cam_dirs = (centre / np.sqrt((centre ** 2).sum(axis=1, keepdims=True)))[..., 0]
+        hor, vert = self.range_hor / 180 * np.pi, self.range_vert / 180 * np.pi
+        ideal = np.array([[np.sin(az) * np.cos(el), -np.cos(az) * np.cos(el), np.sin(el)]
+                          for az, el in product([-hor, hor], [-vert, vert])])
+        # a scan whose frontal view sees nothing nearer than 2 m is dropped
+        frontal = cam_ids[np.argmax(np.sum(np.array([0.0, -1.0, 0.0])[None] * cam_dirs, axis=-1))]
+        depth = self.read_depth(scan / self.viewdir(frontal) / self.DEPTH_FNAME)
+        if depth[depth != 0].min() > 2:
+            return []
+        out = []
+        for slide in np.arange(-self.slide_range, self.slide_range + 1, self.slide_step):
+            a = slide / 180 * np.pi
+            rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0.0, 0.0, 1.0]])
+            dirs = (rot @ ideal.T).T
+            cos = np.sum(dirs[:, None] * cam_dirs[None], axis=-1)                       # (4, N)
+            ref_idcs = np.argsort(cos, axis=1)[:, ::-1][:, :4]
+            ref_ids = cam_ids[ref_idcs].tolist()
+            corners = cam_dirs[ref_idcs[:, 0]]
+            normals = np.stack([np.cross(corners[1], corners[0]), np.cross(corners[3], corners[1]),
+                                np.cross(corners[2], corners[3]), np.cross(corners[0], corners[2])], axis=0)
+            inside = np.all(np.sum(cam_dirs[:, None] * normals[None], axis=-1) >= 0, axis=-1)
+            firsts = [r[0] for r in ref_ids]
+            for t in cam_ids[inside].tolist():
+                if t in firsts:
+                    continue
+                out.append(dict(idx=first_idx + len(out), scan_path=str(scan.relative_to(self.data_dir)), target_id=t, ref_ids=ref_ids))
+        return out
+
+    def __len__(self):
+        return len(self.metas)
+
+    # ---- one sample (facescape.py:217-293) -----------------------------------------------------------------------------------------
+    def __getitem__(self, idx):
+        import json
+        from src.util.cam_geometry import to_homogeneous_trafo
+        m = self.metas[idx]
+        src_ids = [(np.random.choice(c) if self.random_ref_views else c[0]) for c in m["ref_ids"]]
+        tgt = m["target_id"]
+        scan = self.data_dir / m["scan_path"]
+        frame, subject = scan.name, scan.parent.name
+        rgb_t, alpha_t = self.read_rgba(scan / self.viewdir(tgt) / self.RGBA_FNAME)
+        rgbs, alphas, depths, stds = [], [], [], []
+        for i in src_ids:
+            v = scan / self.viewdir(i)
+            rgb, alpha = self.read_rgba(v / self.RGBA_FNAME)
+            rgbs.append(rgb), alphas.append(alpha)
+            depths.append(self.read_depth(v / self.DEPTH_FNAME))
+            stds.append(self.read_depth(v / self.DEPTH_STD_FNAME))
+        with open(scan / "cameras.json") as f:
+            cams = json.load(f)
+        E_t = to_homogeneous_trafo(torch.tensor(cams[tgt]["extrinsics"])[None])[0]
+        E_s = to_homogeneous_trafo(torch.tensor([cams[i]["extrinsics"] for i in src_ids]))
+        return dict(target_rgb=rgb_t, target_alpha=alpha_t, target_extrinsics=E_t,
+                    target_intrinsics=torch.tensor(cams[tgt]["intrinsics"]), target_view_id=torch.tensor(int(tgt)), scan_idx=0,
+                    sample_name=f"{subject}-{frame}-{tgt}-{'-'.join(src_ids)}-", frame=frame,
+                    src_rgbs=torch.stack(rgbs), src_depths=torch.stack(depths), src_depth_stds=self.conf2std(torch.stack(stds)),
+                    src_alphas=torch.stack(alphas), src_extrinsics=E_s,
+                    src_intrinsics=torch.tensor([cams[i]["intrinsics"] for i in src_ids]),
+                    src_view_ids=torch.tensor([int(i) for i in src_ids]))
+
+    def get_cam_sweep_extrinsics(self, nframes, scan_idx, elevation=0.0, radius=1.8, sweep_range=None):
+        """Horizontal arc of +-sweep_range degrees around the mean direction of the sample's source cameras, looking at the
+        origin with -z up (facescape.py:295-341).  -> (nframes, 4, 4) extrinsics."""
+        E = self[scan_idx]["src_extrinsics"]
+        centres = -1 * E[:, :3, :3].permute(0, 2, 1) @ E[:, :3, -1:]
+        dirs = centres[..., 0] / torch.norm(centres[..., 0], p=2, keepdim=True, dim=-1)
+        mean_dir = dirs.sum(dim=0)
+        mean_dir = mean_dir / torch.norm(mean_dir, p=2, dim=0)
+        centre = mean_dir * radius
+        z_ax = -centre / torch.norm(centre, p=2)
+        y_ax = torch.tensor([0.0, 0.0, -1.0])
+        x_ax = torch.cross(y_ax, z_ax, dim=0)
+        x_ax = x_ax / torch.norm(x_ax, p=2)
+        pose = torch.eye(4)
+        pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = x_ax, y_ax, z_ax, centre
+        rng = sweep_range if sweep_range is not None else self.range_hor
+        rots = torch.stack([torch.tensor([[np.cos(a), -np.sin(a), 0, 0], [np.sin(a), np.cos(a), 0, 0], [0.0, 0.0, 1, 0],
+                                          [0.0, 0.0, 0.0, 1.0]], dtype=torch.float)
+                            for a in np.linspace(-rng / 180 * np.pi, rng / 180 * np.pi, nframes)])
+        return torch.linalg.inv(rots @ pose[None].expand(nframes, -1, -1))
 
 
 def collate(samples):

@@ -62,3 +62,39 @@ def test_missing_tree_is_an_error(tmp_path):
     from diner_amd.datasets import DTUSamples
     with pytest.raises(FileNotFoundError):
         DTUSamples(str(tmp_path / "nope"), "val", scan_list=["x"])
+
+
+def test_facescape_samples_match_reference_dataset(tmp_path):
+    """FacescapeSamples on the tiny tree under tests/golden/facescape_tiny against what the reference's OWN FacescapeDataSet produced
+    there (oracle/make_golden_facescape.py): the view-selection list entry for entry, three sample dicts bit for bit, the sweep."""
+    import json
+    import shutil
+    from diner_amd.datasets import FacescapeSamples, collate, encode_args
+    g = load("g14_facescape.npz")
+    tree = os.path.join(GOLD, "facescape_tiny")
+    shutil.copy(os.path.join(tree, "splits", "publishable_list_v1.txt"), tmp_path)      # the list cache is written next to it
+    ds = FacescapeSamples(tree, "val", split_dir=str(tmp_path))
+    want_metas = json.loads(str(g["metas_json"]))
+    assert len(ds) == int(g["n"]) == len(want_metas) > 0
+    assert json.loads(json.dumps(ds.metas)) == want_metas
+    # the cache file has the reference's name and loads back to the same list
+    assert (tmp_path / "val_45_30_40.txt").exists()
+    assert FacescapeSamples(tree, "val", split_dir=str(tmp_path)).metas == want_metas
+    for j, i in enumerate(g["picks"].tolist()):
+        s = ds[i]
+        keys = [k[len(f"s{j}_"):] for k in g.files if k.startswith(f"s{j}_")]
+        assert set(keys) == set(s.keys())
+        for k in keys:
+            want = g[f"s{j}_{k}"]
+            if torch.is_tensor(s[k]):
+                got = s[k].numpy()
+                assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), k
+            else:
+                assert s[k] == want.item(), k
+    sw = ds.get_cam_sweep_extrinsics(7, int(g["picks"][1]))
+    assert sw.shape == (7, 4, 4) and np.abs(sw.numpy() - g["sweep"]).max() < 1e-6
+    # the dict feeds PixelNeRF.encode like the DTU one
+    b = collate([ds[0], ds[1]])
+    a = encode_args(b)
+    assert a["images"].shape == (2, 4, 3, 24, 32) and a["depths_std"].shape == (2, 4, 1, 24, 32) and a["extrinsics"].shape == (2, 4, 4, 4)
+    assert ds.znear == 1.0 and ds.zfar == 2.5
