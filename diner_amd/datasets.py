@@ -162,7 +162,7 @@ class FacescapeSamples:
 
     @staticmethod
     def conf2std(x):                       # facescape.py:50-52
-        return -1.582e-2 * x + 1.649e-2
+        return formats.conf_to_std(x, "facescape")
 
     @staticmethod
     def viewdir(i):

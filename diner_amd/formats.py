@@ -6,7 +6,8 @@
                                        depth_min and depth_interval on line 11, depth_max = min + 192 * interval)
 * TransMVSNet uint16 PNG depth / confidence predictions (value x 1e-4; src/data/dtu.py:104-108: DTU depths are further
                                        divided by 0.7 / 872, the scale used when TransMVSNet was trained)
-* confidence -> depth standard deviation (dtu.py:68-70; the same linear law in src/data/facescape.py:50-52)
+* confidence -> depth standard deviation: one linear law per dataset (dtu.py:68-70; facescape.py:50-52; multiface.py:305-310
+                                       with its clamp at 0 and sigma = 0 where there is no depth)
 
 The reference reads PNGs through PIL and resizes with torchvision; neither exists here, so the PNG reader below
 implements the PNG specification itself (8 / 16-bit grey, grey+alpha, RGB, RGBA; all five row filters; no interlace).
@@ -137,6 +138,19 @@ def read_transmvsnet_png(path, dtu_rescale=False):
     return out
 
 
-def conf_to_std(conf):
-    """confidence in [0,1] -> depth standard deviation: -2.5679e-2 * conf + 3.2818e-2 (dtu.py:68-70)."""
-    return -2.5679e-2 * conf + 3.2818e-2
+CONF_TO_STD = {"dtu": (-2.5679e-2, 3.2818e-2),          # dtu.py:68-70
+               "facescape": (-1.582e-2, 1.649e-2),      # facescape.py:50-52
+               "multiface": (-1.582e-2, 1.649e-2)}      # multiface.py:309, then clipped at 0 and zeroed where depth == 0
+
+
+def conf_to_std(conf, law="dtu", depth=None):
+    """TransMVSNet confidence in [0,1] -> depth standard deviation a * conf + b with the data set's coefficients.  The Multiface law
+    also clamps at 0 and returns 0 where `depth` (same shape, optional) is 0 (multiface.py:309-310)."""
+    a, b = CONF_TO_STD[law]
+    std = a * conf + b
+    if law == "multiface":
+        std = std.clip(min=0) if hasattr(std, "clip") else max(std, 0.0)
+        if depth is not None:
+            std = std.clone() if hasattr(std, "clone") else np.array(std, copy=True)
+            std[depth == 0] = 0
+    return std

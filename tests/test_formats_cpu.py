@@ -121,3 +121,8 @@ def test_transmvsnet_depth_and_confidence(tmp_path):
     assert np.array_equal(c, depth_u16.astype(np.float32) * np.float32(1e-4))
     conf = np.array([0.0, 0.3, 1.0])
     assert np.allclose(F.conf_to_std(conf), [3.2818e-2, 3.2818e-2 - 0.3 * 2.5679e-2, 3.2818e-2 - 2.5679e-2], atol=0, rtol=1e-15)
+    # the Facescape / Multiface coefficients (facescape.py:50-52, multiface.py:309-310: clamp at 0, sigma 0 where there is no depth)
+    assert np.allclose(F.conf_to_std(conf, "facescape"), [1.649e-2, 1.649e-2 - 0.3 * 1.582e-2, 1.649e-2 - 1.582e-2], atol=0, rtol=1e-15)
+    big = np.array([0.0, 1.0, 1.2], dtype=np.float64)
+    assert np.array_equal(F.conf_to_std(big, "multiface", depth=np.array([0.0, 1.0, 1.0])),
+                          np.array([0.0, 1.649e-2 - 1.582e-2, 0.0]))
