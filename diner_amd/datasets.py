@@ -15,7 +15,10 @@ returned dict as `rgb_resample`).
 `FacescapeSamples` does the same for the Facescape capture layout (reference src/data/facescape.py): view selection into the
 cached sample list ("metas"), the sample dict, the sweep path.
 
-Not built: the Multiface class (same schema, another file tree) and the Lightning DataModule.
+`MultifaceSamples` does it for the Multiface layout (reference src/data/multiface.py): KRT camera files, gamma-corrected images,
+separate mask and depth trees, millimetre extrinsics.
+
+Not built: augmentation and the Lightning DataModule.
 """
 import os
 from itertools import product
@@ -302,6 +305,208 @@ class FacescapeSamples:
                                           [0.0, 0.0, 0.0, 1.0]], dtype=torch.float)
                             for a in np.linspace(-rng / 180 * np.pi, rng / 180 * np.pi, nframes)])
         return torch.linalg.inv(rots @ pose[None].expand(nframes, -1, -1))
+
+
+class MultifaceSamples:
+    """Sample dicts from a Multiface tree  root/<subject>/{KRT, images/<seq>/<cam>/<frame>.png, masks/<seq>/<cam>/<frame>.png,
+    depths/<seq>/<cam>/<frame><suffix>}  (multiface.py:22-381).
+
+    Sample list: per subject of the split file, the camera nearest to each of the four ideal reference centres is a source view; every
+    other camera within 100 mm of the inner side of the four planes through neighbouring reference cameras is a target; one entry per
+    (sequence, target camera, frame).  Cached as JSON next to the split files under the reference's name, optional substring filters
+    applied after loading (multiface.py:133-247)."""
+    znear, zfar = 0.5, 1.5
+
+    def __init__(self, root, stage, downsample=8, split_config="assets/data_splits/multiface/tiny_subset.json", depth_suffix=".png",
+                 depth_std_suffix=None, subject_filter=None, sequence_filter=None, target_filter=None, manual_target_params=None,
+                 split_dir="assets/data_splits/multiface"):
+        import json
+        self.data_dir = Path(root)
+        if not self.data_dir.exists():
+            raise FileNotFoundError(root)
+        assert isinstance(downsample, int)
+        self.stage, self.downsample, self.nsource = stage, downsample, 4
+        self.split_config, self.split_dir = Path(split_config), Path(split_dir)
+        self.depth_suffix, self.depth_std_suffix = depth_suffix, depth_std_suffix
+        self.metas = self._metas(subject_filter, sequence_filter, target_filter)
+        self.manual_target_params = None
+        if manual_target_params is not None:
+            with open(manual_target_params) as f:
+                self.manual_target_params = json.load(f)
+            assert len(self.manual_target_params["extrinsics"]) == len(self)
+
+    # ---- file readers -------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def gamma_correct(img, dim=0):
+        """The capture's colour pipeline: per-channel gains (1.4, 1.1, 1.6) / 1.1, black level 3/255, gamma 2 (multiface.py:79-99)."""
+        gamma, black = 2.0, 3.0 / 255.0
+        scale = torch.tensor([1.4, 1.1, 1.6]).view([3 if i == dim else 1 for i in range(img.dim())])
+        img = img * scale.to(img) / 1.1
+        return torch.clamp((((1.0 / (1 - black)) * 0.95 * torch.clamp(img - black, 0, 2)) ** (1.0 / gamma)) - 15.0 / 255.0, 0, 2)
+
+    @classmethod
+    def read_img(cls, path, symmetric_range=False):
+        a = formats.read_png(str(path))
+        rgb = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).float() / 255.0
+        rgb = cls.gamma_correct(rgb, dim=0).clip(0, 1)
+        return rgb * 2 - 1 if symmetric_range else rgb
+
+    @staticmethod
+    def read_alpha(path):
+        a = formats.read_png(str(path))
+        a = a[..., None] if a.ndim == 2 else a
+        return torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).float() / 255.0
+
+    @staticmethod
+    def read_depth(path):
+        return torch.from_numpy(formats.read_png(str(path)).astype(np.int32)).float()[None] * 1e-4
+
+    @staticmethod
+    def load_krt(path):
+        """KRT file: per camera a name line, 3 intrinsics rows, a distortion row, 3 extrinsics rows (3x4, mm), a blank line."""
+        cams = {}
+        with open(path) as f:
+            while True:
+                name = f.readline()
+                if name == "":
+                    break
+                intrin = [[float(x) for x in f.readline().split()] for _ in range(3)]
+                dist = [float(x) for x in f.readline().split()]
+                extrin = [[float(x) for x in f.readline().split()] for _ in range(3)]
+                f.readline()
+                cams[name[:-1]] = dict(intrin=np.array(intrin), dist=np.array(dist), extrin=np.array(extrin))
+        return cams
+
+    # ---- sample list --------------------------------------------------------------------------------------------------------------
+    def _metas(self, subject_filter, sequence_filter, target_filter):
+        import json
+        mp = self.split_dir / f"{self.stage}_{self.split_config.stem}.txt"
+        if mp.exists():
+            with open(mp) as f:
+                metas = json.load(f)
+        else:
+            with open(self.split_config) as f:
+                cfg = json.load(f)["train" if self.stage == "train" else "val"]
+            metas = []
+            for subj in cfg["subjects"]:
+                krt = self.load_krt(self.data_dir / subj / "KRT")
+                names = np.array(sorted(krt.keys()))
+                E = np.array([krt[n]["extrin"] for n in names])
+                E = np.concatenate((E, np.zeros_like(E[:, :1])), axis=1)
+                E[:, -1, -1] = 1
+                centres = (-E[:, :3, :3].transpose(0, 2, 1) @ E[:, :3, -1:])[..., 0]
+                dirs = E[:, 2, :3]
+                origin = np.array([[0, 0, 1000.0]])
+                ideal = np.array(cfg["ref_centers"]).reshape(-1, 3)
+                if subj == "m--20190529--1004--5067077--GHS":          # this capture's rig is rotated (multiface.py:161-166)
+                    b = np.pi * 4 / 6
+                    rot_y = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+                    ideal = (rot_y @ (ideal - origin).T).T + origin
+                dist = np.sqrt(np.sum((ideal[:, None] - centres[None]) ** 2, axis=-1))
+                ref = np.argsort(dist, axis=1)[:, 0]
+                rc, rd = centres[ref], dirs[ref]
+                normals = np.cross(rc[[0, 1, 2, 3]] - rc[[1, 2, 3, 0]], rd[[0, 1, 2, 3]] + rd[[1, 2, 3, 0]])
+                normals = normals / np.sqrt(np.sum(normals ** 2, axis=-1, keepdims=True))
+                inside = np.all(np.sum((centres[None] - rc[:, None]) * normals[:, None], axis=-1) > -100, axis=0)
+                inside[ref] = False
+                targets, ref_names = names[inside].tolist(), names[ref].tolist()
+                for seq in [p for p in sorted((self.data_dir / subj / "images").iterdir()) if p.name in cfg["sequences"]]:
+                    for t in targets:
+                        for frame in sorted((seq / t).iterdir()):
+                            metas.append(dict(idx=len(metas), scan_path=str(frame.relative_to(self.data_dir)), target_id=t,
+                                              ref_ids=ref_names))
+            with open(mp, "w") as f:
+                json.dump(metas, f, indent="\t")
+        if subject_filter is not None:
+            metas = [m for m in metas if any(s in m["scan_path"] for s in subject_filter)]
+        if sequence_filter is not None:
+            metas = [m for m in metas if any(s in m["scan_path"] for s in sequence_filter)]
+        if target_filter is not None:
+            metas = [m for m in metas if any(t == m["target_id"] for t in target_filter)]
+        return metas
+
+    def __len__(self):
+        return len(self.metas)
+
+    def _dpath(self, p, suffix):
+        return p.parents[3] / "depths" / p.relative_to(p.parents[2]).parent / (p.stem + suffix)
+
+    @staticmethod
+    def _apath(p):
+        return p.parents[3] / "masks" / p.relative_to(p.parents[2])
+
+    # ---- one sample (multiface.py:267-381) --------------------------------------------------------------------------------------------
+    def __getitem__(self, idx):
+        from src.util.cam_geometry import to_homogeneous_trafo
+        m = self.metas[idx]
+        src_ids, tgt = m["ref_ids"], m["target_id"]
+        rel = Path(m["scan_path"])
+        subject, seq, frame = rel.parents[3].name, rel.parents[1].name, rel.stem
+        tpath = self.data_dir / rel
+        spaths = [self.data_dir / subject / "images" / seq / s / (frame + ".png") for s in src_ids]
+        rgb_t, alpha_t = self.read_img(tpath), self.read_alpha(self._apath(tpath))
+        rgbs, alphas, depths, stds = [], [], [], []
+        for p in spaths:
+            d = self.read_depth(self._dpath(p, self.depth_suffix))
+            if self.depth_std_suffix is None:
+                std = torch.ones_like(d) * 1e-3
+                std[d == 0] = 0
+            else:
+                std = formats.conf_to_std(self.read_depth(self._dpath(p, self.depth_std_suffix)), "multiface", depth=d)
+            rgbs.append(self.read_img(p)), alphas.append(self.read_alpha(self._apath(p))), depths.append(d), stds.append(std)
+        rgbs, alphas, depths, stds = torch.stack(rgbs), torch.stack(alphas), torch.stack(depths), torch.stack(stds)
+        rgbs.permute(0, 2, 3, 1)[alphas[:, 0] < 1] = 1                       # white background
+        rgb_t.permute(1, 2, 0)[alpha_t[0] < 1] = 1
+        cams = self.load_krt(self.data_dir / subject / "KRT")
+        if self.manual_target_params is None:
+            E_t, K_t = torch.tensor(cams[tgt]["extrin"]).float(), torch.tensor(cams[tgt]["intrin"]).float()
+        else:
+            E_t = torch.tensor(self.manual_target_params["extrinsics"][idx]).float()
+            K_t = torch.tensor(self.manual_target_params["intrinsics"][idx]).float()
+        E_s = torch.tensor(np.array([cams[s]["extrin"] for s in src_ids])).float()
+        E_t, E_s = to_homogeneous_trafo(E_t[None]).float()[0], to_homogeneous_trafo(E_s).float()
+        K_s = torch.tensor(np.array([cams[s]["intrin"] for s in src_ids])).float()
+        E_t[..., :3, -1] /= 1000                                             # mm -> m
+        E_s[..., :3, -1] /= 1000
+        H, W = rgb_t.shape[-2:]
+        h, w = int((H / self.downsample) // 32 * 32), int((W / self.downsample) // 32 * 32)
+        if h != H or w != W:
+            # torchvision.transforms.functional.resize on tensors: bilinear without antialiasing for images, nearest for masks / depths
+            F = torch.nn.functional
+
+            def bil(x):
+                return F.interpolate(x if x.dim() == 4 else x[None], (h, w), mode="bilinear", align_corners=False)[slice(None) if x.dim() == 4 else 0]
+
+            def nn(x):
+                return F.interpolate(x if x.dim() == 4 else x[None], (h, w), mode="nearest")[slice(None) if x.dim() == 4 else 0]
+            rgb_t, rgbs, alpha_t, alphas = bil(rgb_t), bil(rgbs), nn(alpha_t), nn(alphas)
+            if depths.shape[-2:] != rgbs.shape[-2:]:
+                depths, stds = nn(depths), nn(stds)
+            K_t[0] *= w / W
+            K_t[1] *= h / H
+            K_s[:, 0] *= w / W
+            K_s[:, 1] *= h / H
+        return dict(target_rgb=rgb_t, target_alpha=alpha_t, target_extrinsics=E_t, target_intrinsics=K_t,
+                    target_view_id=torch.tensor(int(tgt)), scan_idx=0, sample_name=f"{subject}-{seq}-{frame}-{tgt}-{'-'.join(src_ids)}",
+                    frame=frame, src_rgbs=rgbs, src_depths=depths, src_depth_stds=stds, src_alphas=alphas, src_extrinsics=E_s,
+                    src_intrinsics=K_s, src_view_ids=torch.tensor([int(s) for s in src_ids]))
+
+    def get_cam_sweep_extrinsics(self, nframes, scan_idx, elevation=0.0, radius=1.8, sweep_range=None):
+        """Closed loop through the four source cameras (0, 1, 2, 3, 0, 2): spherical interpolation of the orientations, piece-wise
+        linear interpolation of the positions (multiface.py:383-430)."""
+        from scipy.spatial.transform import Rotation
+        from src.util.cam_geometry import Slerp
+        pose = torch.linalg.inv(self[scan_idx]["src_extrinsics"])
+        rots = Rotation.from_matrix(pose[:, :3, :3].cpu().numpy())
+        rots = Rotation.concatenate((rots, rots[0], rots[2]))
+        c = pose[:, :3, -1]
+        c = torch.cat((c, c[0][None], c[2][None]), dim=0).cpu().numpy()
+        slerp = Slerp(np.linspace(0, 1, len(rots)), rots, c)
+        R, t = slerp(np.linspace(0, 1, nframes + 1)[:-1])
+        poses = np.repeat(np.eye(4)[None], nframes, axis=0)
+        poses[:, :3, :3] = R.as_matrix()
+        poses[:, :3, -1] = t
+        return torch.linalg.inv(torch.from_numpy(poses)).float()
 
 
 def collate(samples):

@@ -98,3 +98,40 @@ def test_facescape_samples_match_reference_dataset(tmp_path):
     a = encode_args(b)
     assert a["images"].shape == (2, 4, 3, 24, 32) and a["depths_std"].shape == (2, 4, 1, 24, 32) and a["extrinsics"].shape == (2, 4, 4, 4)
     assert ds.znear == 1.0 and ds.zfar == 2.5
+
+
+def test_multiface_samples_match_reference_dataset(tmp_path):
+    """MultifaceSamples on tests/golden/multiface_tiny against the reference's OWN MultiFaceDataset (oracle/make_golden_multiface.py):
+    sample list, one dict with the constant sigma and one with the confidence law (clamped at 0, 0 where there is no depth), the sweep."""
+    import json
+    import shutil
+    from diner_amd.datasets import MultifaceSamples, collate, encode_args
+    g = load("g15_multiface.npz")
+    tree = os.path.join(GOLD, "multiface_tiny")
+    shutil.copy(os.path.join(tree, "splits", "tiny_subset.json"), tmp_path)
+    kw = dict(downsample=1, split_config=str(tmp_path / "tiny_subset.json"), split_dir=str(tmp_path))
+    ds = MultifaceSamples(tree, "val", **kw)
+    ds_c = MultifaceSamples(tree, "val", depth_std_suffix="_conf.png", **kw)          # loads the list the first one cached
+    want_metas = json.loads(str(g["metas_json"]))
+    assert len(ds) == int(g["n"]) == len(want_metas) > 0 and (tmp_path / "val_tiny_subset.txt").exists()
+    assert json.loads(json.dumps(ds.metas)) == want_metas and ds_c.metas == want_metas
+    picks = g["picks"].tolist()
+    for j, s in enumerate((ds[picks[0]], ds_c[picks[1]])):
+        keys = [k[len(f"s{j}_"):] for k in g.files if k.startswith(f"s{j}_")]
+        assert set(keys) == set(s.keys())
+        for k in keys:
+            want = g[f"s{j}_{k}"]
+            if torch.is_tensor(s[k]):
+                got = s[k].numpy()
+                assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), k
+            else:
+                assert s[k] == want.item(), k
+    std = ds_c[picks[1]]["src_depth_stds"]
+    assert float(std.min()) == 0.0 and bool((std[ds_c[picks[1]]["src_depths"] == 0] == 0).all())
+    sw = ds.get_cam_sweep_extrinsics(6, picks[0])
+    assert sw.shape == (6, 4, 4) and np.abs(sw.numpy() - g["sweep"]).max() < 1e-6
+    # filters act on the loaded list  (the down-sampling branch -- torchvision's resize, restated with F.interpolate -- is not
+    # pinned: torchvision is absent from the build container, and the tiny images are already the multiples of 32 it rounds to)
+    assert len(MultifaceSamples(tree, "val", target_filter=[want_metas[0]["target_id"]], **kw)) < len(ds)
+    a = encode_args(collate([ds[0], ds[1]]))
+    assert a["images"].shape == (2, 4, 3, 32, 64) and a["depths"].shape == (2, 4, 1, 32, 64)
