@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-modes", action="store_true", help="skip the extra one-frame passes in the other arithmetic modes")
     ap.add_argument("--ray-batch", type=int, default=8192, help="rays per launch group (bounds the workspace)")
+    ap.add_argument("--emulate-shard", default=None, metavar="R/N",
+                    help="single-GPU measurement aid: render only the ray range rank R of an N-way sharded frame would render "
+                         "(no process group, no gather); the line then reports that shard's time and the frame rate N such "
+                         "GPUs would reach if the slowest shard took this long")
     ap.add_argument("--precision", choices=["f16x3", "fp32", "f16"], default=None,
                     help="MLP GEMM arithmetic of the headline number (default: the library default, f16x3)")
     return ap.parse_args()
@@ -124,6 +128,10 @@ def main():
     else:               # one frame, contiguous ray range per rank
         tgt = sc["target_extrinsics"]
         lo, hi = shard_range(NRF, rank, world)
+        if args.emulate_shard:
+            assert world == 1, "--emulate-shard is a single-process measurement"
+            er, en = (int(x) for x in args.emulate_shard.split("/"))
+            lo, hi = shard_range(NRF, er, en)
     tgt_E, tgt_K = tgt[None].contiguous(), sc["target_intrinsics"][None].contiguous()
     out = torch.empty(hi - lo, 4, device=dev)      # packed (rgb, depth) tile of this rank
     frame = [None]
@@ -177,10 +185,12 @@ def main():
     elapsed, prof = timed(args.steps, head, args.warmup, profile=True)
     if not os.environ.get("DINER_AMD_LIB"):        # (timing experiments with ablated libraries produce garbage)
         assert torch.isfinite(out).all(), "non-finite render output"
-        if rank == 0 and not args.weak:
+        if rank == 0 and not args.weak and not args.emulate_shard:
             assert frame[0].shape == (NRF, 4) and torch.isfinite(frame[0]).all()
 
     rays_per_step = NRF * (world if args.weak else 1)
+    if args.emulate_shard:
+        rays_per_step = hi - lo
     rays_per_s = rays_per_step * args.steps / elapsed
 
     # ---- the other arithmetic modes: one extra timed frame each ------------------------------------------
@@ -292,6 +302,9 @@ def main():
         par = (f"{world} independent frames (weak)" if args.weak else
                f"one frame ray-sharded x{world}" + (" (BASELINE configs[3])" if world > 1 else "")) + \
               ", RCCL gather of (rgb,depth) tiles to rank 0"
+        if args.emulate_shard:
+            par = (f"EMULATION on one GPU: the ray range of rank {er} of {en} only (rays {lo}..{hi}), scene preparation included, no "
+                   f"process group and no gather; {en} GPUs whose slowest shard takes this long render {NRF * args.steps / elapsed:.0f} rays/s")
         line = {
             "metric": f"rendered rays/sec ({K} samples/ray, 4 src views)", "value": round(rays_per_s, 1),
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
