@@ -55,14 +55,20 @@ def parse():
                     help="Facescape depth range / sigma law (BASELINE configs[4]): znear/zfar 1.0/2.5, white background")
     ap.add_argument("--weak", action="store_true",
                     help="every rank renders its own full frame (weak scaling) instead of sharding one frame")
-    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU baseline sample (0 disables)")
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the CPU baseline sample (0 disables)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-modes", action="store_true", help="skip the extra one-frame passes in the other arithmetic modes")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the extra one-frame passes of the other single-GPU BASELINE configs (400x300; 1024x1024 K=192 f16 / f16x3)")
     ap.add_argument("--ray-batch", type=int, default=8192, help="rays per launch group (bounds the workspace)")
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="single-GPU measurement aid: render only the ray range rank R of an N-way sharded frame would render "
                          "(no process group, no gather); the line then reports that shard's time and the frame rate N such "
                          "GPUs would reach if the slowest shard took this long")
+    ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
+                    help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = the tile gather "
+                         "and the seed broadcast staged through pinned host memory (ranks SHARING a GPU: RCCL refuses two ranks "
+                         "on one device); auto = nccl when every local rank has its own device, else gloo")
     ap.add_argument("--precision", choices=["f16x3", "fp32", "f16"], default=None,
                     help="MLP GEMM arithmetic of the headline number (default: the library default, f16x3)")
     return ap.parse_args()
@@ -87,13 +93,31 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to measure")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.emulate_shard and (args.weak or world > 1):
+        raise SystemExit("--emulate-shard is a single-process measurement of one shard of the sharded frame: not with --weak / N > 1")
+    n_dev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    shared = local_world > n_dev                    # ranks time-slice a GPU (single-GPU box): not a scaling measurement
+    dev = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(dev)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        backend = args.backend if args.backend != "auto" else ("gloo" if shared else "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)                          # gloo prints "[Gloo] Rank ..." notes to stdout: the JSON line must stay alone there
+            try:
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
 
     from diner_amd import ops
     from diner_amd.render import shard_range, gather_tiles
@@ -103,64 +127,73 @@ def main():
         ops.set_precision(args.precision)
     head = ops.get_precision()
     names = {ops.PRECISION_FP32: "fp32", ops.PRECISION_F16X3: "f16x3", ops.PRECISION_F16: "f16"}
-    W, H, K = args.width, args.height, args.samples
-    G = int(15 * K / 40)                           # create_prediction_folder.py:44-47
-    n_cand = args.candidates
-    white = bool(args.white_bkgd or args.facescape)
-    scene_kw = dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape") if args.facescape else {}
-
-    # ---- scene + weights, resident in HBM -----------------------------------------------------------
-    sc = make_scene(W, H, seed=0, **scene_kw)
-    Kin = sc["src_intrinsics"]
-    depths = sc["depths"].to(dev)
-    normals = ops.depth2normal(depths, Kin.to(dev))                     # encode-side prep (row f2), not timed
-    scene = ops.HipScene(sc["latent"].to(dev), depths, sc["depths_std"].to(dev), normals,
-                         sc["src_extrinsics"], Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"],
-                         sc["feature_padding"])
-    del sc["latent"]
     msd = make_mlp_state_dict()
     mlp = ops.HipMlp({k: v.to(dev) for k, v in msd.items()})
-    NRF = W * H
-    s = scene_kw.get("scale", 1.0)
-    if args.weak:       # every rank renders its own target view of the same scene
-        tgt = look_at_extrinsics((s * (0.03 + 0.04 * rank), -0.02 * s, -1.0 * s))
-        lo, hi = 0, NRF
-    else:               # one frame, contiguous ray range per rank
-        tgt = sc["target_extrinsics"]
-        lo, hi = shard_range(NRF, rank, world)
-        if args.emulate_shard:
-            assert world == 1, "--emulate-shard is a single-process measurement"
-            er, en = (int(x) for x in args.emulate_shard.split("/"))
-            lo, hi = shard_range(NRF, er, en)
-    tgt_E, tgt_K = tgt[None].contiguous(), sc["target_intrinsics"][None].contiguous()
-    out = torch.empty(hi - lo, 4, device=dev)      # packed (rgb, depth) tile of this rank
-    frame = [None]
 
-    def step(seed, precision):
-        # per-scene preparation (projection of the latent through lin_z[0..2]) is redone every
-        # frame inside the timed region, so that no cached per-scene output is excluded from the measurement
-        scene.prepare(mlp, force=True)
-        rays = ops.gen_rays(tgt_E, tgt_K, W, H, sc["znear"], sc["zfar"], dev, ray0=lo, n_rays=hi - lo)[0]
-        for r0 in range(0, hi - lo, args.ray_batch):
-            r = rays[r0:r0 + args.ray_batch]
-            z = ops.sample_depthguided(scene, r, K, n_cand, G, 0.05, noise=None, seed=seed, ray_index0=lo + r0)   # one key per frame
-            _, rgb, depth = ops.render(scene, mlp, r, z, white_bkgd=white, want_weights=False, precision=precision)
-            out[r0:r0 + args.ray_batch, :3] = rgb
-            out[r0:r0 + args.ray_batch, 3] = depth
-        if world > 1 and not args.weak:
-            frame[0] = gather_tiles(out, NRF, rank, world)        # one RCCL gather of the rendered tiles per frame
-        elif world > 1:
-            gat = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
-            dist.gather(out, gat, dst=0)
-        else:
-            frame[0] = out
+    def workload(W, H, K, facescape, white, lo_hi=None):
+        """Scene resident in HBM + the per-frame step of one configuration -> dict(step, out, frame, ...)."""
+        G = int(15 * K / 40)                           # create_prediction_folder.py:44-47
+        scene_kw = dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape") if facescape else {}
+        sc = make_scene(W, H, seed=0, **scene_kw)
+        Kin = sc["src_intrinsics"]
+        depths = sc["depths"].to(dev)
+        normals = ops.depth2normal(depths, Kin.to(dev))                     # encode-side prep (row f2), not timed
+        scene = ops.HipScene(sc["latent"].to(dev), depths, sc["depths_std"].to(dev), normals,
+                             sc["src_extrinsics"], Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"],
+                             sc["feature_padding"])
+        del sc["latent"]
+        NRF = W * H
+        s_ = scene_kw.get("scale", 1.0)
+        if args.weak:       # every rank renders its own target view of the same scene
+            tgt = look_at_extrinsics((s_ * (0.03 + 0.04 * rank), -0.02 * s_, -1.0 * s_))
+            lo, hi = 0, NRF
+        else:               # one frame, contiguous ray range per rank
+            tgt = sc["target_extrinsics"]
+            lo, hi = lo_hi(NRF) if lo_hi else shard_range(NRF, rank, world)
+        tgt_E, tgt_K = tgt[None].contiguous(), sc["target_intrinsics"][None].contiguous()
+        out = torch.empty(hi - lo, 4, device=dev)      # packed (rgb, depth) tile of this rank
+        frame = [None]
+
+        def step(seed, precision, max_rays=None):
+            # per-scene preparation (projection of the latent through lin_z[0..2], DESIGN.md section 4) is redone every
+            # frame inside the timed region, so that no cached per-scene output is excluded from the measurement
+            scene.prepare(mlp, force=True)
+            n = hi - lo if max_rays is None else min(hi - lo, max_rays)
+            rays = ops.gen_rays(tgt_E, tgt_K, W, H, sc["znear"], sc["zfar"], dev, ray0=lo, n_rays=n)[0]
+            for r0 in range(0, n, args.ray_batch):
+                r = rays[r0:r0 + args.ray_batch]
+                z = ops.sample_depthguided(scene, r, K, n_cand, G, 0.05, noise=None, seed=seed, ray_index0=lo + r0)   # one key per frame
+                _, rgb, depth = ops.render(scene, mlp, r, z, white_bkgd=white, want_weights=False, precision=precision)
+                out[r0:r0 + args.ray_batch, :3] = rgb
+                out[r0:r0 + args.ray_batch, 3] = depth
+            if world > 1 and not args.weak:
+                frame[0] = gather_tiles(out, NRF, rank, world)        # one RCCL gather of the rendered tiles per frame
+            elif world > 1:
+                src = out if backend == "nccl" else out.cpu()
+                gat = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+                dist.gather(src, gat, dst=0)
+            else:
+                frame[0] = out
+        return dict(step=step, out=out, frame=frame, sc=sc, scene=scene, normals=normals, Kin=Kin, NRF=NRF, lo=lo, hi=hi, G=G,
+                    scene_kw=scene_kw)
+
+    W, H, K = args.width, args.height, args.samples
+    n_cand = args.candidates
+    white = bool(args.white_bkgd or args.facescape)
+    lo_hi = None
+    if args.emulate_shard:
+        er, en = (int(x) for x in args.emulate_shard.split("/"))
+        lo_hi = lambda n: shard_range(n, er, en)
+    wl_head = workload(W, H, K, args.facescape, white, lo_hi)
+    step, out, frame, sc, scene, normals, Kin = (wl_head[k] for k in ("step", "out", "frame", "sc", "scene", "normals", "Kin"))
+    NRF, lo, hi, G = (wl_head[k] for k in ("NRF", "lo", "hi", "G"))
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_steps, precision, seed0, profile=False):
+    def timed(n_steps, precision, seed0, profile=False, step=step):
         sync()
         if profile:
             ops.profile_enable(True)
@@ -175,7 +208,7 @@ def main():
             prof = ops.profile_collect()
             ops.profile_enable(False)
         if world > 1:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, prof
@@ -191,6 +224,7 @@ def main():
     rays_per_step = NRF * (world if args.weak else 1)
     if args.emulate_shard:
         rays_per_step = hi - lo
+    scene_kw = wl_head["scene_kw"]
     rays_per_s = rays_per_step * args.steps / elapsed
 
     # ---- the other arithmetic modes: one extra timed frame each ------------------------------------------
@@ -243,6 +277,13 @@ def main():
                 "avg_launch_ms": round(prof["pre_ms"] / max(prof["launches"], 1), 3),
                 "points_per_launch": round(prof["points"] / max(prof["launches"], 1)),
                 "post_kernel_ms_total": round(prof["post_ms"], 2), "pre_kernel_ms_total": round(prof["pre_ms"], 2)}
+    # whole path: every MFMA FLOP of the two field kernels over the WALL time of the timed frames (sampler, hoist, compositor, ray
+    # generation, launch gaps and -- for N > 1 -- the gather included), against the same peak
+    flop_path = prof["points"] * (ops.FLOP_PRE_PER_POINT + ops.FLOP_POST_PER_POINT) * mfma_per_product
+    roofline["whole_path"] = {"achieved": round(flop_path / elapsed / 1e12, 2), "frac": round(flop_path / elapsed / 1e12 / peak, 4),
+                              "unit": "TFLOP/s", "note": "MFMA FLOP of the per-view and post kernels of this rank / wall time of the "
+                              "timed steps (sampler, per-frame hoist, compositor, ray generation and launch gaps included)",
+                              "field_kernels_share_of_wall": round((prof["pre_ms"] + prof["post_ms"]) * 1e-3 / elapsed, 4)}
 
     # ---- CPU baseline: the oracle on the host cores of this box (rank 0, N = 1 only) ----
     cpu = None
@@ -289,6 +330,25 @@ def main():
                          f"{times[-1]:.1f}); {best} of {hw} hardware threads = fastest of the sweep {sweep} (rays/s on 256 rays)",
                "repeats_s": [round(t, 2) for t in times], "thread_sweep_rays_per_s": sweep, "host_threads": hw}
 
+    # ---- the other single-GPU configurations of BASELINE.json, one timed frame each (N = 1 only) ---------------------
+    configs = {}
+    if world == 1 and not args.no_configs and not args.emulate_shard and (W, H, K, bool(args.facescape)) == (800, 600, 128, False):
+        for key, (cw, ch, ck, cfs, cmodes) in {
+                "configs[1] 400x300 K=128": (400, 300, 128, False, (ops.PRECISION_F16X3,)),
+                "configs[4] 1024x1024 K=192 Facescape range, white background": (1024, 1024, 192, True, (ops.PRECISION_F16, ops.PRECISION_F16X3))}.items():
+            wl = workload(cw, ch, ck, cfs, cfs)
+            for m in cmodes:
+                wl["step"](0, m, max_rays=2 * args.ray_batch)          # warm-up on the first two ray batches
+                el, _ = timed(1, m, 7, step=wl["step"])
+                assert torch.isfinite(wl["out"]).all()
+                configs[f"{key} [{names[m]}]"] = {
+                    "rays_per_s": round(cw * ch / el, 1), "ms_per_frame": round(el * 1e3, 2), "rays_per_frame": cw * ch, "samples_per_ray": ck,
+                    "mode": names[m], "steps": 1,
+                    "parity": "outside the 1e-4 bar (~1e-3; 85.8 dB against the reference image, tests/test_hip_parity.py::test_cfg5_fp16_mlp_psnr)"
+                    if m == ops.PRECISION_F16 else "1e-4 bar (tests/test_hip_parity.py::test_render_at_metric_sample_counts)"}
+            del wl
+            torch.cuda.empty_cache()
+
     if rank == 0:
         frame_name = f"{W}x{H}"
         if (W, H, K) == (800, 600, 128) and not args.facescape:
@@ -301,7 +361,10 @@ def main():
             wl = "variant of BASELINE configs[2]"
         par = (f"{world} independent frames (weak)" if args.weak else
                f"one frame ray-sharded x{world}" + (" (BASELINE configs[3])" if world > 1 else "")) + \
-              ", RCCL gather of (rgb,depth) tiles to rank 0"
+              (", RCCL gather of (rgb,depth) tiles to rank 0" if backend != "gloo" else
+               ", gloo gather of (rgb,depth) tiles to rank 0 staged through pinned host memory") + \
+              (f"; OVERSUBSCRIBED: {local_world} ranks time-slice {n_dev} GPU(s) -- exercises the N-rank code path, NOT a scaling number"
+               if shared and world > 1 else "")
         if args.emulate_shard:
             par = (f"EMULATION on one GPU: the ray range of rank {er} of {en} only (rays {lo}..{hi}), scene preparation included, no "
                    f"process group and no gather; {en} GPUs whose slowest shard takes this long render {NRF * args.steps / elapsed:.0f} rays/s")
@@ -321,8 +384,10 @@ def main():
                                    f"{'white' if white else 'black'} background",
                        "rays_per_step": rays_per_step, "rays_per_gpu_per_step": hi - lo, "samples_per_ray": K, "src_views": 4,
                        "frame": frame_name, "parallelism": par},
+            "backend": backend, "ranks_share_gpu": bool(shared and world > 1),
             "roofline": roofline,
             "modes": modes,
+            "configs": configs,
             "cpu_baseline": cpu,
         }
         if cpu:

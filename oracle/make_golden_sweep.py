@@ -1,0 +1,73 @@
+"""G12: camera-sweep geometry from the reference's OWN functions (build container only; test infrastructure).
+
+    python oracle/make_golden_sweep.py      # writes tests/golden/g12_sweep.npz
+
+* `DTUDataSet.get_cam_sweep_extrinsics` (reference src/data/dtu.py:246-318) is called as the unbound method on a stand-in `self`
+  that carries only what the method reads: `cam_dict["extrinsics"]` with the centre / left / right cameras at indices 24 / 11 / 18.
+  The three cameras are look-at cameras at fixed positions (diner_amd.synthetic.look_at_extrinsics, stored in the fixture).
+* `TransSlerp`, `pose_spherical` (reference src/util/cam_geometry.py:151-205, :51-75) on fixed inputs.
+The repo's diner_amd.sweep.sweep_extrinsics and src/util/cam_geometry.py are asserted against these outputs here (same bounds as
+tests/test_sweep_cpu.py) before the fixture is written."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden", "g12_sweep.npz")
+NFRAMES = 9
+CAMS = dict(left=(-0.6, -0.05, -0.85), center=(0.05, -0.1, -1.0), right=(0.55, 0.1, -0.9))
+
+
+def main():
+    from diner_amd.synthetic import look_at_extrinsics
+    from diner_amd.sweep import sweep_extrinsics
+    import src.util.cam_geometry as my_cg
+    from oracle.ref_import import import_reference
+    E = {k: look_at_extrinsics(v) for k, v in CAMS.items()}
+    ns = import_reference()
+    saved = {k: v for k, v in sys.modules.items() if k == "src" or k.startswith("src.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.modules.update(ns._modules)
+    tv = sys.modules["torchvision.transforms"]
+    tvf = sys.modules["torchvision.transforms.functional"]
+    tv.InterpolationMode = types.SimpleNamespace(NEAREST="nearest")          # names dtu.py imports; not on this path
+    tvf.pil_to_tensor = tvf.resize = None
+    sys.path.insert(0, "/root/reference")
+    try:
+        dtu = importlib.import_module("src.data.dtu")
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    ext = [torch.eye(4) for _ in range(25)]
+    ext[24], ext[11], ext[18] = E["center"].clone(), E["left"].clone(), E["right"].clone()
+    fake_self = types.SimpleNamespace(cam_dict=dict(extrinsics=ext))
+    ref = dtu.DTUDataSet.get_cam_sweep_extrinsics(fake_self, NFRAMES)       # the reference's method body, unmodified
+    ref = torch.as_tensor(ref).float()
+    assert ref.shape == (NFRAMES, 4, 4)
+    got = sweep_extrinsics(E["left"], E["center"], E["right"], NFRAMES)
+    err = float((got - ref).abs().max())
+    print(f"sweep_extrinsics vs reference get_cam_sweep_extrinsics: max abs diff {err:.2e}")
+    assert err < 2e-6
+    rcg = ns.cam_geometry
+    ts_times, ts_loc = np.array([0.0, 0.4, 1.0]), np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 2.0]])
+    ts_q = np.linspace(-0.1, 1.1, 13)
+    ts_out = rcg.TransSlerp(ts_times, ts_loc)(ts_q)
+    assert np.abs(my_cg.TransSlerp(ts_times, ts_loc)(ts_q) - ts_out).max() < 1e-12
+    pose_sph = rcg.pose_spherical(30.0, -20.0, 1.3)
+    assert torch.equal(my_cg.pose_spherical(30.0, -20.0, 1.3), pose_sph)
+    np.savez_compressed(OUT, left=E["left"].numpy(), center=E["center"].numpy(), right=E["right"].numpy(), nframes=NFRAMES,
+                        extrinsics=ref.numpy(), ts_times=ts_times, ts_loc=ts_loc, ts_q=ts_q, ts_out=ts_out,
+                        pose_sph=pose_sph.numpy())
+    print("fixture written:", OUT)
+
+
+if __name__ == "__main__":
+    main()

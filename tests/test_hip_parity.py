@@ -220,12 +220,14 @@ def test_render_cfg1_end_to_end(ops, precision):
 
 RENDER_FIXTURES = {
     # name: (scene kwargs of diner_amd.synthetic.make_scene,
-    #        max share of rays whose sample set may differ from the reference's (erf round-off classes only, see below),
-    #        PSNR floor of the whole 4096-ray image against the reference's image, all rays included)
-    # measured on MI355X (gpurun_out/dump_*.npz, round 2): G9 11 / 4096 rays (0.27 %), 48.1 dB; G10 994 / 4096 (24.3 %),
-    # 45.3 dB -- 107 / 128 dB on the rays with the reference's sample set
-    "g9_render_K128": (dict(), 0.01, 45.0),
-    "g10_render_cfg5": (dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape"), 0.30, 42.0),
+    #        max number of class-A rays, max number of class-B rays (erf round-off classes, see the test), each pinned a few per cent
+    #        above what the kernel measures on MI355X (deterministic: the HIP picks do not depend on the box),
+    #        PSNR floor of the whole image against the reference's image, all rays included)
+    # measured on MI355X (round 2, unchanged in round 3): G9 11 / 4096 rays (11 A, 0 B), 48.1 dB; G10 994 / 4096 (961 A, 33 B), 45.3 dB;
+    # G16 (K=192 like G10, but the wide DTU sigmas): see profiles/r03_parity_classes.md
+    "g9_render_K128": (dict(), 14, 2, 47.0),
+    "g10_render_cfg5": (dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape"), 1010, 40, 44.0),
+    "g16_render_K192_dtu": (dict(), 24, 4, 46.0),
 }
 
 
@@ -245,24 +247,31 @@ def _render_fixture(name):
 def test_render_at_metric_sample_counts(ops, precision, name):
     """renderer.forward against the reference's output at the sample counts the metric uses: G9 = K=128 / G=48 on 4096
     rays of the 400x300 bench scene (BASELINE configs[1..3]), G10 = K=192 / G=72, white background, Facescape depth range
-    and sigma law (configs[4]).  Statements, the last one on ALL rays:
-      (1) with the reference's sample positions EVERY ray matches to 1e-4 (field kernels + compositor; K=128 and 192 take
-          the two- / three-samples-per-lane paths of the compositor);
+    and sigma law (configs[4]), G16 = K=192 / G=72 with the DTU sigma law.  EVERY ray carries a 1e-4 statement:
+      (1) with the reference's sample positions every ray matches the reference's colours and depth to 1e-4 (field kernels +
+          compositor; K=128 and 192 take the two- / three-samples-per-lane paths of the compositor);
       (2) the HIP sampler reproduces the reference's sample positions to fp32 round-off (3e-6) on every ray except two
-          classes that no second implementation of erf can reproduce, each verified per ray:
+          classes that no second implementation of erf can reproduce (the reference's likelihoods come from MKL's vsErf on
+          the pinning host, CUDA's erff on an A100, ocml's here: an ulp apart here and there), each verified per ray:
             A. the pick sets differ only by candidates whose likelihood lies within SAT_L of the ray's cut-off
-               (helpers.selection_diff); one such candidate changes the number of empty slots and with it every
-               stratified fill sample of the ray;
+               (helpers.selection_diff; anything further away must match); one such candidate changes the number of
+               empty slots and with it every stratified fill sample of the ray;
             B. identical picks, but the gaussian fit (weighted_mean_n_std of the occupancy O) rests on likelihood mass
                that is itself erf round-off residue (sum(O) < 1e-2: a surface just beyond the far plane);
-          on the rays with the reference's samples the image matches to 1e-4, except where a 1e-7 shift of a gaussian
-          sample is amplified by the depth positional encoding (200 rad per unit depth) beyond that -- for those rays
-          (a handful) the oracle evaluated AT THE HIP SAMPLES must agree with the HIP image to 1e-4;
-      (3) over all rays, classes A and B included: their share and the PSNR of the image against the reference's image are
-          bounded explicitly (RENDER_FIXTURES).  A class-A/B ray is rendered from a different but equally valid random
-          sample set -- like another noise seed -- so PSNR against ground truth is unchanged in expectation."""
+          and for EVERY ray of those classes, not a sample of them:
+            a. the G gaussian slots equal the reference implementation's to 3e-6 whenever the fit is conditioned
+               (sum(O) >= 1e-2): they depend on O over all candidates, not on the picks (nerf_renderer.py:181-190);
+            b. the reference's fill (nerf_renderer.py:377-396, oracle) applied to the HIP pick set with the same noise gives the
+               HIP sample positions BIT FOR BIT: what differs from the reference is the pick set alone;
+            c. the reference's field + compositor (oracle) evaluated AT THE HIP SAMPLES agree with the HIP colours and depth to 1e-4;
+          on the rays with the reference's samples the image matches the reference's to 1e-4, except where a 1e-7 shift of a gaussian
+          sample is amplified by the depth positional encoding (200 rad per unit depth) beyond that -- those rays (a handful)
+          get statement c as well;
+      (3) over all rays: the number of class-A and class-B rays and the PSNR of the image against the reference's image are
+          bounded near their measured values (RENDER_FIXTURES).  A class-A/B ray is rendered from a different but equally
+          valid random sample set -- like another noise seed -- so PSNR against ground truth is unchanged in expectation."""
     g, sc, scene, w, msd, (K, G, n_cand, white), (nc, ng, nf) = _render_fixture(name)
-    _, max_share, psnr_floor = RENDER_FIXTURES[name]
+    _, max_a, max_b, psnr_floor = RENDER_FIXTURES[name]
     hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
     rays = T(g["rays"])
     rc = rays.cuda()
@@ -281,14 +290,15 @@ def test_render_at_metric_sample_counts(ops, precision, name):
     np.testing.assert_allclose(wts.cpu().sum(-1).numpy(), g["weights_sum"], atol=3e-5)
     assert max_norm_rel(wts.cpu()[::16], g["weights_sub"]) < TOL
     # (2)
-    z = ops.sample_depthguided(hs, rc, K, n_cand, G, 0.05, noise=(nc.cuda(), ng.cuda(), nf.cuda()))
-    zh = z.cpu()
+    z, zu = ops.sample_depthguided(hs, rc, K, n_cand, G, 0.05, noise=(nc.cuda(), ng.cuda(), nf.cuda()), want_unfilled=True)
+    zh, zuh = z.cpu(), zu.cpu()
     same = torch.isclose(zh, ref_z, rtol=3e-6, atol=1e-7).all(-1)
     zc = O.sample_coarse(rays, n_cand, nc)
     L, Occ = O.point_likelihood(scene, rays, zc)
     ties = set(int(r) for r in g["tie_rays"])      # exact likelihood ties at the cut-off: the reference's pick there is
     n_a = n_b = 0                                  # torch's unstable argsort order (make_golden_r2.py)
-    for r in (~same).nonzero().flatten().tolist():
+    diff = (~same).nonzero().flatten()
+    for r in diff.tolist():
         only = set(ref_z[r].tolist()) ^ set(zh[r].tolist())
         cand = [int((zc[r] == zz).nonzero().flatten()[0]) for zz in only if (zc[r] == zz).any()]
         if cand:                                   # class A
@@ -306,12 +316,30 @@ def test_render_at_metric_sample_counts(ops, precision, name):
     e_rgb, e_d = errs(rgb, depth)
     hot = (same & ((e_rgb >= TOL) | (e_d >= TOL))).nonzero().flatten()
     assert len(hot) <= 0.002 * NR
-    if len(hot):       # sample positions agree to round-off, colours do not: must be the conditioning of the reference
-        o_w, o_rgb, o_d, _ = O.composite(scene, w, rays[hot].contiguous(), zh[hot].contiguous(), white)
-        h_rgb, h_d = errs(rgb[hot], depth[hot], o_rgb, o_d)
-        print(f"{name} [{precision}] {len(hot)} rays with the reference's samples (to 3e-6) but colours off by up to "
-              f"{e_rgb[hot].max().item():.1e}: oracle at the HIP samples agrees to rgb {h_rgb.max().item():.1e} depth {h_d.max().item():.1e}")
-        assert h_rgb.max().item() < TOL and h_d.max().item() < TOL
+    # per-ray statements a / b / c on every ray whose sample set differs (and c on the "hot" ones)
+    n_gauss_checked, g_worst = 0, 0.0
+    if len(diff):
+        rd = rays[diff].contiguous()
+        mu, sd = O.weighted_mean_n_std(zc[diff], Occ[diff])
+        g_ref = ng[diff] * sd + mu                                                       # nerf_renderer.py:188
+        cond = Occ[diff].sum(-1) >= 1e-2
+        g_hip = zuh[diff][:, K - G:]
+        if cond.any():
+            close = torch.isclose(g_hip[cond], g_ref[cond], rtol=3e-6, atol=1e-7)
+            g_worst = float(((g_hip[cond] - g_ref[cond]).abs() / g_ref[cond].abs().clamp(min=1e-3)).max())
+            n_gauss_checked = int(cond.sum())
+            assert close.all(), f"a. gaussian slots of {int((~close.all(-1)).sum())} differing rays are not the reference's (worst {g_worst:.1e})"
+        refill = O.fill_up_uniform_samples(zuh[diff], rd, nf[diff])
+        assert torch.equal(refill, zh[diff]), "b. the reference's fill of the HIP pick set is not the HIP sample set"
+    chk = torch.cat((diff, hot))
+    if len(chk):
+        o_w, o_rgb, o_d, _ = O.composite(scene, w, rays[chk].contiguous(), zh[chk].contiguous(), white)
+        h_rgb, h_d = errs(rgb[chk], depth[chk], o_rgb, o_d)
+        print(f"{name} [{precision}] oracle field + compositor AT THE HIP SAMPLES on the {len(diff)} rays with a different sample set and the "
+              f"{len(hot)} rays with the reference's samples (to 3e-6) but colours off by more than 1e-4: rgb {h_rgb.max().item():.1e} depth "
+              f"{h_d.max().item():.1e}; gaussian slots of {n_gauss_checked} differing rays within {g_worst:.1e} of the reference's; fill of the "
+              f"HIP pick sets reproduced bit for bit")
+        assert h_rgb.max().item() < TOL and h_d.max().item() < TOL, "c. oracle at the HIP samples"
     cool = same.clone()
     cool[hot] = False
     assert e_rgb[cool].max().item() < TOL and e_d[cool].max().item() < TOL
@@ -324,7 +352,7 @@ def test_render_at_metric_sample_counts(ops, precision, name):
           f"(class A {n_a}, class B {n_b}); rays with the reference's samples: rgb {e_rgb[cool].max().item():.2e} depth "
           f"{e_d[cool].max().item():.2e}, PSNR {10 * np.log10(1.0 / max(mse_same, 1e-30)):.1f} dB; ALL rays: rgb "
           f"{e_rgb.max().item():.2e} depth {e_d.max().item():.2e}, PSNR of the image against the reference's {psnr:.1f} dB")
-    assert n_diff <= max_share * NR
+    assert n_a <= max_a and n_b <= max_b, (n_a, n_b)
     assert psnr >= psnr_floor
 
 
@@ -453,26 +481,6 @@ def test_philox_sampler_statistics(ops):
         ze = z1.cpu()[empty]
         edges = torch.linspace(sc["znear"], sc["zfar"], 129)
         assert (ze >= edges[:-1] - 1e-5).all() and (ze <= edges[1:] + 1e-5).all()
-
-
-def test_k192_against_oracle(ops, precision):
-    """BASELINE configs[4] samples 192 points per ray (72 gaussian): no reference fixture at that size, so compare with
-    the CPU oracle (pinned bit-exact against the reference on the other sizes) on a few hundred rays."""
-    sc, scene, w, msd, rays = oracle_setup(40, 32, 5)
-    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
-    K, G, n_cand, NRr = 192, 72, 1000, 160
-    sel = torch.linspace(0, rays.shape[0] - 1, NRr).long()
-    rs = rays[sel].contiguous()
-    g = torch.Generator().manual_seed(9)
-    nc, ng, nf = torch.rand(NRr, n_cand, generator=g), torch.randn(NRr, G, generator=g), torch.rand(NRr, K, generator=g)
-    ref = O.render(scene, w, rs, K, n_cand, G, True, nc, ng, nf)
-    z = ops.sample_depthguided(hs, rs.cuda(), K, n_cand, G, 0.05, noise=(nc.cuda(), ng.cuda(), nf.cuda()))
-    same = torch.isclose(z.cpu(), ref["z"], rtol=3e-6, atol=1e-7).all(-1)
-    wts, rgb, depth = ops.render(hs, hm, rs.cuda(), ref["z"].cuda(), True, want_weights=True)
-    e_rgb, e_d = max_norm_rel(rgb.cpu(), ref["rgb"]), max_norm_rel(depth.cpu(), ref["depth"])
-    print(f"K=192: sampler agrees on {int(same.sum())}/{NRr} rays; render on the oracle's z: rgb {e_rgb:.2e} depth {e_d:.2e}")
-    assert int((~same).sum()) <= 3
-    assert e_rgb < TOL and e_d < TOL and max_norm_rel(wts.cpu(), ref["weights"]) < TOL
 
 
 def test_replicated_points_are_bit_identical(ops, precision):

@@ -132,7 +132,8 @@ def test_g8_render_cfg1_subset():
 
 
 @pytest.mark.parametrize("name,kw", [("g9_render_K128", dict()),
-                                     ("g10_render_cfg5", dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape"))])
+                                     ("g10_render_cfg5", dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape")),
+                                     ("g16_render_K192_dtu", dict())])
 def test_g9_g10_render_at_metric_sample_counts_subset(name, kw):
     """The oracle against the reference's renderer.forward at the sample counts the metric uses (K=128 / 48 gaussian on
     the bench scene; K=192 / 72 gaussian, white background, Facescape range), on every 64th fixture ray."""
