@@ -12,7 +12,7 @@ class DinerScene(C.Structure):
                 ("std_pad_scale", C.c_void_p),
                 ("img_w", C.c_float), ("img_h", C.c_float), ("feature_padding", C.c_float),
                 ("nv", C.c_int32), ("C", C.c_int32), ("Hf", C.c_int32), ("Wf", C.c_int32),
-                ("Hs", C.c_int32), ("Ws", C.c_int32)]
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("proj_stamp", C.c_uint64)]
 
 
 class DinerMlpParams(C.Structure):
@@ -33,6 +33,8 @@ SIGNATURES = {
     "diner_mlp_create": (C.c_int, [C.POINTER(DinerMlpParams), C.c_void_p, C.POINTER(C.c_void_p)]),
     "diner_mlp_destroy": (C.c_int, [C.c_void_p]),
     "diner_mlp_weights_fit_f16x3": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "diner_mlp_stamp": (C.c_uint64, [C.c_void_p]),
+    "diner_mlp_fallback_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.c_void_p]),
     "diner_sample_depthguided_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_uint64, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -82,7 +84,7 @@ SIGNATURES = {
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),
 }
 
-ABI_VERSION = 2          # DINER_ABI_VERSION of include/diner_hip.h
+ABI_VERSION = 3          # DINER_ABI_VERSION of include/diner_hip.h
 _lib = None
 
 

@@ -305,6 +305,7 @@ struct PostArgs {
   int raw;             // 1: ResnetFC.forward output; 0: sigmoid(rgb), relu(sigma) (pixelnerf.py:139-143)
   const int* gate;     // optional: return at once when *gate == 0
   int* overflow;       // optional (fp16-operand kernels): set to 1 when a raw lin_out value is not finite
+  unsigned int* fallback_count;   // optional (gated exact pass): +1 per launch that actually recomputes
 };
 
 }  // namespace diner

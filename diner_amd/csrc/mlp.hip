@@ -31,6 +31,7 @@
 //  * the view-mean boundary (resnetfc.py:148-151) splits the network into two persistent kernels;
 //    the hand-over is 8 KB/point of pre-mean activations stored in accumulator layout (coalesced 1 KB
 //    wave stores).
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "field_common.hpp"
@@ -52,6 +53,8 @@ struct DinerMlpImpl {
   float* wmax_dev; // max |parameter| (device scalar, reduced at pack time)
   float wmax;      // ... read back at the end of diner_mlp_create
   float freq_factor;   // PositionalEncoding.freq_factor of the inputs this MLP was trained on
+  unsigned int* fallback_dev;   // launches recomputed by the gated exact-fp32 pass (device counter)
+  uint64_t stamp;      // identity of this handle (DinerScene.proj_stamp)
 };
 
 // mlp_h3n.hip
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post(PostArgs a) {
   const long long n_t16 = (a.P + kPtsPerWave - 1) / kPtsPerWave;
   const long long n_tiles = (n_t16 + 3) / 4;           // 4 waves x 16 points per workgroup tile
   if (a.gate && *a.gate == 0) return;
+  if (a.gate && a.fallback_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.fallback_count, 1u);
 
   WeightStream ws;
   ws.base = a.w_post;
@@ -619,7 +623,7 @@ constexpr size_t kFlagBytes = 256;                           // overflow flag of
 static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa, int nv, float* out, int raw,
                         void* workspace, int precision, hipStream_t stream) {
   DINER_CHECK_ARG(precision == DINER_PRECISION_FP32 || precision == DINER_PRECISION_F16X3 || precision == DINER_PRECISION_F16,
-                  "field: precision must be DINER_PRECISION_FP32 (0), _F16X3 (1) or _F16 (2), got %d", precision);
+                  "field: precision must be DINER_PRECISION_FP32 (0), _F16X3 (1) or _F16 (3), got %d (2 is retired)", precision);
   const int cus = prepare_device();
   if (cus < 0) return cus;
   // explicit matrices (diner_mlp_forward_f32) and weights outside the fp16 range always take the exact kernels
@@ -658,7 +662,7 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     DINER_HIP_OK(hipEventCreate(&e1));
     DINER_HIP_OK(hipEventCreate(&e2));
   }
-  PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw, nullptr, nullptr};
+  PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw, nullptr, nullptr, m->fallback_dev};
   if (use_hn) {
     DINER_HIP_OK(hipMemsetAsync(flag, 0, sizeof(int), stream));
     if (timed) DINER_HIP_OK(hipEventRecord(e0, stream));
@@ -718,6 +722,8 @@ static int mlp_pack(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& i
   DINER_HIP_OK(hipMalloc(&im.b_pre, 7 * kHidden * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&im.b_post, (4 * kHidden + 16) * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&im.wmax_dev, sizeof(float)));
+  DINER_HIP_OK(hipMalloc(&im.fallback_dev, sizeof(unsigned int)));
+  DINER_HIP_OK(hipMemsetAsync(im.fallback_dev, 0, sizeof(unsigned int), stream));
   DINER_HIP_OK(hipMemsetAsync(im.wmax_dev, 0, sizeof(float), stream));
   auto pack = [&](const float* W, int rows, int cols, int n_kc, float* dst) {
     hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, W, rows, cols, n_kc, dst);
@@ -775,6 +781,8 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
   DinerMlp* m = new DinerMlp();
   memset(&m->impl, 0, sizeof(m->impl));
   m->impl.freq_factor = p->freq_factor;
+  static std::atomic<uint64_t> next_stamp{1};
+  m->impl.stamp = next_stamp.fetch_add(1);
   rc = mlp_pack(p, (hipStream_t)stream_, m->impl);
   if (rc) {                       // nothing is left behind by a failed create
     diner_mlp_destroy(m);
@@ -787,7 +795,8 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
 extern "C" int diner_mlp_destroy(DinerMlp* m) {
   if (!m) return 0;
   float* bufs[] = {m->impl.w_hoist, m->impl.w_pre, m->impl.w_post, m->impl.b_hoist, m->impl.b_pre, m->impl.b_post,
-                   m->impl.hn_w, m->impl.hn_w_out, m->impl.hn_b_pre, m->impl.hn_b_post, m->impl.wmax_dev};
+                   m->impl.hn_w, m->impl.hn_w_out, m->impl.hn_b_pre, m->impl.hn_b_post, m->impl.wmax_dev,
+                   (float*)m->impl.fallback_dev};
   for (float* b : bufs)
     if (b) hipFree(b);
   delete m;
@@ -798,6 +807,19 @@ extern "C" int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs) 
   DINER_CHECK_ARG(mlp, "mlp_weights_fit_f16x3: null handle");
   if (max_abs) *max_abs = mlp->impl.wmax;
   return (mlp->impl.wmax == mlp->impl.wmax && mlp->impl.wmax < 1024.0f) ? 1 : 0;
+}
+
+extern "C" uint64_t diner_mlp_stamp(const DinerMlp* mlp) { return mlp ? mlp->impl.stamp : 0; }
+
+extern "C" int diner_mlp_fallback_count(const DinerMlp* mlp, long long* launches, int reset, void* stream_) {
+  DINER_CHECK_ARG(mlp && launches, "mlp_fallback_count: null argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned int n = 0;
+  DINER_HIP_OK(hipMemcpyAsync(&n, mlp->impl.fallback_dev, sizeof(n), hipMemcpyDeviceToHost, stream));
+  if (reset) DINER_HIP_OK(hipMemsetAsync(mlp->impl.fallback_dev, 0, sizeof(n), stream));
+  DINER_HIP_OK(hipStreamSynchronize(stream));
+  *launches = (long long)n;
+  return 0;
 }
 
 extern "C" int diner_profile_enable(int enable) {
@@ -843,9 +865,14 @@ extern "C" size_t diner_mlp_forward_workspace_bytes(long long B) {
   return xpre_bytes(B, kMaxViews) + kFlagBytes + (size_t)B * kMaxViews * (kLatent + kDInPad + 3 * kLatent) * sizeof(float);
 }
 
-static int check_field_scene(const DinerScene* scene, SceneDev* sd) {
+static int check_field_scene(const DinerScene* scene, const DinerMlp* mlp, SceneDev* sd) {
   int rc = make_scene_dev(scene, sd);
   if (rc) return rc;
+  DINER_CHECK_ARG(scene->proj_stamp == mlp->impl.stamp,
+                  "field: scene->latent_proj was prepared with another packed-weights handle (proj_stamp %llu, this handle %llu): "
+                  "the projected maps carry that handle's lin_z / fc_1 biases -- call diner_scene_prepare_f32 with this handle and "
+                  "store diner_mlp_stamp() in scene->proj_stamp", (unsigned long long)scene->proj_stamp,
+                  (unsigned long long)mlp->impl.stamp);
   DINER_CHECK_ARG(scene->nv == kMaxViews, "field: the fused kernel is built for NV=%d source views (got %d)", kMaxViews,
                   scene->nv);
   DINER_CHECK_ARG(scene->C == kLatent, "field: latent size %d != %d", scene->C, kLatent);
@@ -862,7 +889,7 @@ extern "C" int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp
   DINER_CHECK_ARG(scene && mlp && rays && z && field_out && workspace, "field_from_rays: null pointer argument");
   DINER_CHECK_ARG(NR > 0 && K > 0, "field_from_rays: bad sizes NR=%d K=%d", NR, K);
   SceneDev sd;
-  int rc = check_field_scene(scene, &sd);
+  int rc = check_field_scene(scene, mlp, &sd);
   if (rc) return rc;
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -881,7 +908,7 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
   DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && field_out && workspace, "field_from_points: null pointer argument");
   DINER_CHECK_ARG(P > 0, "field_from_points: P must be positive");
   SceneDev sd;
-  int rc = check_field_scene(scene, &sd);
+  int rc = check_field_scene(scene, mlp, &sd);
   if (rc) return rc;
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));

@@ -308,7 +308,8 @@ extern "C" int diner_sample_depthguided_f32(const DinerScene* scene, const float
   DINER_CHECK_ARG(n_cand > 0 && n_cand <= kMaxCand, "sample_depthguided: n_cand=%d outside [1,%d]", n_cand, kMaxCand);
   DINER_CHECK_ARG(K > 0 && K <= kMaxK, "sample_depthguided: n_samples=%d outside [1,%d]", K, kMaxK);
   DINER_CHECK_ARG(G >= 0 && G <= K, "sample_depthguided: need 0 <= n_gaussian <= n_samples (got %d, %d)", G, K);
-  DINER_CHECK_ARG(ray_index0 >= 0, "sample_depthguided: ray_index0 must not be negative");
+  DINER_CHECK_ARG(ray_index0 >= 0 && ray_index0 + NR <= (1ll << 32),
+                  "sample_depthguided: ray_index0 = %lld outside [0, 2^32 - NR] (the noise key of a ray is a 32-bit index)", ray_index0);
   SceneDev sd;
   int rc = make_scene_dev(scene, &sd);
   if (rc) return rc;
@@ -326,6 +327,8 @@ extern "C" int diner_fill_uniform_f32(const float* z_in, const float* rays, int 
                                       uint64_t seed, long long ray_index0, float* z_out, void* stream) {
   DINER_CHECK_ARG(z_in && rays && z_out, "fill_uniform: null pointer argument");
   DINER_CHECK_ARG(NR > 0 && K > 0 && K <= kMaxK, "fill_uniform: bad sizes NR=%d K=%d", NR, K);
+  DINER_CHECK_ARG(ray_index0 >= 0 && ray_index0 + NR <= (1ll << 32),
+                  "fill_uniform: ray_index0 = %lld outside [0, 2^32 - NR] (the noise key of a ray is a 32-bit index)", ray_index0);
   const int blocks = (NR + kRaysPerBlock - 1) / kRaysPerBlock;
   hipLaunchKernelGGL(k_fill_uniform, dim3(blocks), dim3(kRaysPerBlock * kWave), 0, (hipStream_t)stream, z_in, rays, NR,
                      K, noise_fill, seed, (uint32_t)ray_index0, z_out);

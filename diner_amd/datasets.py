@@ -514,7 +514,12 @@ def collate(samples):
     out = {}
     for k in samples[0]:
         v = [s[k] for s in samples]
-        out[k] = torch.stack(v) if torch.is_tensor(v[0]) else v
+        if torch.is_tensor(v[0]):
+            out[k] = torch.stack(v)
+        elif isinstance(v[0], (bool, int, float)):         # numeric scalars become tensors, as torch's default_collate does
+            out[k] = torch.tensor(v, dtype=torch.bool if isinstance(v[0], bool) else torch.float64 if isinstance(v[0], float) else torch.int64)
+        else:
+            out[k] = v
     return out
 
 

@@ -119,6 +119,7 @@ class HipScene:
         s.img_w, s.img_h, s.feature_padding = self.img_w, self.img_h, self.feature_padding
         s.nv, s.C, s.Hf, s.Wf, s.Hs, s.Ws = self.nv, self.C, self.Hf, self.Wf, self.Hs, self.Ws
         s.latent_proj = None
+        s.proj_stamp = 0
         self.struct = s
         self.latent_proj = None
         self._prepared_for = None
@@ -136,6 +137,7 @@ class HipScene:
                 self.latent_proj = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
             _lib.check(lib.diner_scene_prepare_f32(self.ref, mlp.handle, _ptr(self.latent_proj), _stream()))
         self.struct.latent_proj = self.latent_proj.data_ptr()
+        self.struct.proj_stamp = lib.diner_mlp_stamp(mlp.handle)      # the library refuses these maps with any other handle
         self._prepared_for = mlp
 
     @property
@@ -187,6 +189,15 @@ class HipMlp:
         wmax = C.c_float()
         self.h3_ok = lib.diner_mlp_weights_fit_f16x3(h, C.byref(wmax)) == 1
         self.wmax = float(wmax.value)
+
+    def fallback_launches(self, reset=False):
+        """Field launches with this handle that the fp16-operand kernels could not finish (an activation left the fp16 range or an
+        input was not finite) and that the gated exact-fp32 kernels recomputed on the device: correct results, 2-3x the time.
+        Synchronises the current stream (one 4-byte read back)."""
+        n = C.c_longlong()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.diner_mlp_fallback_count(self.handle, C.byref(n), int(bool(reset)), _stream()))
+        return int(n.value)
 
     def __del__(self):
         try:
@@ -411,7 +422,7 @@ def profile_collect():
 
 
 # ---- arithmetic of the MLP GEMMs: a per-call argument of the C ABI (DINER_PRECISION_* of include/diner_hip.h) --------
-PRECISION_FP32, PRECISION_F16X3, PRECISION_F16 = 0, 1, 2
+PRECISION_FP32, PRECISION_F16X3, PRECISION_F16 = 0, 1, 3      # DINER_PRECISION_* (2 is retired and rejected)
 PRECISION_NAMES = {"fp32": PRECISION_FP32, "f32": PRECISION_FP32, "exact": PRECISION_FP32,
                    "f16x3": PRECISION_F16X3, "f16x3n": PRECISION_F16X3, "split": PRECISION_F16X3,
                    "f16": PRECISION_F16, "fp16": PRECISION_F16, "half": PRECISION_F16}
@@ -426,8 +437,9 @@ def set_precision(mode):
     1e-4 parity bar.  Env: DINER_AMD_PRECISION = fp32 | f16x3 | f16."""
     if isinstance(mode, str):
         mode = PRECISION_NAMES[mode.lower()]
-    if int(mode) not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16):
-        raise ValueError(f"diner_amd: unknown precision {mode!r}")
+    if isinstance(mode, bool) or int(mode) not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16):
+        raise ValueError(f"diner_amd: unknown precision {mode!r} (use the names 'fp32' / 'f16x3' / 'f16' or the PRECISION_* "
+                         f"constants; the integer 2 of ABI v1 is retired)")
     _default_precision[0] = int(mode)
 
 
@@ -440,6 +452,8 @@ def _precision_for(scene, precision):
     fp16-operand kernels (>= 4 GiB per map: images beyond ~2700 x 2700) is rendered by the exact kernels."""
     prec = get_precision() if precision is None else (PRECISION_NAMES[precision.lower()] if isinstance(precision, str)
                                                       else int(precision))
+    if prec not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16):
+        raise ValueError(f"diner_amd: unknown precision {precision!r}")
     if prec != PRECISION_FP32 and scene.nv * scene.Hf * scene.Wf * 2048 >= (1 << 32):
         return PRECISION_FP32
     return prec

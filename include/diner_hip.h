@@ -9,8 +9,9 @@
  * Conventions
  *   - all pointers are DEVICE pointers (HIP) to contiguous row-major fp32 unless stated;
  *   - every call only ENQUEUES work on the caller's stream (hipStream_t passed as void*);
- *     no hidden synchronisation, no allocation, no global mutable state besides the
- *     thread-local error string;
+ *     no hidden synchronisation, no global mutable state besides the thread-local error string, and no
+ *     device allocation -- with one exception: diner_mlp_create() hipMallocs the buffers of the packed-weights
+ *     handle it returns (freed by diner_mlp_destroy) and synchronises `stream` once before it returns;
  *   - return value: 0 = ok, negative = DINER_E_*; diner_last_error() gives the message;
  *   - the caller (PyTorch's caching allocator in the Python host) owns all buffers; the library
  *     owns only the packed-weights handle created by diner_mlp_create().
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DINER_ABI_VERSION 2
+#define DINER_ABI_VERSION 3
 
 #define DINER_E_INVALID     (-1)  /* bad argument (null pointer, size, unsupported configuration) */
 #define DINER_E_UNSUPPORTED (-2)  /* configuration outside what the kernels are built for        */
@@ -55,6 +56,10 @@ typedef struct DinerScene {
   float img_w, img_h;       /* PixelNeRF.image_shape = [W, H] (pixelnerf.py:50-51)                         */
   float feature_padding;    /* SpatialEncoder.feature_padding (image_encoder.py:59), 32 in the shipped configs */
   int32_t nv, C, Hf, Wf, Hs, Ws;
+  uint64_t proj_stamp;      /* diner_mlp_stamp() of the handle that wrote latent_proj (set by the caller after
+                               diner_scene_prepare_f32).  The field entry points return DINER_E_INVALID when it is not the
+                               stamp of the handle they are called with: maps prepared with another (or an older) handle carry
+                               that handle's biases */
 } DinerScene;
 
 /* ResnetFC parameters as the reference stores them (nn.Linear: weight (out,in), bias (out));
@@ -89,6 +94,13 @@ int diner_mlp_destroy(DinerMlp* mlp);
  * stream synchronise): DINER_PRECISION_F16X3 / _F16 carry the weights x16 as fp16 and need it below 1024.
  * Returns 1 when the f16 modes may be used with this handle, 0 when not, <0 on error; *max_abs (optional) receives the value. */
 int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs);
+/* Identity of a packed-weights handle: unique per diner_mlp_create call of the process, never 0.  Goes into
+ * DinerScene.proj_stamp after diner_scene_prepare_f32(scene, mlp, ...). */
+uint64_t diner_mlp_stamp(const DinerMlp* mlp);
+/* Number of field launches with this handle whose fp16-operand pass left the fp16 range (or met a non-finite input) and were
+ * recomputed by the exact-fp32 kernels on the device (see DINER_PRECISION_* below) -- a 2-3x slower launch that is otherwise
+ * invisible.  Waits for `stream` (one 4-byte read back); `reset` != 0 zeroes the counter. */
+int diner_mlp_fallback_count(const DinerMlp* mlp, long long* launches, int reset, void* stream);
 
 /* ---- a1+a2+a3+a4: NeRFRendererDGS.sample_depthguided + fill_up_uniform_samples ---------------
  * (nerf_renderer.py:39-63, :65-190, :367-397; torch_helpers.py:215-223; image_encoder.py:148-223)
@@ -133,7 +145,8 @@ int diner_scene_prepare_f32(const DinerScene* scene, const DinerMlp* mlp, float*
  * diner_mlp_forward_f32 (explicit matrices), diner_scene_prepare_f32 and the training path always use exact fp32. */
 #define DINER_PRECISION_FP32  0
 #define DINER_PRECISION_F16X3 1
-#define DINER_PRECISION_F16   2
+#define DINER_PRECISION_F16   3   /* (2 is retired: it meant the parity-grade split mode in ABI v1 and is rejected, so that an old
+                                     caller passing the bare integer cannot end up in the reduced-precision mode) */
 
 /* ---- a5+a6+a7+a8: PixelNeRF.forward at ray samples -------------------------------------------
  * (pixelnerf.py:55-145; positional_encoding.py:33-53; image_encoder.py:97-170; resnetfc.py:129-159)

@@ -239,6 +239,65 @@ def test_render_from_facescape_sample(tmp_path):
     frac = float((err < TOL).float().mean())
     print(f"facescape sample: {H}x{W}, rays within 1e-4: {frac:.4f}, worst {float(err.max()):.2e}, PSNR vs oracle {psnr:.1f} dB")
     # rays whose sample selection is implementation-defined (erf saturation / ties, see tests/helpers.selection_diff) may differ
-    assert frac >= 0.97 and psnr > 40.0
+    assert frac >= 0.985 and psnr > 50.0        # measured 0.992 / 54.8 dB
     derr = (depth[0, 0].reshape(-1).cpu() - ref["depth"]).abs()
     assert float(derr[err < TOL].max()) < TOL * ds.zfar
+
+
+def test_render_from_dtu_sample():
+    """Rows f4 -> a, the data set of BASELINE configs[0], [2], [3]: the DTU sample dict assembled from the on-disk layout
+    (tests/golden/dtu_tiny: cam files, rectified PNGs, TransMVSNet uint16 depth / confidence PNGs; pinned bit for bit against the
+    reference's own DTUDataSet on the CPU side, G13; reference src/data/dtu.py:183-239) goes through encode() (ResNet trunk, torch)
+    and the HIP renderer at the metric's sample count (K = 128, 48 gaussian, 1000 candidates) and the data set's depth range; the
+    320x256 image is compared with the CPU oracle rendering the same encoded scene with the same noise on a 48x40 lattice of its rays."""
+    import os
+    from oracle import diner_oracle as O
+    from diner_amd import noise
+    from diner_amd.datasets import DTUSamples, collate, encode_args
+    from diner_amd.render import predict_image
+    from diner_amd.synthetic import make_mlp_state_dict
+    from src.util.import_helper import import_obj
+    from tests.helpers import GOLD
+    g13 = load("g13_dtu_sample.npz")
+    tree = os.path.join(GOLD, "dtu_tiny")
+    ds = DTUSamples(tree, "val", scan_list=os.path.join(tree, "scan_list.txt"))
+    batch = collate([ds[int(g13["idx"])]])
+    H, W = batch["target_rgb"].shape[-2:]
+    assert (H, W) == (256, 320)
+    torch.manual_seed(0)                      # the ResNet trunk's random init decides the feature maps
+    nerf = build_nerf().cuda().eval()
+    msd = make_mlp_state_dict()
+    nerf.mlp_fine.load_state_dict(msd)
+    with torch.no_grad():
+        nerf.encode(**encode_args(batch, "cuda"))
+    K, G, NC = 128, 48, 1000
+    ren = import_obj("src.models.nerf_renderer.NeRFRendererDGS")(n_samples=K, n_gaussian=G, n_depth_candidates=NC, white_bkgd=False)
+    g = torch.Generator().manual_seed(7)
+    nz = (torch.rand(1, H * W, NC, generator=g), torch.randn(1, H * W, G, generator=g), torch.rand(1, H * W, K, generator=g))
+    with noise.inject(*[n.cuda() for n in nz]):
+        rgb, depth = predict_image(nerf, ren, batch["target_extrinsics"].cuda(), batch["target_intrinsics"].cuda(), W, H,
+                                   ds.znear, ds.zfar, ray_batch_size=8192)
+    assert rgb.shape == (1, 3, H, W) and torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+    enc = nerf.encoder
+    Kin = batch["src_intrinsics"][0]
+    scene = O.Scene(latent=enc.latent[0].cpu(), depths=enc.depths[0].cpu(), depths_std=enc.depths_std[0].cpu(),
+                    normals=enc.normals[0].cpu(), poses=batch["src_extrinsics"][0], focal=Kin[:, [0, 1], [0, 1]], c=Kin[:, :2, -1],
+                    image_shape=nerf.image_shape.cpu(), feature_padding=enc.feature_padding)
+    w = O.MLPWeights.from_state_dict(msd)
+    rays = O.gen_rays(batch["target_extrinsics"][0], batch["target_intrinsics"][0], W, H, ds.znear, ds.zfar)
+    rows, cols = torch.linspace(0, H - 1, 40).round().long(), torch.linspace(0, W - 1, 48).round().long()
+    idx = (rows[:, None] * W + cols[None, :]).reshape(-1)
+    ref = O.render(scene, w, rays[idx].contiguous(), K, NC, G, False, nz[0][0][idx], nz[1][0][idx], nz[2][0][idx])
+    got = rgb[0].permute(1, 2, 0).reshape(-1, 3).cpu()[idx]
+    scale = ref["rgb"].abs().max()
+    err = (got - ref["rgb"]).abs().max(-1).values / scale
+    mse = float(((got - ref["rgb"]) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    frac = float((err < TOL).float().mean())
+    n_surf = int(((ref["weights"].sum(-1)) > 0.5).sum())
+    print(f"dtu sample: {H}x{W} at K={K}, {len(idx)} lattice rays ({n_surf} with sum(w) > 0.5): within 1e-4 of the oracle: {frac:.4f}, "
+          f"worst {float(err.max()):.2e}, PSNR vs oracle {psnr:.1f} dB")
+    # rays whose sample selection is implementation-defined (erf round-off at the cut-off, tests/test_hip_parity.py) may differ
+    assert frac >= 0.98 and psnr > 45.0
+    derr = (depth[0, 0].reshape(-1).cpu()[idx] - ref["depth"]).abs() / ref["depth"].abs().max()
+    assert float(derr[err < TOL].max()) < TOL

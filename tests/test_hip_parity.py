@@ -398,6 +398,34 @@ def test_fp16_overflow_falls_back_to_exact_kernels(ops):
     # in-range network: the flag stays down and the fp16-operand result is NOT the fp32 one bit for bit (different arithmetic)
     a, b = ops.field_from_points(hs, hm2, pts, dirs, precision="f16x3"), ops.field_from_points(hs, hm2, pts, dirs, precision="fp32")
     assert max_norm_rel(a.cpu(), b.cpu()) < TOL_STAGE and not torch.equal(a, b)
+    # the fall-back is visible: the handle counts the launches the exact kernels had to recompute
+    assert hm.fallback_launches() == 2 and hm2.fallback_launches() == 0
+    assert hm.fallback_launches(reset=True) == 2 and hm.fallback_launches() == 0
+
+
+def test_scene_prepared_with_another_handle_is_refused(ops):
+    """The projected maps carry the lin_z / fc_1 biases of the handle that prepared them (DinerScene.proj_stamp): the C ABI refuses
+    them with any other handle instead of silently dropping or duplicating biases; the retired precision value 2 is refused too."""
+    import ctypes as C
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    hs = hip_scene(ops, sc)
+    hm_a, hm_b = hip_mlp(ops, msd), hip_mlp(ops, msd)
+    pts, dirs = T(g["pts"]).cuda(), T(g["dirs"]).cuda()
+    out = torch.empty(pts.shape[0], 4, device="cuda")
+    ws = torch.empty(ops.lib.diner_field_workspace_bytes(pts.shape[0]), dtype=torch.uint8, device="cuda")
+    hs.prepare(hm_a)
+
+    def call(handle, prec):
+        return ops.lib.diner_field_from_points_f32(hs.ref, handle, C.c_void_p(pts.data_ptr()), C.c_void_p(dirs.data_ptr()),
+                                                   pts.shape[0], prec, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert call(hm_a.handle, ops.PRECISION_F16X3) == 0
+    assert call(hm_b.handle, ops.PRECISION_F16X3) == -1 and b"another packed-weights handle" in ops.lib.diner_last_error()
+    assert call(hm_a.handle, 2) == -1 and b"retired" in ops.lib.diner_last_error()
+    with pytest.raises(ValueError):
+        ops.set_precision(2)
+    assert max_norm_rel(ops.field_from_points(hs, hm_b, pts, dirs).cpu(), g["out"]) < TOL_STAGE      # the host re-prepares
 
 
 def test_freq_factor_is_honoured(ops, precision):
