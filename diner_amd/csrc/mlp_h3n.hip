@@ -42,18 +42,23 @@ constexpr size_t kLdsBytesPost = (size_t)kBHalfs * 2;
 // each use site: otherwise the compiler materialises one address register per fragment, hoists them out of the
 // tile loop and spills them.
 typedef __attribute__((address_space(3))) char* lds_ptr;
+typedef __attribute__((address_space(3))) h8* lds_h8;
+constexpr int kChunkBytes = 4 * kGroups * 2 * 1024;      // a chunk = four k32 blocks = 32 fragments of 1 KB
 struct LdsB {
-  lds_ptr lo, hi;          // lane's 16 B slot in fragment 0 of k32 blocks 0 and 8
-  __device__ __forceinline__ static LdsB make(h8* base, int lane) {
-    lds_ptr p = (lds_ptr)(reinterpret_cast<char*>(base)) + lane * 16;
-    return {p, p + 65536};
-  }
-  __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(lo), "+v"(hi)); }
-  __device__ __forceinline__ __attribute__((address_space(3))) h8* at(int t, int g, int hl) const {      // fragment (t, g, hl)
-    const int frag = ((t & 7) * kGroups + g) * 2 + hl;
-    return (__attribute__((address_space(3))) h8*)((t < 8 ? lo : hi) + frag * 1024);
+  lds_ptr base;            // lane's 16 B slot in fragment 0 of k32 block 0
+  __device__ __forceinline__ static LdsB make(h8* b, int lane) { return {(lds_ptr)(reinterpret_cast<char*>(b)) + lane * 16}; }
+  __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(base)); }
+  // pointer to chunk c (k32 blocks 4c .. 4c+3); c may be a run-time (wave-uniform) value.  Fragments are then reached with
+  // immediates (the ds offset field holds 16 bits; a chunk is 32 KB)
+  __device__ __forceinline__ lds_ptr chunk(int c) const { return base + c * kChunkBytes; }
+  __device__ __forceinline__ static lds_h8 at(lds_ptr cb, int tl, int g, int hl) {       // fragment (block tl of the chunk, g, hl)
+    return (lds_h8)(cb + ((tl * kGroups + g) * 2 + hl) * 1024);
   }
 };
+// Order in which wave w walks the four chunks of a 512-wide contraction: its OWN chunk first (k32 blocks 4w .. 4w+3 are the B
+// operands this wave itself publishes -- it can multiply with them straight from its registers, before anybody else has
+// published anything), then the others in ascending order.  The weights are packed in that order per wave (k_pack_layer_h3n).
+__device__ __forceinline__ int chunk_of(int pos, int wave) { return pos == 0 ? wave : (pos - 1 < wave ? pos - 1 : pos); }
 
 #define DINER_HN_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
 
@@ -246,42 +251,151 @@ struct ARing {
   }
 };
 
-template <int KT, int R, bool LO, class Side>
-__device__ __forceinline__ void gemm(ARing<KT, R, LO>& ring, LdsB B, f32x4 (&acc)[kSlice][kGroups], Side& side) {
+// one IEEE fp32 multiply / add as an opaque single instruction (see GatherSide::blend_step)
+__device__ __forceinline__ float mul1(float a, float b) {
+  float d;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float mul1s(float a, float s) {      // s: wave-uniform (SGPR or inline constant), no VGPR for it
+  float d;
+  asm("v_mul_f32 %0, %2, %1" : "=v"(d) : "v"(a), "s"(s));
+  return d;
+}
+__device__ __forceinline__ float add1(float a, float b) {
+  float d;
+  asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// ---- fp32 accumulator values -> fp16 (hi, lo) B operands, in SINGLE-WIDTH full-rate instructions (tools/ubench/valu_rate: 4.5-4.8 clocks
+// each; packed-fp32 arithmetic does not overlap with MFMAs at all and v_fma_mixlo/hi_f16 are half rate):
+//   v = max_i32(x, 0) * scale                     relu on the bit pattern, one multiply
+//   hi = v_cvt_pk_f16_f32(v0, v1)                 round-to-nearest-even, two values per instruction
+//   r  = v_fma_mix_f32(hi.half, -1.0, v)          v - float(hi): exact, the fp16 operand is read in place
+//   lo = v_cvt_pk_f16_f32(r0, r1)
+// = 4.5 instructions per value with the accumulator read (the compiler's version of the same arithmetic: 5.5).
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  unsigned d;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float resid_lo(unsigned h, float v) {       // v - float(low half of h)
+  float d;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(v));
+  return d;
+}
+__device__ __forceinline__ float resid_hi(unsigned h, float v) {       // v - float(high half of h)
+  float d;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(v));
+  return d;
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// four accumulator values (rows 4q .. 4q+3 of one row tile, one column) -> dwords [2 part, 2 part + 1] of the B fragments hi / lo
+template <bool LO, int PART>
+__device__ __forceinline__ void cvt4(const f32x4& x, float scale, u32x4& h, u32x4& l) {
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // the source stays in the accumulator half of the file: an explicit v_accvgpr_read per value (a plain read lets the register
+    // allocator move whole accumulator tuples of the block into VGPRs across the GEMM and spill others to make room)
+    int xi;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(xi) : "a"(x[i]));
+    v[i] = mul1s(__int_as_float(max(xi, 0)), scale);
+  }
+  const unsigned h0 = cvt_pk_f16(v[0], v[1]), h1 = cvt_pk_f16(v[2], v[3]);
+  h[2 * PART] = h0;
+  h[2 * PART + 1] = h1;
+  if constexpr (LO) {
+    l[2 * PART] = cvt_pk_f16(resid_lo(h0, v[0]), resid_hi(h0, v[1]));
+    l[2 * PART + 1] = cvt_pk_f16(resid_lo(h1, v[2]), resid_hi(h1, v[3]));
+  }
+}
+
+// acc[mo][g] += W[slice rows][all k] . B[k][cols g]   (A straight from global, wave-private; B = the activations in fp16 hi / lo).
+// Fully unrolled over 2 KT half-steps (k32 block, row-tile half) of four quarter-steps (column group g): 12 MFMAs
+// each (4 row tiles x {hi*hi, lo*hi, hi*lo}), an accumulator revisited 4 MFMAs apart.  A 512-wide contraction is walked in
+// the wave's own chunk order (chunk_of): position 0 = the k32 blocks this wave publishes.
+//   * A fragments (8 x 1 KB per half-step, wave-private) are requested R-1 half-steps ahead, two per quarter-step,
+//     into a ring of R register buffers (an L2 hit takes longer than one half-step's 768 MFMA cycles);
+//   * B fragments (hi, lo of one column group, shared through LDS) live in one buffer: group g of the next k32 block is re-read
+//     right after its last use in the second half (576 MFMA cycles before the next use);
+//   * the side task gets a slot per quarter-step, so its VALU / VMEM work is spread between the MFMAs;
+//   * OWN (round 3): the B operands of the wave's own chunk never come back from LDS.  `src` (the accumulator block whose relu
+//     is this GEMM's input) is converted by this wave anyway: block 0 in front of the GEMM, block tl + 1 as a side task of block
+//     tl's 96 MFMAs -- one f32x4 per quarter-step, written to LDS for the other waves and kept in registers (cv) as this wave's B
+//     operands.  A barrier in front of chunk position 1 is the only one the publish needs (everybody's blocks are in LDS then);
+//     the conversion of 3/4 of a publish and all of its LDS writes run in the MFMAs' shadow instead of in front of the GEMM.
+// LO = false: plain fp16 operands (hi parts only, one MFMA per product; DINER_PRECISION_F16).
+template <int KT, int R, bool LO, bool OWN, class Side>
+__device__ __forceinline__ void gemm(ARing<KT, R, LO>& ring, LdsB B, int wave, const f32x4 (&src)[kSlice][kGroups], float scale,
+                                     f32x4 (&acc)[kSlice][kGroups], Side& side) {
   constexpr int NH = 2 * KT;
+  static_assert(!OWN || KT == 16, "own-chunk scheme: 512-wide contractions only");
   h8 bb[kGroups][2];                     // B of the current k32 block: [g][hl]
   B.opaque();
+  lds_ptr cbp[4];                        // chunk pointers, made when first needed (wave-uniform offsets on the lane's base)
+  auto chunk_ptr = [&](int pos) {
+    lds_ptr cb = B.chunk(KT == 16 ? chunk_of(pos, wave) : 0);
+    asm volatile("" : "+v"(cb));
+    return cb;
+  };
   auto load_b = [&](int t, int g) {
 #ifdef DINER_HN_NO_B          // ablation: price the LDS operand reads
     asm volatile("" : "+v"(bb[g][0]), "+v"(bb[g][1]));
 #else
-    bb[g][0] = *B.at(t, g, 0);
-    if (LO) bb[g][1] = *B.at(t, g, 1);
+    bb[g][0] = *LdsB::at(cbp[t >> 2], t & 3, g, 0);
+    if (LO) bb[g][1] = *LdsB::at(cbp[t >> 2], t & 3, g, 1);
 #endif
   };
+  cbp[0] = chunk_ptr(0);
 #if defined(DINER_HN_NO_A) || defined(DINER_HN_NO_B)
 #pragma unroll
-  for (int g = 0; g < kGroups; ++g) bb[g][0] = bb[g][1] = *B.at(0, g, 0);
+  for (int g = 0; g < kGroups; ++g) bb[g][0] = bb[g][1] = *LdsB::at(cbp[0], 0, g, 0);
 #endif
 #pragma unroll
-  for (int g = 0; g < kGroups; ++g) load_b(0, g);
+  for (int g = 0; g < kGroups; ++g) load_b(0, g);      // (OWN: block 0 of the own chunk, written by this wave just before)
+  u32x4 ch, cl;                          // OWN: the fragment pair being converted
   static_for<NH * kGroups>([&](auto Q) {
     constexpr int qi = decltype(Q)::value;
     constexpr int h = qi >> 2, g = qi & 3;
     constexpr int t = h >> 1, half = h & 1;
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (h + R - 1 < NH) ring.load_a2(ring.a[(h + R - 1) % R], g);
-    if constexpr (half == 1 && g > 0 && t + 1 < KT) load_b(t + 1, g - 1);       // previous quarter's group is free
-    if constexpr (half == 0 && g == 0 && t > 0) load_b(t, kGroups - 1);         // ... and the last one of block t-1
+    if constexpr (OWN && t == 4 && half == 0 && g == 0) __syncthreads();      // every wave's own blocks are in LDS behind this barrier
+    if constexpr (half == 1 && g == 1 && (t & 3) == 3 && t + 1 < KT) cbp[(t + 1) >> 2] = chunk_ptr((t + 1) >> 2);
+    // previous quarter's group is free (OWN: chunk position 1 belongs to another wave -- not before the barrier)
+    if constexpr (half == 1 && g > 0 && t + 1 < KT && !(OWN && t == 3)) load_b(t + 1, g - 1);
+    if constexpr (OWN && t == 4 && half == 0 && g == 0) {
+#pragma unroll
+      for (int g2 = 0; g2 < kGroups; ++g2) load_b(4, g2);
+    } else {
+      if constexpr (half == 0 && g == 0 && t > 0) load_b(t, kGroups - 1);         // ... and the last one of block t-1
+    }
+    if constexpr (OWN && t + 1 < 4) {    // convert block t + 1 of the own chunk, one f32x4 per quarter-step: unit u of 8
+      constexpr int u = half * 4 + g, gu = u >> 1, part = u & 1;
+      cvt4<LO, part>(src[2 * (t + 1) + part][gu], scale, ch, cl);
+      if constexpr (part == 1) {         // the pair is complete: to LDS, for the other waves and for this one (in order: no barrier)
+        asm volatile("" : "+v"(cbp[0]));
+        *LdsB::at(cbp[0], t + 1, gu, 0) = __builtin_bit_cast(h8, ch);
+        if constexpr (LO) *LdsB::at(cbp[0], t + 1, gu, 1) = __builtin_bit_cast(h8, cl);
+      }
+    }
     side.template run<h, g>();
     h8 (&ac)[8] = ring.a[h % R];
+    const h8 b0 = bb[g][0], b1 = bb[g][1];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][0]);
+    for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], b0);
     if constexpr (LO) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m + 1], bb[g][0]);
+      for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m + 1], b0);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], bb[g][1]);
+      for (int m = 0; m < 4; ++m) DINER_HN_MFMA(acc[4 * half + m][g], ac[2 * m], b1);
     }
     // Anchor the quarter-step's results here (no code): MFMAs are pure, and without a use in place the optimiser may
     // sink a whole accumulation chain below all of the GEMM's loads (seen in k_field_post_h3n: every fragment spilled).
@@ -290,72 +404,84 @@ __device__ __forceinline__ void gemm(ARing<KT, R, LO>& ring, LdsB B, f32x4 (&acc
   });
   side.finish();
 }
-// start + run in one go (no publish in front of it)
+// all B operands from LDS (published before the call): start + run in one go
 template <int KT, int R, bool LO, class Side>
 __device__ __forceinline__ void gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
                                      f32x4 (&acc)[kSlice][kGroups], Side& side) {
   ARing<KT, R, LO> ring;
   ring.start(layer, wave, lane);
-  gemm<KT, R, LO>(ring, B, acc, side);
+  gemm<KT, R, LO, false>(ring, B, wave, acc, 0.0f, acc, side);
 }
 
-// relu(x) * scale of eight accumulator values -> fp16 hi parts and lo parts (x * scale - hi), packed as MFMA B operands.
-__device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, float scale, h8& h, h8& l) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float x = j < 4 ? lo4[j] : hi4[j - 4];
-    const float v = __int_as_float(max(__float_as_int(x), 0)) * scale;
-    const _Float16 hh = (_Float16)v;
-    h[j] = hh;
-    l[j] = (_Float16)(v - (float)hh);
-  }
-}
-
-// publish relu(acc)/16 of this wave's 128-feature slice as B operands (k32 blocks 4w .. 4w+3) for all 4 column groups
+// publish relu(acc) * scale of this wave's 128-feature slice as B operands (its own chunk: k32 blocks 4w .. 4w+3) for all 4 column
+// groups, in front of a GEMM (the GEMMs that carry a gather side task, lin_out)
 template <bool LO>
 __device__ __forceinline__ void publish(LdsB B, int wave, int lane, const f32x4 (&acc)[kSlice][kGroups]) {
   B.opaque();
 #ifdef DINER_HN_NO_PUBLISH
   return;
 #endif
+  lds_ptr cb = B.chunk(wave);
+  asm volatile("" : "+v"(cb));
 #pragma unroll
   for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
-      h8 h, l;
-#ifdef DINER_HN_PUB_NOCVT        // ablation: LDS writes only
-      h = __builtin_bit_cast(h8, acc[2 * tl][g]);
-      l = __builtin_bit_cast(h8, acc[2 * tl + 1][g]);
-#else
-      split8(acc[2 * tl][g], acc[2 * tl + 1][g], kInvScale, h, l);
-#endif
-      const int t = 4 * wave + tl;
-#ifdef DINER_HN_PUB_NOWRITE      // ablation: conversion only
-      asm volatile("" :: "v"(h), "v"(l));
-#else
-      *B.at(t, g, 0) = h;
-      if constexpr (LO) *B.at(t, g, 1) = l;
-#endif
+      u32x4 h, l;
+      cvt4<LO, 0>(acc[2 * tl][g], kInvScale, h, l);
+      cvt4<LO, 1>(acc[2 * tl + 1][g], kInvScale, h, l);
+      *LdsB::at(cb, tl, g, 0) = __builtin_bit_cast(h8, h);
+      if constexpr (LO) *LdsB::at(cb, tl, g, 1) = __builtin_bit_cast(h8, l);
     }
 }
 
-// hidden state -> B operands, then the GEMM of `layer` on them: barrier, publish, barrier, GEMM, with the weight ring started first
-template <int R, bool LO, bool EARLY, class Side, class Between>
+// relu(src) -> B operands and the GEMM of `layer` on them.  OWN: the own-chunk scheme of gemm (one barrier in front, block 0 of the
+// own chunk converted before it so that the wait overlaps with the conversion, one barrier inside the GEMM); otherwise barrier,
+// publish, barrier, GEMM.  The weight ring is started first (EARLY) -- the barriers wait on LDS traffic only.
+template <int R, bool LO, bool EARLY, bool OWN, bool BIAS_FIRST = true, class Side, class Between>
 __device__ __forceinline__ void publish_gemm(const _Float16* __restrict__ layer, LdsB B, int wave, int lane,
                                              const f32x4 (&src)[kSlice][kGroups], f32x4 (&acc)[kSlice][kGroups], Side& side,
                                              Between&& between, Prof& pf, int ph) {
   ARing<16, R, LO> ring;
   if constexpr (EARLY) ring.start(layer, wave, lane);
-  __syncthreads();                                // everybody finished reading the previous B
-  pf.mark(ph);
-  publish<LO>(B, wave, lane, src);
-  pf.mark(ph + 1);
-  __syncthreads();
-  pf.mark(ph + 2);
-  between();                                      // bias of the accumulators the GEMM adds into
-  if constexpr (!EARLY) ring.start(layer, wave, lane);
-  gemm<16, R, LO>(ring, B, acc, side);
-  pf.mark(ph + 3);
+  if constexpr (OWN) {
+    if constexpr (BIAS_FIRST) between();          // bias of the accumulators the GEMM adds into (its loads fly during the conversion)
+    u32x4 c0[kGroups][2];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {           // block 0 of the own chunk, converted while the others finish the previous GEMM
+      cvt4<LO, 0>(src[0][g], kInvScale, c0[g][0], c0[g][1]);
+      cvt4<LO, 1>(src[1][g], kInvScale, c0[g][0], c0[g][1]);
+    }
+    pf.mark(ph);
+    __syncthreads();                              // everybody finished reading the previous B
+    pf.mark(ph + 1);
+    {
+      B.opaque();
+      lds_ptr cb = B.chunk(wave);
+      asm volatile("" : "+v"(cb));
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        *LdsB::at(cb, 0, g, 0) = __builtin_bit_cast(h8, c0[g][0]);
+        if constexpr (LO) *LdsB::at(cb, 0, g, 1) = __builtin_bit_cast(h8, c0[g][1]);
+      }
+    }
+    if constexpr (!BIAS_FIRST) between();
+    if constexpr (!EARLY) ring.start(layer, wave, lane);
+    pf.mark(ph + 2);
+    gemm<16, R, LO, true>(ring, B, wave, src, kInvScale, acc, side);
+    pf.mark(ph + 3);
+  } else {
+    __syncthreads();                              // everybody finished reading the previous B
+    pf.mark(ph);
+    publish<LO>(B, wave, lane, src);
+    pf.mark(ph + 1);
+    __syncthreads();
+    pf.mark(ph + 2);
+    between();                                    // bias of the accumulators the GEMM adds into
+    if constexpr (!EARLY) ring.start(layer, wave, lane);
+    gemm<16, R, LO, false>(ring, B, wave, src, kInvScale, acc, side);
+    pf.mark(ph + 3);
+  }
 }
 
 // Tell the register allocator that a block of accumulators lives in the AGPR half of the file at this point (no code).
@@ -383,29 +509,24 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
   }
 }
 
+#ifndef DINER_HN_OWN            // 1: own-chunk scheme on every GEMM without a gather side task (see gemm); 0: exposed publishes
+#define DINER_HN_OWN 1
+#endif
+#ifndef DINER_HN_EARLY1         // weight ring of the fc_1 GEMMs started in front of the conversion as well
+#define DINER_HN_EARLY1 0
+#endif
+#ifndef DINER_HN_EARLYP         // ... and in the post kernel
+#define DINER_HN_EARLYP 0
+#endif
+#ifndef DINER_HN_OWNG           // the same on the two GEMMs that carry the gather side task
+#define DINER_HN_OWNG 1
+#endif
 #ifndef DINER_HN_GDEPTH
 #define DINER_HN_GDEPTH 2
 #endif
 #ifndef DINER_HN_G0DEPTH        // units in flight for block 0's stand-alone gather (no GEMM buffers live there)
 #define DINER_HN_G0DEPTH 8
 #endif
-
-// one IEEE fp32 multiply / add as an opaque single instruction (see GatherSide::blend_step)
-__device__ __forceinline__ float mul1(float a, float b) {
-  float d;
-  asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-__device__ __forceinline__ float add1(float a, float b) {
-  float d;
-  asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-__device__ __forceinline__ float fma1(float a, float b, float c) {
-  float d;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
 
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
 // (g, mo) of 4 taps each.  As a GEMM side task (SIDE) one unit's taps are requested per half-step, one per quarter-step, and
@@ -598,14 +719,23 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       g0.all();
       pf.mark(5);
     }
-    for (int b = 0; b < 3; ++b) {
+#pragma nounroll
+    for (int b = 0; b < 2; ++b) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
       {
         NoSide none;
-        publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYA != 0>(w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none,
-                                         [&] { set_bias(ns, bias, wave, q); }, pf, 6);
+        publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
+            w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] { set_bias(ns, bias, wave, q); }, pf, 6);
       }
+      // the next block's lin_z contribution rides on the fc_1 GEMM (additions into xs commute); this block's fc_1 bias comes with it
+      // (folded into the projected map's bias when the weights are packed, mlp.hip)
       const _Float16* w1 = w_blk + (size_t)(2 * b + 1) * kLayerHalfs;
+#if DINER_HN_OWNG
+      {
+        GatherSide<DINER_HN_GDEPTH> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
+        publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLY1 != 0, true>(w1, Bl, wave, lane, ns, xs, gs, [&] { pin_acc(xs); }, pf, 10);
+      }
+#else
       __syncthreads();
       pf.mark(10);
       publish<LO>(Bl, wave, lane, ns);
@@ -613,15 +743,18 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       __syncthreads();
       pf.mark(12);
       pin_acc(xs);
-      if (b < 2) {     // the next block's lin_z contribution rides on this GEMM (additions into xs commute); this block's fc_1
-                       // bias comes with it (folded into the projected map's bias when the weights are packed, mlp.hip)
-        GatherSide<DINER_HN_GDEPTH> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
-        gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, gs);
-      } else {         // (block 2's fc_1 bias is added by the post kernel)
-        NoSide none;
-        gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, none);
-      }
+      GatherSide<DINER_HN_GDEPTH> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
+      gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, gs);
       pf.mark(13);
+#endif
+    }
+    {   // block 2: no gather left (and its fc_1 bias is added by the post kernel)
+      const float* bias = a.b + kHidden * 5;
+      NoSide none;
+      publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
+          w_blk + (size_t)4 * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] { set_bias(ns, bias, wave, q); }, pf, 6);
+      publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLY1 != 0, DINER_HN_OWN != 0>(w_blk + (size_t)5 * kLayerHalfs, Bl, wave, lane, ns, xs, none,
+                                                                [&] { pin_acc(xs); }, pf, 10);
     }
     // view mean = mean over the four column groups; hand-over at scale 1 in accumulator layout (row tile 8 w + mo)
     f32x4* out = reinterpret_cast<f32x4*>(fa.xpre) + (size_t)tile * (kTiles * 64) + lane;
@@ -676,12 +809,12 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
       const float* bias = pa.b_post + 2 * kHidden * b;
-      publish_gemm<DINER_HN_RING0, LO, false>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
+      publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
         set_bias(ns, bias, wave, q);
         pin_acc(xs);                              // the residual stream stays in registers across the fc_0 GEMM
       }, pf, 0);
       pin_acc(xs);
-      publish_gemm<DINER_HN_RING, LO, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
+      publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
                                       [&] { add_bias(xs, bias + kHidden, wave, q); }, pf, 4);
     }
     // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
@@ -696,8 +829,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       gh8 wo = (gh8)(reinterpret_cast<const h8*>(a.w_out) + lane);
       asm volatile("" : "+v"(wo));                // loop-invariant otherwise: 32 hoisted (and spilled) addresses
       LdsB Bo = Bl;                               // column group `wave`: two fragments = 2 KB further on
-      Bo.lo += wave * 2048;
-      Bo.hi += wave * 2048;
+      Bo.base += wave * 2048;
       Bo.opaque();
       f32x4 o[4];
 #pragma unroll
@@ -706,7 +838,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       for (int t = 0; t < 16; ++t) {
         if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keep the operand loads from being hoisted in one burst
         const h8 ah = wo[(t * 2 + 0) * 64], al = wo[(t * 2 + 1) * 64];
-        const h8 bh = *Bo.at(t, 0, 0), bl = *Bo.at(t, 0, 1);
+        const h8 bh = *LdsB::at(Bo.chunk(t >> 2), t & 3, 0, 0), bl = *LdsB::at(Bo.chunk(t >> 2), t & 3, 0, 1);
         DINER_HN_MFMA(o[t & 3], ah, bh);
         if constexpr (LO) {
           DINER_HN_MFMA(o[(t + 1) & 3], al, bh);
@@ -738,13 +870,15 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
   pf.end(a.prof, lane);
 }
 
-// layer packing: [w 4][t KT][mo 8][hl 2][lane 64][8]: W[128 w + 16 mo + (lane&15)][32 t + 16 (j>>2) + 4 (lane>>4) + (j&3)] * scale
+// layer packing: [w 4][ts KT][mo 8][hl 2][lane 64][8]: W[128 w + 16 mo + (lane&15)][32 t(w, ts) + 16 (j>>2) + 4 (lane>>4) + (j&3)] * scale
 __global__ void k_pack_layer_h3n(const float* __restrict__ W, int rows, int cols, int KT, float scale,
                                  _Float16* __restrict__ dst) {
   const long long total = (long long)4 * KT * 8192;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int j = i & 7, lane = (i >> 3) & 63, hl = (i >> 9) & 1, mo = (i >> 10) & 7;
-    const int wt = (int)(i >> 13), t = wt % KT, w = wt / KT;
+    const int wt = (int)(i >> 13), ts = wt % KT, w = wt / KT;
+    // position ts in wave w's weight stream -> k32 block of the contraction: 512-wide layers are walked own chunk first (chunk_of)
+    const int t = KT == 16 ? 4 * ((ts >> 2) == 0 ? w : ((ts >> 2) - 1 < w ? (ts >> 2) - 1 : (ts >> 2))) + (ts & 3) : ts;
     const int row = 128 * w + 16 * mo + (lane & 15);
     const int col = 32 * t + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
     const float x = (row < rows && col < cols) ? W[(size_t)row * cols + col] * scale : 0.0f;

@@ -298,6 +298,8 @@ def test_render_from_dtu_sample():
     print(f"dtu sample: {H}x{W} at K={K}, {len(idx)} lattice rays ({n_surf} with sum(w) > 0.5): within 1e-4 of the oracle: {frac:.4f}, "
           f"worst {float(err.max()):.2e}, PSNR vs oracle {psnr:.1f} dB")
     # rays whose sample selection is implementation-defined (erf round-off at the cut-off, tests/test_hip_parity.py) may differ
-    assert frac >= 0.98 and psnr > 45.0
     derr = (depth[0, 0].reshape(-1).cpu()[idx] - ref["depth"]).abs() / ref["depth"].abs().max()
-    assert float(derr[err < TOL].max()) < TOL
+    both = float(((err < TOL) & (derr < TOL)).float().mean())
+    print(f"dtu sample: colour AND depth within 1e-4: {both:.4f}; worst depth error among the rays with matching colour {float(derr[err < TOL].max()):.2e}")
+    assert frac >= 0.99 and both >= 0.985 and psnr > 55.0        # measured 0.9969 / 78.6 dB
+    assert float(derr[err < TOL].max()) < 1e-3      # (a ray whose sample set differs can land on the same colour with another depth)

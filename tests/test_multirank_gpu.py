@@ -25,12 +25,14 @@ def _free_port():
     return p
 
 
-def _render(rank, world, seed):
+def _render(rank, world, seed, reseed=None):
     from diner_amd.render import predict_image
     from tests.test_boundary_gpu import setup_model
     sc, nerf, R, _ = setup_model(W, H, SCENE_SEED)
     ren = R(n_samples=K, n_depth_candidates=N_CAND, n_gaussian=G, white_bkgd=False)
     E, Km = sc["target_extrinsics"][None].cuda(), sc["target_intrinsics"][None].cuda()
+    if reseed is not None:                         # (building the model consumes the global generator: seed it after that)
+        torch.manual_seed(reseed)
     return predict_image(nerf, ren, E, Km, W, H, sc["znear"], sc["zfar"], ray_batch_size=8192 + 5, rank=rank, world=world, seed=seed)
 
 
@@ -42,8 +44,7 @@ def _worker(rank, world, port, q):
     try:
         rgb, depth = _render(rank, world, FRAME_SEED)
         # second frame without an explicit seed: rank 0 draws it from ITS generator, the broadcast makes it the frame's seed
-        torch.manual_seed(1000 + rank)
-        rgb2, depth2 = _render(rank, world, None)
+        rgb2, depth2 = _render(rank, world, None, reseed=1000 + rank)
         if rank == 0:
             torch.manual_seed(1000)               # the seed rank 0 drew, for the parent's single-process frame
             drawn = int(torch.randint(0, 2 ** 62, (1,)).item())
