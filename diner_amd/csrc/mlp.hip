@@ -61,8 +61,9 @@ struct DinerMlpImpl {
 int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w, float** w_out, float** b_pre, float** b_post);
 int h3n_set_attributes();
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
-                    hipStream_t stream);
-void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_out, int grid, bool split, hipStream_t stream);
+                    unsigned* tile_counter, hipStream_t stream);
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_out, int grid, bool split, unsigned* tile_counter,
+                     hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing (runs once per parameter version, on the device)
@@ -664,15 +665,15 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
   }
   PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw, nullptr, nullptr, m->fallback_dev};
   if (use_hn) {
-    DINER_HIP_OK(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    DINER_HIP_OK(hipMemsetAsync(flag, 0, 4 * sizeof(int), stream));      // overflow flag + the tile counters of the two kernels
     if (timed) DINER_HIP_OK(hipEventRecord(e0, stream));
-    h3n_launch_pre(*sc, fa, m->hn_w, m->hn_b_pre, grid_pre, split, stream);
+    h3n_launch_pre(*sc, fa, m->hn_w, m->hn_b_pre, grid_pre, split, reinterpret_cast<unsigned*>(flag) + 1, stream);
     DINER_LAUNCH_OK();
     if (timed) DINER_HIP_OK(hipEventRecord(e1, stream));
     PostArgs pn = pa;
     pn.b_post = m->hn_b_post;
     pn.overflow = flag;
-    h3n_launch_post(pn, m->hn_w, m->hn_w_out, grid_post, split, stream);
+    h3n_launch_post(pn, m->hn_w, m->hn_w_out, grid_post, split, reinterpret_cast<unsigned*>(flag) + 2, stream);
     DINER_LAUNCH_OK();
     if (timed) DINER_HIP_OK(hipEventRecord(e2, stream));
     fa.gate = flag;                 // the exact kernels below only run when the flag was raised

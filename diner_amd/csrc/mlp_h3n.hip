@@ -135,6 +135,31 @@ struct Args {
   const _Float16* w;       // n-split packed weights: lin_in, then per block b<3: fc_0, fc_1
   const float* b;          // biases x16: lin_in, then per block: fc_0, fc_1  (7 x 512)
   unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
+  unsigned* tile_counter;     // zeroed per launch: tiles are handed out dynamically (a workgroup's first tile is blockIdx.x)
+};
+
+#ifndef DINER_HN_DYN            // 1: dynamic tile hand-out (atomic counter); 0: static round-robin tile += gridDim.x
+#define DINER_HN_DYN 1
+#endif
+// Tile hand-out.  The workgroups are persistent (one per CU: LDS and registers admit no second one); with a static round-robin the
+// launch ends when the slowest CU has done its share.  Here thread 0 asks for the NEXT tile at the top of the current one (an atomic
+// on a per-launch counter; the answer is needed ~230 k clocks later) and hands it to the workgroup through LDS at the bottom.
+struct TileQueue {
+  unsigned nxt;
+  __device__ __forceinline__ void request(unsigned* counter) {
+#if DINER_HN_DYN
+    if (threadIdx.x == 0) nxt = atomicAdd(counter, 1u) + gridDim.x;
+#endif
+  }
+  __device__ __forceinline__ long long next(long long tile, unsigned* slot) {
+#if DINER_HN_DYN
+    if (threadIdx.x == 0) *slot = nxt;
+    __syncthreads();
+    return (long long)__builtin_amdgcn_readfirstlane((int)*slot);
+#else
+    return tile + gridDim.x;
+#endif
+  }
 };
 
 // Phase timer of the per-view kernel (DINER_HN_PROF builds only; tools/prof_phases.sh): mark(i) books the shader clocks since the
@@ -669,7 +694,10 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
 
   Prof pf;
   pf.begin();
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  __shared__ unsigned s_tile;
+  TileQueue tq;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile = tq.next(tile, &s_tile)) {
+    tq.request(a.tile_counter);
     long long p = tile * kPtsPerWave + pt;
     if (p >= fa.P) p = fa.P - 1;
     Taps taps;
@@ -771,6 +799,7 @@ struct PostArgsN {
   const _Float16* w;        // n-split packed fc_0 / fc_1 of blocks 3, 4 (4 layers of 4 * 16 * 16 KB)
   const _Float16* w_out;    // lin_out fragments [t 16][hl 2][lane 64][8] (rows >= 4 zero), x16
   unsigned long long* prof; // DINER_HN_PROF builds: phase counters, else unused
+  unsigned* tile_counter;   // see TileQueue
 };
 
 // Blocks 3-4 + lin_out + output activations on the view-averaged hidden state, same feature-sliced scheme: a
@@ -790,7 +819,10 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
 
   Prof pf;
   pf.begin();
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  __shared__ unsigned s_tile;
+  TileQueue tq;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile = tq.next(tile, &s_tile)) {
+    tq.request(a.tile_counter);
     f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
@@ -962,8 +994,8 @@ int h3n_set_attributes() {
 }
 // split = true: f16x3 split products (hi and lo parts, three MFMAs per product); false: plain fp16 operands
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
-                    hipStream_t stream) {
-  h3n::Args a{fa, (const _Float16*)w, b, nullptr};
+                    unsigned* tile_counter, hipStream_t stream) {
+  h3n::Args a{fa, (const _Float16*)w, b, nullptr, tile_counter};
 #ifdef DINER_HN_PROF
   static unsigned long long* prof = nullptr;
   if (!prof) hipMalloc(&prof, 32 * sizeof(unsigned long long));
@@ -989,10 +1021,11 @@ void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, con
 }
 
 // w: the n-split pack (post layers follow the per-view ones); w_lin_out: the lin_out fragments
-void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out, int grid, bool split, hipStream_t stream) {
+void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out, int grid, bool split, unsigned* tile_counter,
+                     hipStream_t stream) {
   const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
   const _Float16* wo = (const _Float16*)w_lin_out;
-  h3n::PostArgsN a{pa, wn, wo, nullptr};
+  h3n::PostArgsN a{pa, wn, wo, nullptr, tile_counter};
 #ifdef DINER_HN_PROF
   static unsigned long long* prof = nullptr;
   if (!prof) hipMalloc(&prof, 32 * sizeof(unsigned long long));
