@@ -665,15 +665,15 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
   }
   PostArgs pa{(const float*)workspace, m->w_post, m->b_post, out, fa.P, nv, raw, nullptr, nullptr, m->fallback_dev};
   if (use_hn) {
-    DINER_HIP_OK(hipMemsetAsync(flag, 0, 4 * sizeof(int), stream));      // overflow flag + the tile counters of the two kernels
+    DINER_HIP_OK(hipMemsetAsync(flag, 0, 24 * sizeof(int), stream));     // overflow flag + the tile counters (8 queues) of the two kernels
     if (timed) DINER_HIP_OK(hipEventRecord(e0, stream));
-    h3n_launch_pre(*sc, fa, m->hn_w, m->hn_b_pre, grid_pre, split, reinterpret_cast<unsigned*>(flag) + 1, stream);
+    h3n_launch_pre(*sc, fa, m->hn_w, m->hn_b_pre, grid_pre, split, reinterpret_cast<unsigned*>(flag) + 8, stream);
     DINER_LAUNCH_OK();
     if (timed) DINER_HIP_OK(hipEventRecord(e1, stream));
     PostArgs pn = pa;
     pn.b_post = m->hn_b_post;
     pn.overflow = flag;
-    h3n_launch_post(pn, m->hn_w, m->hn_w_out, grid_post, split, reinterpret_cast<unsigned*>(flag) + 2, stream);
+    h3n_launch_post(pn, m->hn_w, m->hn_w_out, grid_post, split, reinterpret_cast<unsigned*>(flag) + 16, stream);
     DINER_LAUNCH_OK();
     if (timed) DINER_HIP_OK(hipEventRecord(e2, stream));
     fa.gate = flag;                 // the exact kernels below only run when the flag was raised

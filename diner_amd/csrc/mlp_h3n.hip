@@ -135,7 +135,7 @@ struct Args {
   const _Float16* w;       // n-split packed weights: lin_in, then per block b<3: fc_0, fc_1
   const float* b;          // biases x16: lin_in, then per block: fc_0, fc_1  (7 x 512)
   unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
-  unsigned* tile_counter;     // zeroed per launch: tiles are handed out dynamically (a workgroup's first tile is blockIdx.x)
+  unsigned* tile_counter;     // 8 counters (one per XCD queue), zeroed per launch: see TileQueue (a workgroup's first tile is blockIdx.x)
 };
 
 #ifndef DINER_HN_DYN            // 1: dynamic tile hand-out (atomic counter); 0: static round-robin tile += gridDim.x
@@ -144,18 +144,54 @@ struct Args {
 // Tile hand-out.  The workgroups are persistent (one per CU: LDS and registers admit no second one); with a static round-robin the
 // launch ends when the slowest CU has done its share.  Here thread 0 asks for the NEXT tile at the top of the current one (an atomic
 // on a per-launch counter; the answer is needed ~230 k clocks later) and hands it to the workgroup through LDS at the bottom.
+// One queue per XCD: tile t belongs to queue t % 8 and workgroup b runs on XCD b % 8, so an XCD keeps seeing the tiles the static
+// round-robin gave it -- the same 16-sample depth segment of every ray, whose taps share texel rows in that XCD's L2 (a single
+// global queue was measured at 4x the L2 misses and HBM reads of the per-view kernel: 98 KB instead of 24 KB per point).  An XCD
+// that runs dry takes from the others' queues.
 struct TileQueue {
   unsigned nxt;
-  __device__ __forceinline__ void request(unsigned* counter) {
+  unsigned done;       // queues seen empty (thread 0)
+  __device__ __forceinline__ void begin() { done = 0; }
+  __device__ __forceinline__ void request(unsigned* counters, long long n_tiles) {
 #if DINER_HN_DYN
-    if (threadIdx.x == 0) nxt = atomicAdd(counter, 1u) + gridDim.x;
+    if (threadIdx.x == 0) {
+      unsigned t = 0xffffffffu;
+      const unsigned xcd = blockIdx.x & 7;
+#pragma nounroll
+      for (unsigned s = 0; s < 8; ++s) {
+        const unsigned qn = (xcd + s) & 7;
+        if (done & (1u << qn)) continue;
+        const unsigned taken = gridDim.x > qn ? (gridDim.x - qn + 7) >> 3 : 0;       // entries the workgroups' first tiles used up
+        const unsigned long long cand = 8ull * (atomicAdd(counters + qn, 1u) + taken) + qn;
+        if (cand < (unsigned long long)n_tiles) {
+          t = (unsigned)cand;
+          break;
+        }
+        done |= 1u << qn;
+      }
+      nxt = t;
+    }
+#endif
+  }
+  // the same in two halves around a barrier the caller has anyway: offer() in front of it, take() behind it
+  __device__ __forceinline__ void offer(unsigned* slot) {
+#if DINER_HN_DYN
+    if (threadIdx.x == 0) *slot = nxt;
+#endif
+  }
+  __device__ __forceinline__ long long take(long long tile, const unsigned* slot) {
+#if DINER_HN_DYN
+    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)*slot);
+    return t == 0xffffffffu ? 0x7fffffffffffffffll : (long long)t;
+#else
+    return tile + gridDim.x;
 #endif
   }
   __device__ __forceinline__ long long next(long long tile, unsigned* slot) {
 #if DINER_HN_DYN
-    if (threadIdx.x == 0) *slot = nxt;
+    offer(slot);
     __syncthreads();
-    return (long long)__builtin_amdgcn_readfirstlane((int)*slot);
+    return take(tile, slot);
 #else
     return tile + gridDim.x;
 #endif
@@ -696,8 +732,9 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   pf.begin();
   __shared__ unsigned s_tile;
   TileQueue tq;
+  tq.begin();
   for (long long tile = blockIdx.x; tile < n_tiles; tile = tq.next(tile, &s_tile)) {
-    tq.request(a.tile_counter);
+    tq.request(a.tile_counter, n_tiles);
     long long p = tile * kPtsPerWave + pt;
     if (p >= fa.P) p = fa.P - 1;
     Taps taps;
@@ -821,19 +858,31 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
   pf.begin();
   __shared__ unsigned s_tile;
   TileQueue tq;
-  for (long long tile = blockIdx.x; tile < n_tiles; tile = tq.next(tile, &s_tile)) {
-    tq.request(a.tile_counter);
-    f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
+  tq.begin();
+  f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
+  // The hand-over of a tile (2 KB per point, written by the per-view kernel in accumulator layout) is REQUESTED while the previous
+  // tile's lin_out runs, straight into the residual block, which is dead from lin_out's publish on (round 2's attempt at this made the
+  // allocator spill the block; with the accumulator accesses pinned it does not).  A tile starts by waiting for it: x16 + block 2's
+  // fc_1 bias, which the per-view kernel leaves to this one.
+  auto request_handover = [&](long long t) {
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
-      long long t16 = tile * 4 + g;
+      long long t16 = t * 4 + g;
       if (t16 >= n_t16) t16 = n_t16 - 1;
       const f32x4* in = reinterpret_cast<const f32x4*>(pa.xpre) + (size_t)t16 * (kTiles * 64) + lane;
 #pragma unroll
-      for (int mo = 0; mo < kSlice; ++mo) {     // + block 2's fc_1 bias (x16), which the per-view kernel leaves to this one
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 16 + 128 * wave + 16 * mo + 4 * q);
-        xs[mo][g] = in[(8 * wave + mo) * 64] * kScale + b2;
-      }
+      for (int mo = 0; mo < kSlice; ++mo) xs[mo][g] = in[(8 * wave + mo) * 64];
+    }
+  };
+  long long tile = blockIdx.x;
+  if (tile < n_tiles) request_handover(tile);
+  while (tile < n_tiles) {
+    tq.request(a.tile_counter, n_tiles);
+#pragma unroll
+    for (int mo = 0; mo < kSlice; ++mo) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 16 + 128 * wave + 16 * mo + 4 * q);
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) xs[mo][g] = xs[mo][g] * kScale + b2;
     }
     NoSide none;
     pin_acc(xs);
@@ -852,9 +901,12 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
     // (requesting its 32 weight fragments before the publish moves 4 k clocks from here into the publish and the next tile's
     // hand-over load: measured, no net gain)
+    tq.offer(&s_tile);
     __syncthreads();
     publish<LO>(Bl, wave, lane, xs);
     __syncthreads();
+    const long long tile_next = tq.take(tile, &s_tile);
+    if (tile_next < n_tiles) request_handover(tile_next);
     pf.mark(9);
     {
       typedef const __attribute__((address_space(1))) h8* gh8;
@@ -898,6 +950,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       }
     }
     pf.mark(11);
+    tile = tile_next;
   }
   pf.end(a.prof, lane);
 }

@@ -26,6 +26,9 @@ struct GemmArgs {
   float* C;             // M x N, [M][ldc]
   const float* bias;    // N or null: added to every row
   const float* mask;    // M x N (ldc) or null: C *= (mask > 0)   (relu adjoint with the saved pre-activation)
+  const float* resid;   // M x N (ldc) or null: added to the product (bf16x6 kernel only): C = resid + A B (+ bias) without a copy of resid
+  float* rowsum;        // M or null (bf16x6 kernel, op(A) stored with kTA only): rowsum[m] += sum_k op(A)[m][k] (atomic) -- the bias gradient
+                        // of a layer is the row sum of the dy^T operand of its weight-gradient product, read by that product anyway
   long long M;
   int N, K, lda, ldb, ldc, flags, k_chunk;      // k_chunk: K range per blockIdx.z (split-K, needs kAtomic)
 };
@@ -392,8 +395,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
   TileRegs ra_t, rb_t;
   tile_fetch(ra_t, g.A, g.lda, a_kc, m0, g.M, kbeg, kend, ra, tid);
   tile_fetch(rb_t, g.B, g.ldb, b_kc, n0, g.N, kbeg, kend, rb, tid);
+  const bool do_rowsum = g.rowsum && bx == 0;          // (one N-tile column of workgroups sums the rows of op(A))
+  float rs0 = 0.0f, rs1 = 0.0f;
   for (int k0 = kbeg; k0 < kend; k0 += XK) {
     __syncthreads();                                   // the previous tile's fragment reads are done
+    if (do_rowsum) {                                   // op(A) stored [K][lda]: this thread holds rows 2 (tid % 64), +1, 8 contraction indices
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        rs0 += ra_t.v[0][e];
+        rs1 += ra_t.v[1][e];
+      }
+    }
     tile_stash(ra_t, As, a_kc, tid);
     tile_stash(rb_t, Bs, b_kc, tid);
     __syncthreads();
@@ -428,6 +440,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
         }
     }
   }
+  if (do_rowsum) {
+    const long long row = m0 + 2 * (tid & 63);
+    if (row < g.M) atomicAdd(g.rowsum + row, rs0);
+    if (row + 1 < g.M) atomicAdd(g.rowsum + row + 1, rs1);
+  }
   // D layout of the 32x32 tile: lane holds column lane & 31, rows 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -441,6 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
         const long long m = m0 + 64 * wm + 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
         if (m >= g.M) continue;
         float v = acc[i][j][e] + bias;
+        if (g.resid) v += g.resid[(size_t)m * g.ldc + n];
         float* c = g.C + (size_t)m * g.ldc + n;
         if (g.mask && !(g.mask[(size_t)m * g.ldc + n] > 0.0f)) v = 0.0f;
         if (g.flags & kAtomic) atomicAdd(c, v);
@@ -620,17 +638,21 @@ using namespace diner;
 using namespace diner::train;
 
 static int gemm_launch(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc,
-                       int flags, const float* bias, const float* mask, int k_split, hipStream_t stream) {
+                       int flags, const float* bias, const float* mask, int k_split, hipStream_t stream,
+                       const float* resid = nullptr, float* rowsum = nullptr) {
   DINER_CHECK_ARG(A && B && C, "gemm: null pointer argument");
   DINER_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad sizes M=%lld N=%d K=%d", M, N, K);
   DINER_CHECK_ARG((flags & ~127) == 0, "gemm: unknown flags 0x%x", flags);
   DINER_CHECK_ARG(k_split >= 1 && (k_split == 1 || (flags & kAtomic)), "gemm: split-K needs the atomic output flag");
   DINER_CHECK_ARG(!((flags & kAtomic) && mask), "gemm: a relu mask cannot be combined with atomic accumulation");
+  DINER_CHECK_ARG(!(resid || rowsum) || !(flags & kExact), "gemm: resid / rowsum are epilogues of the bf16x6 kernel");
+  DINER_CHECK_ARG(!rowsum || (flags & kTA), "gemm: rowsum needs op(A) stored with the contraction index outermost (kTA)");
+  DINER_CHECK_ARG(!resid || !(flags & (kAtomic | kAccum)), "gemm: resid replaces the accumulate flags");
   int chunk = (K + k_split - 1) / k_split;
   chunk = (chunk + XK - 1) / XK * XK;               // (a multiple of every kernel's k-tile)
   static const bool no_xcd = [] { const char* e = getenv("DINER_TRAIN_NO_XCD"); return e && *e == '1'; }();
   if (no_xcd) flags |= kNoXcdOrder;
-  GemmArgs g{A, B, C, bias, mask, M, N, K, lda, ldb, ldc, flags, chunk};
+  GemmArgs g{A, B, C, bias, mask, resid, rowsum, M, N, K, lda, ldb, ldc, flags, chunk};
   if (!(flags & kExact)) {
     // split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6); ragged and skinny shapes (lin_out: N = 4,
     // its adjoints: K = 4 / M = 4) ride along zero-padded -- a partly empty 128 x 128 tile is still faster than the fp32 kernels
@@ -764,11 +786,10 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   static const long long cap = [] { const char* e = getenv("DINER_TRAIN_WGRAD_CAP"); return e ? atoll(e) : 64LL; }();
   long long split = M / rows_per_chunk;
   split = split < 1 ? 1 : (split > cap ? cap : split);
-  int rc = gemm_launch(dy, x, dW, N, K, M, ldy, ldx, K, kTA | kAtomic | (relu_in ? kReluB : 0), nullptr, nullptr, (int)split, st);
+  // the bias gradient (column sums of dy) rides on the weight-gradient product: dy^T is its A operand (no k_colsum pass over dy)
+  int rc = gemm_launch(dy, x, dW, N, K, M, ldy, ldx, K, kTA | kAtomic | (relu_in ? kReluB : 0), nullptr, nullptr, (int)split, st,
+                       nullptr, db);
   if (rc) return rc;
-  long long gy = (M + 255) / 256;
-  if (gy > 256) gy = 256;
-  hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, (unsigned)gy), dim3(256), 0, st, dy, M, N, ldy, db);
   if (dx) rc = gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
   return rc;
 }
@@ -791,8 +812,8 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
   rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
   if (rc) return rc;
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
-                 bool accum) {
-    return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st);
+                 bool accum, const float* resid = nullptr) {
+    return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid);
   };
   if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, false))) return rc;
   for (int b = 0; b < 5; ++b) {
@@ -802,8 +823,8 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     if ((rc = lin(X, kHidden, p->fc0_w[b], p->fc0_b[b], ws + w.H[b], M, kHidden, kHidden, true, false))) return rc;
     // next residual stream: X + fc_1(relu(H)); the view mean comes after block 2
     float* nx = b == 4 ? ws + w.x_last : (b == 2 ? ws + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
-    DINER_HIP_OK(hipMemcpyAsync(nx, X, (size_t)M * kHidden * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, true))) return rc;
+    // (the residual enters through the product's epilogue: no copy of X)
+    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X))) return rc;
     if (b == 2)
       hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3]);
   }
