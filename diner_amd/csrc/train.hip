@@ -360,6 +360,8 @@ __device__ __forceinline__ void tile_stash(const TileRegs& r, __bf16* lds, bool 
   }
 }
 
+// EPI: 0 plain, 1 + resid in the epilogue, 2 + row sums of op(A) (separate instantiations: the plain kernel must stay at 3 waves per SIMD)
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) __bf16 As[3 * kPlaneElems], Bs[3 * kPlaneElems];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -395,11 +397,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
   TileRegs ra_t, rb_t;
   tile_fetch(ra_t, g.A, g.lda, a_kc, m0, g.M, kbeg, kend, ra, tid);
   tile_fetch(rb_t, g.B, g.ldb, b_kc, n0, g.N, kbeg, kend, rb, tid);
-  const bool do_rowsum = g.rowsum && bx == 0;          // (one N-tile column of workgroups sums the rows of op(A))
+  const bool do_rowsum = EPI == 2 && g.rowsum && bx == 0;          // (one N-tile column of workgroups sums the rows of op(A))
   float rs0 = 0.0f, rs1 = 0.0f;
   for (int k0 = kbeg; k0 < kend; k0 += XK) {
     __syncthreads();                                   // the previous tile's fragment reads are done
-    if (do_rowsum) {                                   // op(A) stored [K][lda]: this thread holds rows 2 (tid % 64), +1, 8 contraction indices
+    if (EPI == 2 && do_rowsum) {                       // op(A) stored [K][lda]: this thread holds rows 2 (tid % 64), +1, 8 contraction indices
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         rs0 += ra_t.v[0][e];
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
         }
     }
   }
-  if (do_rowsum) {
+  if (EPI == 2 && do_rowsum) {
     const long long row = m0 + 2 * (tid & 63);
     if (row < g.M) atomicAdd(g.rowsum + row, rs0);
     if (row + 1 < g.M) atomicAdd(g.rowsum + row + 1, rs1);
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
         const long long m = m0 + 64 * wm + 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
         if (m >= g.M) continue;
         float v = acc[i][j][e] + bias;
-        if (g.resid) v += g.resid[(size_t)m * g.ldc + n];
+        if (EPI == 1) v += g.resid[(size_t)m * g.ldc + n];
         float* c = g.C + (size_t)m * g.ldc + n;
         if (g.mask && !(g.mask[(size_t)m * g.ldc + n] > 0.0f)) v = 0.0f;
         if (g.flags & kAtomic) atomicAdd(c, v);
@@ -648,6 +650,7 @@ static int gemm_launch(const float* A, const float* B, float* C, long long M, in
   DINER_CHECK_ARG(!(resid || rowsum) || !(flags & kExact), "gemm: resid / rowsum are epilogues of the bf16x6 kernel");
   DINER_CHECK_ARG(!rowsum || (flags & kTA), "gemm: rowsum needs op(A) stored with the contraction index outermost (kTA)");
   DINER_CHECK_ARG(!resid || !(flags & (kAtomic | kAccum)), "gemm: resid replaces the accumulate flags");
+  DINER_CHECK_ARG(!(resid && rowsum), "gemm: resid and rowsum are separate epilogues");
   int chunk = (K + k_split - 1) / k_split;
   chunk = (chunk + XK - 1) / XK * XK;               // (a multiple of every kernel's k-tile)
   static const bool no_xcd = [] { const char* e = getenv("DINER_TRAIN_NO_XCD"); return e && *e == '1'; }();
@@ -657,7 +660,9 @@ static int gemm_launch(const float* A, const float* B, float* C, long long M, in
     // split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6); ragged and skinny shapes (lin_out: N = 4,
     // its adjoints: K = 4 / M = 4) ride along zero-padded -- a partly empty 128 x 128 tile is still faster than the fp32 kernels
     const dim3 grid((N + XN - 1) / XN, (unsigned)((M + XM - 1) / XM), (K + chunk - 1) / chunk);
-    hipLaunchKernelGGL(k_gemm_bf16x6, grid, dim3(256), 0, stream, g);
+    if (resid) hipLaunchKernelGGL(k_gemm_bf16x6<1>, grid, dim3(256), 0, stream, g);
+    else if (rowsum) hipLaunchKernelGGL(k_gemm_bf16x6<2>, grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(k_gemm_bf16x6<0>, grid, dim3(256), 0, stream, g);
   } else if (N >= BN2 && M >= BM2) {
     const dim3 grid((N + BN2 - 1) / BN2, (unsigned)((M + BM2 - 1) / BM2), (K + chunk - 1) / chunk);
     hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, stream, g);
