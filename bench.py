@@ -55,7 +55,7 @@ def parse():
                     help="Facescape depth range / sigma law (BASELINE configs[4]): znear/zfar 1.0/2.5, white background")
     ap.add_argument("--weak", action="store_true",
                     help="every rank renders its own full frame (weak scaling) instead of sharding one frame")
-    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the CPU baseline sample (0 disables)")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU baseline sample (0 disables)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-modes", action="store_true", help="skip the extra one-frame passes in the other arithmetic modes")
     ap.add_argument("--no-configs", action="store_true",
@@ -320,13 +320,13 @@ def main():
         torch.set_num_threads(best)
         n_cpu = min(args.cpu_rays, NRF)
         smp = sample(n_cpu)
-        cpu_once(smp)                                             # warm-up at size
+        cpu_once(sample(min(512, n_cpu)))                         # warm-up with the chosen thread count (the sweep above warmed every code path)
         times = sorted(cpu_once(smp) for _ in range(max(1, args.cpu_repeats)))
         med = times[len(times) // 2]
         cpu = {"value": round(n_cpu / med, 2), "unit": "rays/s", "cores": best, "kind": "port",
                "sample": f"{n_cpu} rays spread over the same {W}x{H} frame, {K} samples/ray, one call of the torch CPU oracle "
                          f"(restatement of the reference renderer, pinned bit-exact; 100,000-point MLP chunks) per repeat; "
-                         f"1 warm-up at size + {len(times)} timed repeats, median {med:.1f} s (min {times[0]:.1f}, max "
+                         f"1 warm-up (512 rays, after the thread sweep) + {len(times)} timed repeats, median {med:.1f} s (min {times[0]:.1f}, max "
                          f"{times[-1]:.1f}); {best} of {hw} hardware threads = fastest of the sweep {sweep} (rays/s on 256 rays)",
                "repeats_s": [round(t, 2) for t in times], "thread_sweep_rays_per_s": sweep, "host_threads": hw}
 
