@@ -12,6 +12,7 @@
 // Reference: ResnetFC.forward resnetfc.py:129-159, PixelNeRF.forward pixelnerf.py:55-145, NeRFRendererDGS.composite
 // nerf_renderer.py:286-365, differentiated by torch autograd in DINER.calc_losses (diner.py:217-290).
 #include "field_common.hpp"
+#include "train_lin512.hpp"
 
 namespace diner {
 namespace train {
@@ -679,6 +680,21 @@ extern "C" int diner_gemm_f32(const float* A, const float* B, float* C, long lon
   return gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, flags, bias, mask, k_split, (hipStream_t)stream);
 }
 
+extern "C" size_t diner_linear512_pack_bytes(void) { return kL512PackBytes; }
+
+extern "C" int diner_linear512_f32(const float* X, const float* W, float* Y, long long M, int ldx, int ldy, int transpose, int flags,
+                                   const float* bias, const float* resid, const float* mask, void* wpack, void* stream) {
+  DINER_CHECK_ARG(X && W && Y && wpack && M > 0, "linear512: bad arguments");
+  DINER_CHECK_ARG((flags & ~3) == 0, "linear512: unknown flags 0x%x", flags);
+  auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
+  DINER_CHECK_ARG(ldx >= 512 && ldy >= 512 && (ldx & 3) == 0 && (ldy & 3) == 0 && al(X) && al(Y) && al(bias) && al(resid) && al(mask) && al(wpack),
+                  "linear512: row strides must be multiples of 4 (>= 512) and pointers 16-byte aligned");
+  int rc = lin512_pack(W, transpose != 0, wpack, (hipStream_t)stream);
+  if (rc) return rc;
+  Lin512Args a{X, wpack, Y, bias, resid, mask, M, ldx, ldy, flags};
+  return lin512_launch(a, (hipStream_t)stream);
+}
+
 extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P,
                                       float freq_factor, float* feat, int* tap_row, float* tap_w, float* lat, void* stream) {
   DINER_CHECK_ARG(scene && xyz && viewdirs && feat && tap_row && tap_w && lat, "train_inputs: null pointer argument");
@@ -752,8 +768,11 @@ extern "C" int diner_composite_bwd_f32(const float* field, const float* z, const
 // ---- the whole forward / backward of the field as one call each (what diner_amd/train.py does call by call; one entry
 // saves ~100 host round trips per step, which matter at the reference's 128-ray training batch) -------------------------
 namespace {
+// packed-weights slots of the workspace: fc_0 / fc_1 of the 5 blocks + the 3 lin_z, forward and transposed
+constexpr int kWPackSlots = 2 * 13;
+enum { kSlotFc0 = 0, kSlotFc1 = 5, kSlotLinZ = 10 };
 struct TrainWs {               // float offsets into the workspace
-  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, total;
+  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, total;
 };
 TrainWs train_ws(long long P, int nv) {
   TrainWs w;
@@ -775,13 +794,27 @@ TrainWs train_ws(long long P, int nv) {
   w.dx = take(cols * kHidden);
   w.dH = take(cols * kHidden);
   w.d_lat = take(cols * kLatent);
+  w.wpack = take(kWPackSlots * (kL512PackBytes / sizeof(float)));      // packed 512 x 512 weights of train_lin512.hip
   w.total = o;
   return w;
 }
 int check_train_params(const DinerMlpParams* p, bool poscode) { return check_mlp_config(p, "field_train", poscode); }
+// DINER_TRAIN_LIN512=0 routes the 512 x 512 layer products back to the general kernel (A/B measurement)
+bool use_lin512() {
+  static const bool on = [] { const char* e = getenv("DINER_TRAIN_LIN512"); return !(e && *e == '0'); }();
+  return on;
+}
+bool lin512_ok(const float* x, int ldx, const float* y, int ldy, const float* resid, const float* mask) {
+  auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
+  return use_lin512() && (ldx & 3) == 0 && (ldy & 3) == 0 && al(x) && al(y) && al(resid) && al(mask);
+}
+void* wpack_slot(float* ws, const TrainWs& w, int slot, bool transposed) {
+  return reinterpret_cast<char*>(ws + w.wpack) + (size_t)(slot + (transposed ? 13 : 0)) * kL512PackBytes;
+}
 // adjoint of y = act(x) W^T + b: dW = dy^T act(x) (split-K atomics into zeroed dW), db = column sums, dx (+)= (dy W) [masked]
 int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, const float* W, float* dW, float* db,
-               long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st) {
+               long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st,
+               const void* Wt_packed = nullptr) {
   DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
   DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
   // split-K so that the 16 output tiles of a 512 x 512 weight gradient become 500-1000 workgroups of >= 15 k-tiles each (measured:
@@ -795,6 +828,11 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   int rc = gemm_launch(dy, x, dW, N, K, M, ldy, ldx, K, kTA | kAtomic | (relu_in ? kReluB : 0), nullptr, nullptr, (int)split, st,
                        nullptr, db);
   if (rc) return rc;
+  if (dx && Wt_packed && N == 512 && K == 512 && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask)) {
+    // dx = dy W on the feature-sliced kernel (train_lin512.hip): D[k][row] = sum_f W[f][k] dy[row][f], W packed transposed
+    Lin512Args a{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+    return lin512_launch(a, st);
+  }
   if (dx) rc = gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
   return rc;
 }
@@ -816,20 +854,28 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
   const long long cols = P * scene->nv;
   rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
   if (rc) return rc;
+  // the 512 x 512 layers: weights packed once per call (three bf16 planes in the consuming wave's order), products on k_lin512
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
-                 bool accum, const float* resid = nullptr) {
+                 bool accum, const float* resid = nullptr, int slot = -1) {
+    if (slot >= 0 && N == 512 && K == 512 && lin512_ok(x, ldx, y, N, resid, nullptr)) {
+      void* wp = wpack_slot(ws, w, slot, false);
+      int prc = lin512_pack(W, 0, wp, st);
+      if (prc) return prc;
+      Lin512Args a{x, wp, y, b, resid, nullptr, M, ldx, N, (relu ? kL512ReluIn : 0) | (accum ? kL512Accum : 0)};
+      return lin512_launch(a, st);
+    }
     return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid);
   };
   if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, false))) return rc;
   for (int b = 0; b < 5; ++b) {
     const long long M = b < 3 ? cols : P;
     float* X = ws + w.X[b];
-    if (b < 3 && (rc = lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], X, M, kHidden, kLatent, false, true))) return rc;
-    if ((rc = lin(X, kHidden, p->fc0_w[b], p->fc0_b[b], ws + w.H[b], M, kHidden, kHidden, true, false))) return rc;
+    if (b < 3 && (rc = lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], X, M, kHidden, kLatent, false, true, nullptr, kSlotLinZ + b))) return rc;
+    if ((rc = lin(X, kHidden, p->fc0_w[b], p->fc0_b[b], ws + w.H[b], M, kHidden, kHidden, true, false, nullptr, kSlotFc0 + b))) return rc;
     // next residual stream: X + fc_1(relu(H)); the view mean comes after block 2
     float* nx = b == 4 ? ws + w.x_last : (b == 2 ? ws + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
     // (the residual enters through the product's epilogue: no copy of X)
-    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X))) return rc;
+    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b))) return rc;
     if (b == 2)
       hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3]);
   }
@@ -855,6 +901,11 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   const long long cols = P * scene->nv;
   float* dx = ws + w.dx;
   float* dH = ws + w.dH;
+  auto wt = [&](const float* W, int slot) -> const void* {      // W packed transposed for the data gradient (k_lin512), or null
+    if (!use_lin512()) return nullptr;
+    void* wp = wpack_slot(ws, w, slot, true);
+    return lin512_pack(W, 1, wp, st) == 0 ? wp : nullptr;
+  };
   hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, ws + w.d_raw);
   if ((rc = linear_bwd(ws + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
                        (float*)grads->lin_out_b, P, 4, kHidden, dx, ws + w.x_last, false, st))) return rc;
@@ -863,11 +914,12 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
     const float* X = ws + w.X[b];
     const float* H = ws + w.H[b];
     if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
-                         kHidden, kHidden, dH, H, false, st))) return rc;
+                         kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b)))) return rc;
     if ((rc = linear_bwd(dH, kHidden, X, kHidden, true, p->fc0_w[b], (float*)grads->fc0_w[b], (float*)grads->fc0_b[b], M,
-                         kHidden, kHidden, dx, X, true, st))) return rc;
+                         kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b)))) return rc;
     if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
-                                  (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st))) return rc;
+                                  (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st,
+                                  wt(p->lin_z_w[b], kSlotLinZ + b)))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
       hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P * kHidden)), dim3(256), 0, st, dx, scene->nv, P * kHidden, dH);
       float* t = dx; dx = dH; dH = t;

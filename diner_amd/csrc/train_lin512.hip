@@ -1,0 +1,287 @@
+// Training path, the layer-sized products with a 512 x 512 weight matrix (forward y = act(x) W^T + b and the data gradient
+// dx = dy W of every ResnetFC layer, resnetfc.py:61-69 / :129-159 under torch autograd in DINER.calc_losses, diner.py:217-290):
+// the inference kernels' decomposition with the training path's arithmetic.
+//
+//   * arithmetic: "bf16x6" as in train.hip -- every fp32 operand is split into three bf16 terms (8 + 8 + 8 mantissa bits, fp32's
+//     exponent range: no scaling, no range limit) and the six products above 2^-24 are accumulated in fp32 on
+//     v_mfma_f32_32x32x16_bf16;
+//   * decomposition: D[feature][row] = sum_k W[feature][k] x[row][k].  A persistent workgroup (one per CU, one wave per SIMD) takes
+//     tiles of 64 rows; wave w owns output features [128 w, 128 w + 128) of all 64 rows = 4 x 2 MFMA tiles = 128 accumulator
+//     registers.  The weights (A operand) are wave-private: packed once per parameter version into three bf16 planes in the wave's
+//     consumption order and streamed global -> VGPR through a register ring, 12 KB per k16 step (every fragment feeds 2 x {1..3}
+//     MFMAs of 32 clocks: the 64 B/clk vector-memory path is ~half busy);
+//   * the activations (B operand) are staged by the four waves together: each converts its share of the next 64 x 128 slab
+//     (fp32 -> three bf16 planes, optional relu) as a side task of the current slab's 384 MFMAs and writes it to LDS in B-fragment
+//     order; two 48 KB slab buffers, one barrier per slab;
+//   * epilogue straight from the accumulators: bias, residual, relu mask of the saved pre-activation, "+=".
+// The general kernel of train.hip (128 x 128 x 32 tiles, operands split while staged, two barriers per k-tile) stays for the
+// weight gradients and the ragged / skinny products; on a 327680 x 512 x 512 product it reaches 112-137 TFLOP/s fp32-equivalent.
+#include <atomic>
+#include <utility>
+#include "field_common.hpp"
+#include "train_lin512.hpp"
+
+namespace diner {
+namespace train {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 64;                       // rows of x per tile
+constexpr int kStepsPerSlab = 8;                // k16 steps per staged slab (128 contraction indices)
+constexpr int kSlabs = 512 / (16 * kStepsPerSlab);
+constexpr int kSlabFrags = kStepsPerSlab * 2 * 3;               // [step 8][row half 2][plane 3] fragments of 1 KB
+constexpr size_t kLdsBytes512 = (size_t)2 * kSlabFrags * 1024;  // two slab buffers = 96 KB
+
+// fp32 -> three bf16 planes (round to nearest each time; the residuals are exact in fp32), 8 values at once
+__device__ __forceinline__ void split3x8(const float (&v)[8], bf8& p0, bf8& p1, bf8& p2) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a0 = (__bf16)v[j];
+    const float r1 = v[j] - (float)a0;
+    const __bf16 a1 = (__bf16)r1;
+    const float r2 = r1 - (float)a1;
+    p0[j] = a0;
+    p1[j] = a1;
+    p2[j] = (__bf16)r2;
+  }
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Weight packing: dst[(((w * 32 + s) * 4 + rt) * 3 + pl) * 64 + lane][j] = plane pl of
+//   W[128 w + 32 rt + (lane & 31)][16 s + 8 (lane >> 5) + j]      (transpose = 0: forward, W is (out, in) as nn.Linear stores it)
+//   W[16 s + 8 (lane >> 5) + j][128 w + 32 rt + (lane & 31)]      (transpose = 1: data gradient, the roles of out / in swap)
+__global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* __restrict__ dst) {
+  const int total = 4 * 32 * 4 * 64;              // (w, s, rt, lane) slots of 8 values x 3 planes
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, rt = (i >> 6) & 3, s = (i >> 8) & 31, w = i >> 13;
+    const int f = 128 * w + 32 * rt + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = transpose ? W[(size_t)(k0 + j) * 512 + f] : W[(size_t)f * 512 + k0 + j];
+    bf8 p0, p1, p2;
+    split3x8(v, p0, p1, p2);
+    bf8* d = reinterpret_cast<bf8*>(dst) + ((((size_t)w * 32 + s) * 4 + rt) * 3) * 64 + lane;
+    d[0] = p0;
+    d[64] = p1;
+    d[128] = p2;
+  }
+}
+
+#ifndef DINER_L512_ORDER       // 0: six MFMAs per accumulator back to back; 1: one product term over the four row tiles at a time
+#define DINER_L512_ORDER 1
+#endif
+#ifndef DINER_L512_RING
+#define DINER_L512_RING 2
+#endif
+#define DINER_BF16_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
+
+template <int R>      // weight ring depth in k16 steps (kStepsPerSlab must be a multiple of it)
+__global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  typedef __attribute__((address_space(3))) bf8* lds_bf8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long long n_tiles = (a.M + kRows - 1) / kRows;
+  const bool relu_in = a.flags & kL512ReluIn;
+  lds_ptr lbase = (lds_ptr)smem + lane * 16;                 // lane's 16 B slot in fragment 0 of slab buffer 0
+  // ---- staging share of this wave: fragments (step 2 wave + i, row half h), i, h in {0, 1}; a lane reads 8 consecutive k of one row
+  f32x4 xst[4][2];
+  auto request_slab = [&](long long tile, int slab) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        long long row = tile * kRows + 32 * h + (lane & 31);
+        if (row >= a.M) row = a.M - 1;
+        const float* src = a.X + (size_t)row * a.ldx + 128 * slab + 16 * (2 * wave + i) + 8 * (lane >> 5);
+        xst[2 * i + h][0] = *reinterpret_cast<const f32x4*>(src);
+        xst[2 * i + h][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+  };
+  auto stash_frag = [&](int buf, int i, int h) {             // convert + write one fragment of the requested slab
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = xst[2 * i + h][j >> 2][j & 3];
+      v[j] = relu_in ? fmaxf(x, 0.0f) : x;
+    }
+    bf8 p0, p1, p2;
+    split3x8(v, p0, p1, p2);
+    lds_ptr d = lbase + (buf * kSlabFrags + ((2 * wave + i) * 2 + h) * 3) * 1024;
+    *(lds_bf8)(d) = p0;
+    *(lds_bf8)(d + 1024) = p1;
+    *(lds_bf8)(d + 2048) = p2;
+  };
+  // ---- weights: wave-private stream, 12 fragments (4 row tiles x 3 planes) per k16 step
+  typedef const __attribute__((address_space(1))) char* gptr;
+  const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + (size_t)wave * 32 * 12 * 1024;
+  const unsigned woff = lane * 16;
+  bf8 wr[R][12];
+  auto load_w = [&](bf8 (&dst)[12], int step, int first, int count) {        // fragments [first, first + count) of step (0..31)
+    gptr p = wbase + (size_t)step * 12 * 1024;
+    asm volatile("" : "+s"(p));                  // scalar base + per-lane 32-bit offset + immediate: no address registers per load
+#pragma unroll
+    for (int i = first; i < first + count; ++i) dst[i] = *(const __attribute__((address_space(1))) bf8*)(p + woff + i * 1024);
+  };
+
+  long long tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  // prologue: slab 0 of the first tile
+  request_slab(tile, 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) stash_frag(0, i, h);
+  __syncthreads();
+
+  f32x16 acc[4][2];
+  int unit = 0;                                              // slabs processed by this workgroup so far (buffer = unit & 1)
+  // weight ring: the first R - 1 steps; from then on every step requests the step R - 1 ahead of it (the stream repeats per tile)
+  sfor<R - 1>([&](auto S) { load_w(wr[decltype(S)::value], decltype(S)::value, 0, 12); });
+  for (; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+#pragma nounroll
+    for (int slab = 0; slab < kSlabs; ++slab, ++unit) {
+      const int buf = unit & 1;
+      // what gets staged during this slab: the next slab of this tile, or slab 0 of the workgroup's next tile
+      const bool last = slab == kSlabs - 1;
+      const long long ntile = last ? tile + gridDim.x : tile;
+      const bool stage = ntile < n_tiles;
+      if (stage) request_slab(ntile, last ? 0 : slab + 1);
+      lds_ptr rb = lbase + buf * (kSlabFrags * 1024);
+      asm volatile("" : "+v"(rb));
+      bf8 bb[2][2][3];                                       // B fragments [parity][row half][plane]
+      auto load_b = [&](int par, int s) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * 2 + h) * 3 + pl) * 1024);
+      };
+      load_b(0, 0);
+      sfor<kStepsPerSlab>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        const int gstep = slab * kStepsPerSlab + s;
+        bf8 (&wc)[12] = wr[s % R];
+#if DINER_L512_ORDER == 0
+        sfor<8>([&](auto G) {                                // (row half ct, row tile rt): 6 MFMAs each
+          constexpr int g = decltype(G)::value, ct = g >> 2, rt = g & 3;
+          __builtin_amdgcn_sched_barrier(0);
+          // the step R - 1 ahead: its 12 fragments in 8 portions (wraps into the next slab / tile: the stream repeats per tile)
+          {
+            const int ahead = (gstep + R - 1) & 31;
+            constexpr int first = (g * 12) / 8, count = ((g + 1) * 12) / 8 - first;
+            if constexpr (count > 0) load_w(wr[(s + R - 1) % R], ahead, first, count);
+          }
+          if constexpr (g == 1 && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
+          if constexpr (s >= 2 && s < 6 && g == 5) {         // staging side task: one fragment per step 2..5
+            if (stage) stash_frag(buf ^ 1, (s - 2) >> 1, (s - 2) & 1);
+          }
+          const bf8 b0 = bb[s & 1][ct][0], b1 = bb[s & 1][ct][1], b2 = bb[s & 1][ct][2];
+          const bf8 a0 = wc[3 * rt], a1 = wc[3 * rt + 1], a2 = wc[3 * rt + 2];
+          // smallest terms first
+          DINER_BF16_MFMA(acc[rt][ct], a2, b0);
+          DINER_BF16_MFMA(acc[rt][ct], a0, b2);
+          DINER_BF16_MFMA(acc[rt][ct], a1, b1);
+          DINER_BF16_MFMA(acc[rt][ct], a1, b0);
+          DINER_BF16_MFMA(acc[rt][ct], a0, b1);
+          DINER_BF16_MFMA(acc[rt][ct], a0, b0);
+          asm volatile("" : "+a"(acc[rt][ct]));
+        });
+#else
+        // 12 quarter-groups (row half ct, product term t): one MFMA on each of the four row tiles -- consecutive MFMAs never share an
+        // accumulator, and the next step's weights are requested in the first 6 of them (12 fragments, two per group)
+        sfor<12>([&](auto G) {
+          constexpr int g = decltype(G)::value, ct = g / 6, t = g % 6;
+          constexpr int ia = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;          // smallest terms first: (a2 b0) (a0 b2) (a1 b1) (a1 b0) (a0 b1) (a0 b0)
+          constexpr int ib = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (g < 6) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, 2 * g, 2);
+          if constexpr (g == 7 && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
+          if constexpr (s >= 2 && s < 6 && g == 9) {         // staging side task: one fragment per step 2..5
+            if (stage) stash_frag(buf ^ 1, (s - 2) >> 1, (s - 2) & 1);
+          }
+          const bf8 b = bb[s & 1][ct][ib];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) DINER_BF16_MFMA(acc[rt][ct], wc[3 * rt + ia], b);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) asm volatile("" : "+a"(acc[rt][ct]));
+        });
+#endif
+      });
+      __syncthreads();                                       // slab buffer `buf` is free, the next one is complete
+    }
+    // ---- epilogue: D layout of a 32 x 32 tile: lane holds row (of x) = lane & 31, features 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const long long row = tile * kRows + 32 * ct + (lane & 31);
+      if (row >= a.M) continue;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int f = 128 * wave + 32 * rt + 8 * q4 + 4 * (lane >> 5);
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = acc[rt][ct][4 * q4 + c];
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + f);
+          const size_t at = (size_t)row * a.ldy + f;
+          if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + at);
+          if (a.mask) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + at);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = m[c] > 0.0f ? v[c] : 0.0f;
+          }
+          f32x4* dst = reinterpret_cast<f32x4*>(a.Y + at);
+          if (a.flags & kL512Accum) v += *dst;
+          *dst = v;
+        }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pack_w512, dim3(128), dim3(256), 0, stream, W, transpose, (__bf16*)dst);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+int lin512_launch(const Lin512Args& a, hipStream_t stream) {
+  static std::atomic<int> attr_set[64];                      // per device: dynamic LDS size of the kernel, CU count
+  static std::atomic<int> cu_count[64];
+  int dev = 0;
+  DINER_HIP_OK(hipGetDevice(&dev));
+  dev &= 63;
+  if (!attr_set[dev].load()) {
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    int cus = 0;
+    DINER_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cu_count[dev].store(cus > 0 ? cus : 256);
+    attr_set[dev].store(1);
+  }
+  const int cus = cu_count[dev].load();
+  const long long n_tiles = (a.M + kRows - 1) / kRows;
+  const int grid = (int)(n_tiles < cus ? n_tiles : cus);
+  hipLaunchKernelGGL(k_lin512<DINER_L512_RING>, dim3(grid), dim3(256), kLdsBytes512, stream, a);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace train
+}  // namespace diner

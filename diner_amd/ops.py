@@ -427,6 +427,7 @@ PRECISION_NAMES = {"fp32": PRECISION_FP32, "f32": PRECISION_FP32, "exact": PRECI
                    "f16x3": PRECISION_F16X3, "f16x3n": PRECISION_F16X3, "split": PRECISION_F16X3,
                    "f16": PRECISION_F16, "fp16": PRECISION_F16, "half": PRECISION_F16}
 _default_precision = [PRECISION_F16X3]
+_warned_big_map = False
 
 
 def set_precision(mode):
@@ -455,6 +456,13 @@ def _precision_for(scene, precision):
     if prec not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16):
         raise ValueError(f"diner_amd: unknown precision {precision!r}")
     if prec != PRECISION_FP32 and scene.nv * scene.Hf * scene.Wf * 2048 >= (1 << 32):
+        global _warned_big_map
+        if not _warned_big_map:       # not silent: the exact kernels are ~3x slower than the f16x3 ones
+            import warnings
+            warnings.warn(f"diner_amd: one projected feature map of this scene is {scene.nv * scene.Hf * scene.Wf * 2048 / 2 ** 30:.1f} GiB; the "
+                          f"fp16-operand kernels address it with 32-bit offsets (< 4 GiB), so this scene is rendered by the exact-fp32 "
+                          f"kernels (~3x slower)", RuntimeWarning, stacklevel=3)
+            _warned_big_map = True
         return PRECISION_FP32
     return prec
 

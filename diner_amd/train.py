@@ -28,6 +28,16 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, flags=0, bias=None, mask=None, k_split
                                   int(flags), _ptr(bias), _ptr(mask), int(k_split), _stream()))
 
 
+def linear512(x, W, out, transpose=False, relu_in=False, accumulate=False, bias=None, resid=None, mask=None):
+    """out (M, 512) (+)= act(x (M, 512)) op(W) (+ bias) (+ resid) [* (mask > 0)] on the feature-sliced training kernel
+    (csrc/train_lin512.hip): transpose False = x W^T (nn.Linear forward), True = x W (data gradient)."""
+    ws = torch.empty(lib.diner_linear512_pack_bytes(), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.diner_linear512_f32(_ptr(x), _ptr(W), _ptr(out), int(x.shape[0]), int(x.stride(0)), int(out.stride(0)),
+                                       int(bool(transpose)), (1 if relu_in else 0) | (2 if accumulate else 0), _ptr(bias), _ptr(resid),
+                                       _ptr(mask), _ptr(ws), _stream()))
+    return out
+
+
 def _linear(x, W, b, out=None, relu_in=False, accumulate=False):
     """torch.nn.Linear on row-major (M, K) activations: out (M, N) (+)= act(x) W^T + b, K = W.shape[1] <= x row stride."""
     M, N, K = x.shape[0], W.shape[0], W.shape[1]

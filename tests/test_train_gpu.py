@@ -284,3 +284,31 @@ def test_gradient_reaches_the_image_encoder(ops):
     conv = [p for n, p in nerf.encoder.named_parameters() if n.endswith("conv1.weight")][0]
     assert conv.grad is not None and torch.isfinite(conv.grad).all() and float(conv.grad.abs().max()) > 0
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in nerf.mlp_fine.parameters())
+
+
+def test_linear512_against_float64():
+    """The feature-sliced 512 x 512 training product (csrc/train_lin512.hip) against float64: forward y = relu(x) W^T + b + resid and the
+    data gradient dx = (dy W) * (mask > 0) accumulated onto dx, ragged row counts (1, 63, 65, 1000, 20480: partial tiles, fewer tiles than
+    CUs, several tiles per workgroup), operands spanning 1e-8 .. 1e4 in magnitude (bf16 planes keep fp32's exponent range)."""
+    from diner_amd import train
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(512, 512, generator=g) * 0.05).cuda()
+    b = torch.randn(512, generator=g).cuda()
+    for M in (1, 63, 65, 1000, 20480, 70000):
+        x = torch.randn(M, 512, generator=g).cuda() * torch.logspace(-8, 4, 512).cuda()[torch.randperm(512, generator=g).cuda()]
+        r = torch.randn(M, 512, generator=g).cuda()
+        y = torch.empty(M, 512, device="cuda")
+        train.linear512(x, W, y, relu_in=True, bias=b, resid=r)
+        want = (torch.relu(x.double()) @ W.double().T + b.double() + r.double())
+        scale = (torch.relu(x.double()).abs() @ W.double().abs().T).max()
+        err = float((y.double() - want).abs().max() / scale)
+        # data gradient with mask and accumulation
+        dy = torch.randn(M, 512, generator=g).cuda() * 1e-6
+        m = torch.randn(M, 512, generator=g).cuda()
+        dx = torch.randn(M, 512, generator=g).cuda() * 1e-6
+        want_dx = dx.double() + (dy.double() @ W.double()) * (m.double() > 0)
+        train.linear512(dy, W, dx, transpose=True, accumulate=True, mask=m)
+        scale2 = (dy.double().abs() @ W.double().abs()).max()
+        err2 = float((dx.double() - want_dx).abs().max() / scale2)
+        print(f"linear512 M={M}: forward {err:.2e}, dgrad {err2:.2e} (max error / max sum of |products|)")
+        assert err < 1e-6 and err2 < 1e-6

@@ -13,6 +13,15 @@ cases = {
     "wgrad    dW = dy^T relu(x)": lambda f: train.gemm(dy, x, dW, N, K, M, N, K, K, train.TA | train.ATOMIC | train.RELU_B | f,
                                                         k_split=max(1, min(32, M // 1024))),
 }
+y2 = torch.empty(M, N, device="cuda")
+for label, fn in (("forward  y = relu(x) W^T     [lin512   ]", lambda: train.linear512(x, W, y2, relu_in=True)),
+                  ("dgrad    dx = dy W            [lin512   ]", lambda: train.linear512(dy, W, y2, transpose=True))):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+    print(f"{label} {M}x{N}x{K}: {dt*1e3:8.3f} ms = {2.0*M*N*K/dt/1e12:7.1f} TFLOP/s (fp32-equivalent; includes packing W)")
 for name, fn in cases.items():
     for label, flag in (("bf16x6", 0), ("fp32 MFMA", train.EXACT)):
         fn(flag); torch.cuda.synchronize()
