@@ -77,9 +77,6 @@ __global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* 
   }
 }
 
-#ifndef DINER_L512_ORDER       // 0: six MFMAs per accumulator back to back; 1: one product term over the four row tiles at a time
-#define DINER_L512_ORDER 1
-#endif
 #ifndef DINER_L512_RING
 #define DINER_L512_RING 2
 #endif
@@ -95,33 +92,50 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   const long long n_tiles = (a.M + kRows - 1) / kRows;
   const bool relu_in = a.flags & kL512ReluIn;
   lds_ptr lbase = (lds_ptr)smem + lane * 16;                 // lane's 16 B slot in fragment 0 of slab buffer 0
-  // ---- staging share of this wave: fragments (step 2 wave + i, row half h), i, h in {0, 1}; a lane reads 8 consecutive k of one row
-  f32x4 xst[4][2];
+  // ---- staging share of this wave: rows [16 w, 16 w + 16) of the tile, all 128 contraction indices of the slab.  Request i (0..7)
+  // reads rows 16 w + 2 i and + 1 whole: lanes 0..31 one row (512 contiguous bytes), lanes 32..63 the next -- 8 cache lines per
+  // instruction (a first version read B-fragment-shaped pieces, 32 rows x 16 B per instruction: 32+ lines each, and the slab
+  // staging cost 16 % of the kernel).  A lane then holds 4 consecutive k of one row: three 8-byte pieces of B fragments.
+  f32x4 xst[8];
+  auto request_one = [&](int i, long long tile, int slab) {
+    long long row = tile * kRows + 16 * wave + 2 * i + (lane >> 5);
+    if (row >= a.M) row = a.M - 1;
+    xst[i] = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + 128 * slab + 4 * (lane & 31));
+  };
   auto request_slab = [&](long long tile, int slab) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        long long row = tile * kRows + 32 * h + (lane & 31);
-        if (row >= a.M) row = a.M - 1;
-        const float* src = a.X + (size_t)row * a.ldx + 128 * slab + 16 * (2 * wave + i) + 8 * (lane >> 5);
-        xst[2 * i + h][0] = *reinterpret_cast<const f32x4*>(src);
-        xst[2 * i + h][1] = *reinterpret_cast<const f32x4*>(src + 4);
-      }
+    for (int i = 0; i < 8; ++i) request_one(i, tile, slab);
   };
-  auto stash_frag = [&](int buf, int i, int h) {             // convert + write one fragment of the requested slab
-    float v[8];
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) bf4* lds_bf4;
+  // where this lane's 4 values go inside a slab buffer: step s = k / 16, lane' = (row & 31) + 32 ((k / 8) & 1), element k & 7
+  const int k4 = 4 * (lane & 31);
+  const int st_off = ((k4 >> 4) * 2 * 3) * 1024 + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
+  bf4 sp0, sp1, sp2;                                         // the request being converted (two halves, see the slab loop)
+  auto stash_half = [&](int i, int half) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = xst[2 * i + h][j >> 2][j & 3];
-      v[j] = relu_in ? fmaxf(x, 0.0f) : x;
+    for (int j = 2 * half; j < 2 * half + 2; ++j) {
+      float x = xst[i][j];
+      if (relu_in) x = fmaxf(x, 0.0f);
+      const __bf16 a0 = (__bf16)x;
+      const float r1 = x - (float)a0;
+      const __bf16 a1 = (__bf16)r1;
+      sp0[j] = a0;
+      sp1[j] = a1;
+      sp2[j] = (__bf16)(r1 - (float)a1);
     }
-    bf8 p0, p1, p2;
-    split3x8(v, p0, p1, p2);
-    lds_ptr d = lbase + (buf * kSlabFrags + ((2 * wave + i) * 2 + h) * 3) * 1024;
-    *(lds_bf8)(d) = p0;
-    *(lds_bf8)(d + 1024) = p1;
-    *(lds_bf8)(d + 2048) = p2;
+  };
+  auto stash_write = [&](int buf, int i) {
+    const int r = 16 * wave + 2 * i + (lane >> 5);           // row within the tile
+    lds_ptr d = (lds_ptr)smem + buf * (kSlabFrags * 1024) + st_off + ((r >> 5) * 3) * 1024 + (r & 31) * 16;
+    *(lds_bf4)(d) = sp0;
+    *(lds_bf4)(d + 1024) = sp1;
+    *(lds_bf4)(d + 2048) = sp2;
+  };
+  auto stash_req = [&](int buf, int i) {                     // convert + write request i of the slab in flight
+    stash_half(i, 0);
+    stash_half(i, 1);
+    stash_write(buf, i);
   };
   // ---- weights: wave-private stream, 12 fragments (4 row tiles x 3 planes) per k16 step
   typedef const __attribute__((address_space(1))) char* gptr;
@@ -129,6 +143,9 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   const unsigned woff = lane * 16;
   bf8 wr[R][12];
   auto load_w = [&](bf8 (&dst)[12], int step, int first, int count) {        // fragments [first, first + count) of step (0..31)
+#ifdef DINER_L512_ABL_W       // ablation (wrong results): a 24 KB weight working set per wave, i.e. no L2 latency on the weight stream
+    step &= 1;
+#endif
     gptr p = wbase + (size_t)step * 12 * 1024;
     asm volatile("" : "+s"(p));                  // scalar base + per-lane 32-bit offset + immediate: no address registers per load
 #pragma unroll
@@ -140,9 +157,8 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   // prologue: slab 0 of the first tile
   request_slab(tile, 0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) stash_frag(0, i, h);
+  for (int i = 0; i < 8; ++i) stash_req(0, i);
+  request_slab(tile, 1);                                     // rolling: the slab after the next one is always in flight
   __syncthreads();
 
   f32x16 acc[4][2];
@@ -159,11 +175,14 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
 #pragma nounroll
     for (int slab = 0; slab < kSlabs; ++slab, ++unit) {
       const int buf = unit & 1;
-      // what gets staged during this slab: the next slab of this tile, or slab 0 of the workgroup's next tile
+      // Staging, branch-free so that the conversion can be scheduled between the MFMAs: during this slab the NEXT slab (requested one
+      // slab ago, in xst) is converted and written to the other buffer, one request per k16 step, and each request register is
+      // re-armed at once with the slab after that.  Past the workgroup's last slab the requests repeat valid addresses (harmless).
       const bool last = slab == kSlabs - 1;
-      const long long ntile = last ? tile + gridDim.x : tile;
-      const bool stage = ntile < n_tiles;
-      if (stage) request_slab(ntile, last ? 0 : slab + 1);
+      long long t2 = slab >= kSlabs - 2 ? tile + gridDim.x : tile;            // tile / slab two slabs ahead
+      const int s2 = (slab + 2) & (kSlabs - 1);
+      if (t2 >= n_tiles) t2 = tile;
+      (void)last;
       lds_ptr rb = lbase + buf * (kSlabFrags * 1024);
       asm volatile("" : "+v"(rb));
       bf8 bb[2][2][3];                                       // B fragments [parity][row half][plane]
@@ -178,32 +197,6 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
         constexpr int s = decltype(S)::value;
         const int gstep = slab * kStepsPerSlab + s;
         bf8 (&wc)[12] = wr[s % R];
-#if DINER_L512_ORDER == 0
-        sfor<8>([&](auto G) {                                // (row half ct, row tile rt): 6 MFMAs each
-          constexpr int g = decltype(G)::value, ct = g >> 2, rt = g & 3;
-          __builtin_amdgcn_sched_barrier(0);
-          // the step R - 1 ahead: its 12 fragments in 8 portions (wraps into the next slab / tile: the stream repeats per tile)
-          {
-            const int ahead = (gstep + R - 1) & 31;
-            constexpr int first = (g * 12) / 8, count = ((g + 1) * 12) / 8 - first;
-            if constexpr (count > 0) load_w(wr[(s + R - 1) % R], ahead, first, count);
-          }
-          if constexpr (g == 1 && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
-          if constexpr (s >= 2 && s < 6 && g == 5) {         // staging side task: one fragment per step 2..5
-            if (stage) stash_frag(buf ^ 1, (s - 2) >> 1, (s - 2) & 1);
-          }
-          const bf8 b0 = bb[s & 1][ct][0], b1 = bb[s & 1][ct][1], b2 = bb[s & 1][ct][2];
-          const bf8 a0 = wc[3 * rt], a1 = wc[3 * rt + 1], a2 = wc[3 * rt + 2];
-          // smallest terms first
-          DINER_BF16_MFMA(acc[rt][ct], a2, b0);
-          DINER_BF16_MFMA(acc[rt][ct], a0, b2);
-          DINER_BF16_MFMA(acc[rt][ct], a1, b1);
-          DINER_BF16_MFMA(acc[rt][ct], a1, b0);
-          DINER_BF16_MFMA(acc[rt][ct], a0, b1);
-          DINER_BF16_MFMA(acc[rt][ct], a0, b0);
-          asm volatile("" : "+a"(acc[rt][ct]));
-        });
-#else
         // 12 quarter-groups (row half ct, product term t): one MFMA on each of the four row tiles -- consecutive MFMAs never share an
         // accumulator, and the next step's weights are requested in the first 6 of them (12 fragments, two per group)
         sfor<12>([&](auto G) {
@@ -213,16 +206,29 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (g < 6) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, 2 * g, 2);
           if constexpr (g == 7 && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
-          if constexpr (s >= 2 && s < 6 && g == 9) {         // staging side task: one fragment per step 2..5
-            if (stage) stash_frag(buf ^ 1, (s - 2) >> 1, (s - 2) & 1);
+          // staging side task: two of the slab's eight requests per step, steps 4..7 (requested at step 0)
+          // // (which four steps makes no measurable difference)
+#ifndef DINER_L512_ABL_X
+          if constexpr (g == 8) stash_half(s, 0);
+          if constexpr (g == 9) stash_half(s, 1);
+          if constexpr (g == 10) {
+            stash_write(buf ^ 1, s);
+            request_one(s, t2, s2);
           }
+#endif
           const bf8 b = bb[s & 1][ct][ib];
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) DINER_BF16_MFMA(acc[rt][ct], wc[3 * rt + ia], b);
+          if constexpr (g == 8 || g == 9) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+              __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+          }
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) asm volatile("" : "+a"(acc[rt][ct]));
         });
-#endif
       });
       __syncthreads();                                       // slab buffer `buf` is free, the next one is complete
     }
