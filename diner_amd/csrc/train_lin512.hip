@@ -28,11 +28,9 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRows = 64;                       // rows of x per tile
 constexpr int kStepsPerSlab = 8;                // k16 steps per staged slab (128 contraction indices)
 constexpr int kSlabs = 512 / (16 * kStepsPerSlab);
-constexpr int kSlabFrags = kStepsPerSlab * 2 * 3;               // [step 8][row half 2][plane 3] fragments of 1 KB
-constexpr size_t kLdsBytes512 = (size_t)2 * kSlabFrags * 1024;  // two slab buffers = 96 KB
+constexpr size_t kLdsBytes512 = (size_t)2 * kStepsPerSlab * 2 * 3 * 1024;  // two slab buffers of [step 8][row half CT][plane 3] 1 KB fragments: 96 KB at CT = 2
 
 // fp32 -> three bf16 planes (round to nearest each time; the residuals are exact in fp32), 8 values at once
 __device__ __forceinline__ void split3x8(const float (&v)[8], bf8& p0, bf8& p1, bf8& p2) {
@@ -82,8 +80,12 @@ __global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* 
 #endif
 #define DINER_BF16_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
 
-template <int R>      // weight ring depth in k16 steps (kStepsPerSlab must be a multiple of it)
+// R: weight ring depth in k16 steps (kStepsPerSlab must be a multiple of it); CT: 32-row halves per tile -- 2 = 64-row tiles (the
+// throughput shape), 1 = 32-row tiles for small M (the reference training batch has 20480 rows: 320 tiles of 64 on 256 CUs is two rounds
+// for 1.25 rounds of work; 640 tiles of 32 balance better although a tile then feeds each weight fragment half as many MFMAs)
+template <int R, int CT>
 __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
+  constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * 3, NQ = 4 * CT;      // NQ: staging requests per wave and slab
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char* lds_ptr;
   typedef __attribute__((address_space(3))) bf8* lds_bf8;
@@ -92,25 +94,25 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   const long long n_tiles = (a.M + kRows - 1) / kRows;
   const bool relu_in = a.flags & kL512ReluIn;
   lds_ptr lbase = (lds_ptr)smem + lane * 16;                 // lane's 16 B slot in fragment 0 of slab buffer 0
-  // ---- staging share of this wave: rows [16 w, 16 w + 16) of the tile, all 128 contraction indices of the slab.  Request i (0..7)
-  // reads rows 16 w + 2 i and + 1 whole: lanes 0..31 one row (512 contiguous bytes), lanes 32..63 the next -- 8 cache lines per
+  // ---- staging share of this wave: rows [8 CT w, 8 CT (w + 1)) of the tile, all 128 contraction indices of the slab.  Request i (0..NQ-1)
+  // reads rows 8 CT w + 2 i and + 1 whole: lanes 0..31 one row (512 contiguous bytes), lanes 32..63 the next -- 8 cache lines per
   // instruction (a first version read B-fragment-shaped pieces, 32 rows x 16 B per instruction: 32+ lines each, and the slab
   // staging cost 16 % of the kernel).  A lane then holds 4 consecutive k of one row: three 8-byte pieces of B fragments.
-  f32x4 xst[8];
+  f32x4 xst[NQ];
   auto request_one = [&](int i, long long tile, int slab) {
-    long long row = tile * kRows + 16 * wave + 2 * i + (lane >> 5);
+    long long row = tile * kRows + 8 * CT * wave + 2 * i + (lane >> 5);
     if (row >= a.M) row = a.M - 1;
     xst[i] = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + 128 * slab + 4 * (lane & 31));
   };
   auto request_slab = [&](long long tile, int slab) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) request_one(i, tile, slab);
+    for (int i = 0; i < NQ; ++i) request_one(i, tile, slab);
   };
   typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) bf4* lds_bf4;
   // where this lane's 4 values go inside a slab buffer: step s = k / 16, lane' = (row & 31) + 32 ((k / 8) & 1), element k & 7
   const int k4 = 4 * (lane & 31);
-  const int st_off = ((k4 >> 4) * 2 * 3) * 1024 + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
+  const int st_off = ((k4 >> 4) * CT * 3) * 1024 + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
   bf4 sp0, sp1, sp2;                                         // the request being converted (two halves, see the slab loop)
   auto stash_half = [&](int i, int half) {
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
     }
   };
   auto stash_write = [&](int buf, int i) {
-    const int r = 16 * wave + 2 * i + (lane >> 5);           // row within the tile
+    const int r = 8 * CT * wave + 2 * i + (lane >> 5);       // row within the tile
     lds_ptr d = (lds_ptr)smem + buf * (kSlabFrags * 1024) + st_off + ((r >> 5) * 3) * 1024 + (r & 31) * 16;
     *(lds_bf4)(d) = sp0;
     *(lds_bf4)(d + 1024) = sp1;
@@ -157,11 +159,11 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   // prologue: slab 0 of the first tile
   request_slab(tile, 0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) stash_req(0, i);
+  for (int i = 0; i < NQ; ++i) stash_req(0, i);
   request_slab(tile, 1);                                     // rolling: the slab after the next one is always in flight
   __syncthreads();
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][CT];
   int unit = 0;                                              // slabs processed by this workgroup so far (buffer = unit & 1)
   // weight ring: the first R - 1 steps; from then on every step requests the step R - 1 ahead of it (the stream repeats per tile)
   sfor<R - 1>([&](auto S) { load_w(wr[decltype(S)::value], decltype(S)::value, 0, 12); });
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
 #pragma nounroll
@@ -185,12 +187,12 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
       (void)last;
       lds_ptr rb = lbase + buf * (kSlabFrags * 1024);
       asm volatile("" : "+v"(rb));
-      bf8 bb[2][2][3];                                       // B fragments [parity][row half][plane]
+      bf8 bb[2][CT][3];                                      // B fragments [parity][row half][plane]
       auto load_b = [&](int par, int s) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < CT; ++h)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * 2 + h) * 3 + pl) * 1024);
+          for (int pl = 0; pl < 3; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * CT + h) * 3 + pl) * 1024);
       };
       load_b(0, 0);
       sfor<kStepsPerSlab>([&](auto S) {
@@ -199,19 +201,20 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
         bf8 (&wc)[12] = wr[s % R];
         // 12 quarter-groups (row half ct, product term t): one MFMA on each of the four row tiles -- consecutive MFMAs never share an
         // accumulator, and the next step's weights are requested in the first 6 of them (12 fragments, two per group)
-        sfor<12>([&](auto G) {
+        sfor<6 * CT>([&](auto G) {
           constexpr int g = decltype(G)::value, ct = g / 6, t = g % 6;
           constexpr int ia = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;          // smallest terms first: (a2 b0) (a0 b2) (a1 b1) (a1 b0) (a0 b1) (a0 b0)
           constexpr int ib = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (g < 6) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, 2 * g, 2);
-          if constexpr (g == 7 && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
+          if constexpr (g == (CT == 2 ? 7 : 3) && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
           // staging side task: two of the slab's eight requests per step, steps 4..7 (requested at step 0)
           // // (which four steps makes no measurable difference)
 #ifndef DINER_L512_ABL_X
-          if constexpr (g == 8) stash_half(s, 0);
-          if constexpr (g == 9) stash_half(s, 1);
-          if constexpr (g == 10) {
+          constexpr int g0 = CT == 2 ? 8 : 2;                  // the step's request (steps 0 .. NQ-1 have one) in three groups
+          if constexpr (s < NQ && g == g0) stash_half(s, 0);
+          if constexpr (s < NQ && g == g0 + 1) stash_half(s, 1);
+          if constexpr (s < NQ && g == g0 + 2) {
             stash_write(buf ^ 1, s);
             request_one(s, t2, s2);
           }
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
           const bf8 b = bb[s & 1][ct][ib];
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) DINER_BF16_MFMA(acc[rt][ct], wc[3 * rt + ia], b);
-          if constexpr (g == 8 || g == 9) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
+          if constexpr (s < NQ && (g == (CT == 2 ? 8 : 2) || g == (CT == 2 ? 9 : 3))) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
               __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
     }
     // ---- epilogue: D layout of a 32 x 32 tile: lane holds row (of x) = lane & 31, features 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       const long long row = tile * kRows + 32 * ct + (lane & 31);
       if (row >= a.M) continue;
 #pragma unroll
@@ -269,22 +272,29 @@ int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
 }
 
 int lin512_launch(const Lin512Args& a, hipStream_t stream) {
-  static std::atomic<int> attr_set[64];                      // per device: dynamic LDS size of the kernel, CU count
+  static std::atomic<int> attr_set[64];                      // per device: dynamic LDS size of the kernels, CU count
   static std::atomic<int> cu_count[64];
   int dev = 0;
   DINER_HIP_OK(hipGetDevice(&dev));
   dev &= 63;
   if (!attr_set[dev].load()) {
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
     int cus = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(cus > 0 ? cus : 256);
     attr_set[dev].store(1);
   }
   const int cus = cu_count[dev].load();
-  const long long n_tiles = (a.M + kRows - 1) / kRows;
+  // tile height: 64 rows unless that leaves fewer than DINER_L512_SMALL (default 4) tiles per CU; DINER_L512_CT = 1 | 2 forces one
+  static const int forced = [] { const char* e = getenv("DINER_L512_CT"); return e ? atoi(e) : 0; }();
+  static const int small = [] { const char* e = getenv("DINER_L512_SMALL"); return e ? atoi(e) : 4; }();
+  const long long n64 = (a.M + 63) / 64;
+  const int ct = forced == 1 || forced == 2 ? forced : (n64 < (long long)small * cus ? 1 : 2);
+  const long long n_tiles = (a.M + 32 * ct - 1) / (32 * ct);
   const int grid = (int)(n_tiles < cus ? n_tiles : cus);
-  hipLaunchKernelGGL(k_lin512<DINER_L512_RING>, dim3(grid), dim3(256), kLdsBytes512, stream, a);
+  if (ct == 2) hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 2>), dim3(grid), dim3(256), kLdsBytes512, stream, a);
+  else hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 1>), dim3(grid), dim3(256), kLdsBytes512, stream, a);
   DINER_LAUNCH_OK();
   return 0;
 }
