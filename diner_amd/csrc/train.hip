@@ -819,8 +819,10 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
   // split-K so that the 16 output tiles of a 512 x 512 weight gradient become 500-1000 workgroups of >= 15 k-tiles each (measured:
   // 128 / 512 / 2048-ray steps 5.70 / 15.6 / 53.1 ms with M / 1024 capped at 32, 5.07 / 14.5 / 51.8 ms with M / 480 capped at 64);
+  // round 3: M / 640 -- the row-sum instance of the kernel runs two workgroups per CU, 16 tiles x 32 chunks fill the chip once for the
+  // reference batch (128 / 512 / 2048-ray steps 4.37 / 10.56 / 37.6 ms with 480, 4.00 / 10.31 / 37.5 ms with 640);
   // DINER_TRAIN_WGRAD_ROWS / _CAP override (measurement aid)
-  static const long long rows_per_chunk = [] { const char* e = getenv("DINER_TRAIN_WGRAD_ROWS"); return e ? atoll(e) : 480LL; }();
+  static const long long rows_per_chunk = [] { const char* e = getenv("DINER_TRAIN_WGRAD_ROWS"); return e ? atoll(e) : 640LL; }();
   static const long long cap = [] { const char* e = getenv("DINER_TRAIN_WGRAD_CAP"); return e ? atoll(e) : 64LL; }();
   long long split = M / rows_per_chunk;
   split = split < 1 ? 1 : (split > cap ? cap : split);

@@ -53,7 +53,7 @@ def _linear_backward(dy, x, W, relu_in, dx_out=None, dx_mask=None, dx_accumulate
     dx (M,K) (+)= (dy W) [* (dx_mask > 0)]."""
     M, N, K = dy.shape[0], W.shape[0], W.shape[1]
     dW = torch.zeros_like(W)
-    split = max(1, min(64, M // 480))          # same rule as csrc/train.hip linear_backward
+    split = max(1, min(64, M // 640))          # same rule as csrc/train.hip linear_backward
     gemm(dy, x, dW, N, K, M, dy.stride(0), x.stride(0), dW.stride(0), TA | ATOMIC | (RELU_B if relu_in else 0), k_split=split)
     db = torch.zeros(N, device=dy.device, dtype=torch.float32)
     _lib.check(lib.diner_colsum_f32(_ptr(dy), M, N, dy.stride(0), _ptr(db), _stream()))
