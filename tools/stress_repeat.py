@@ -10,7 +10,7 @@ hs, hm = T.hip_scene(ops, sc), T.hip_mlp(ops, msd)
 R = 12
 pts, dirs = T.T(g["pts"]).repeat(R, 1).cuda(), T.T(g["dirs"]).repeat(R, 1).cuda()
 big_p = T.T(g["pts"]).repeat(400, 1).cuda(); big_d = T.T(g["dirs"]).repeat(400, 1).cuda()     # 204800 points: 50 tiles per CU
-for mode, name in ((1, "f16x3"), (0, "fp32"), (2, "f16")):
+for mode, name in (("f16x3", "f16x3"), ("fp32", "fp32"), ("f16", "f16")):
     ops.set_precision(mode)
     first = ops.field_from_points(hs, hm, pts, dirs).view(R, -1, 4)
     bad = 0
