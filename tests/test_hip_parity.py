@@ -677,7 +677,7 @@ def test_image_output_against_reference_ops(ops, tmp_path):
 def test_full_frame_properties_800x600(ops):
     """BASELINE configs[2]/[3] at FULL size (one 800x600 frame = 480,000 rays, 128 samples per ray): no reference output exists at this
     size, so the statements are the size-independent properties of the path: (1) the frame does not depend on how its rays are batched or
-    sharded -- rendering the contiguous ray ranges of 2 and 7 "ranks" (diner_amd.render.shard_range, ragged last shard) with ragged batch
+    sharded -- rendering the contiguous ray ranges of 2, 7 and 8 "ranks" (diner_amd.render.shard_range, ragged last shard) with ragged batch
     sizes and concatenating gives the single-pass frame bit for bit (one noise seed per frame, keyed by ray position); (2) the same seed reproduces the frame bit for bit, another seed does
     not; (3) compositing weights are a sub-partition of unity (0 <= sum(w) <= 1 + eps), colours stay in [0, 1] on a black background,
     expected depth lies inside [near, far]; (4) with a white background every ray gains exactly 1 - sum(w) in all three channels."""
@@ -702,7 +702,7 @@ def test_full_frame_properties_800x600(ops):
     full = render_range(0, NR, 8192, seed=3, want_w=True)
     assert full.shape == (NR, 7) and torch.isfinite(full).all()
     # (1) sharding / batching invariance: the ray ranges of 2 and 7 ranks (ragged last shard), each with its own ragged batch size
-    for world, batch in ((2, 5000), (7, 8192 + 17)):
+    for world, batch in ((2, 5000), (7, 8192 + 17), (8, 8192)):        # (8 = BASELINE configs[3]'s rank count)
         parts = [render_range(*shard_range(NR, r, world), batch, seed=3) for r in range(world)]
         assert torch.equal(torch.cat(parts), full[:, :4]), f"{world}-way sharded frame differs"
     # (2) determinism
