@@ -69,6 +69,9 @@ def parse():
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = the tile gather "
                          "and the seed broadcast staged through pinned host memory (ranks SHARING a GPU: RCCL refuses two ranks "
                          "on one device); auto = nccl when every local rank has its own device, else gloo")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives of the N-rank path even with ONE rank (a 1-GPU box can "
+                         "then exercise RCCL itself: communicator creation, barrier, gather, all-reduce on device tensors)")
     ap.add_argument("--precision", choices=["f16x3", "fp32", "f16"], default=None,
                     help="MLP GEMM arithmetic of the headline number (default: the library default, f16x3)")
     return ap.parse_args()
@@ -102,8 +105,11 @@ def main():
     torch.cuda.set_device(dev)
     dist = None
     backend = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29577")):
+            os.environ.setdefault(k, v)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = args.backend if args.backend != "auto" else ("gloo" if shared else "nccl")
         if backend == "nccl":
@@ -166,9 +172,9 @@ def main():
                 _, rgb, depth = ops.render(scene, mlp, r, z, white_bkgd=white, want_weights=False, precision=precision)
                 out[r0:r0 + args.ray_batch, :3] = rgb
                 out[r0:r0 + args.ray_batch, 3] = depth
-            if world > 1 and not args.weak:
-                frame[0] = gather_tiles(out, NRF, rank, world)        # one RCCL gather of the rendered tiles per frame
-            elif world > 1:
+            if multi and not args.weak:
+                frame[0] = gather_tiles(out, NRF, rank, world, force=args.force_dist)   # one RCCL gather of the rendered tiles per frame
+            elif multi:
                 src = out if backend == "nccl" else out.cpu()
                 gat = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
                 dist.gather(src, gat, dst=0)
@@ -189,7 +195,7 @@ def main():
     NRF, lo, hi, G = (wl_head[k] for k in ("NRF", "lo", "hi", "G"))
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -207,7 +213,7 @@ def main():
         if profile:
             prof = ops.profile_collect()
             ops.profile_enable(False)
-        if world > 1:
+        if multi:
             t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -393,7 +399,7 @@ def main():
         if cpu:
             line["gpu_over_cpu"] = round(rays_per_s / cpu["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -30,11 +30,12 @@ def host_staged(group=None):
     return "nccl" not in str(dist.get_backend(group))
 
 
-def gather_tiles(local, n_total, rank, world, group=None):
+def gather_tiles(local, n_total, rank, world, group=None, force=False):
     """Gather per-rank (n_r, C) tiles (contiguous ray ranges, see shard_range) to rank 0 -> (n_total, C) or None.
 
-    Uses equal-size padded buffers so that a single gather collective suffices."""
-    if world == 1:
+    Uses equal-size padded buffers so that a single gather collective suffices.  `force`: go through the collective even with one rank
+    (bench.py --force-dist: exercises RCCL on a 1-GPU box)."""
+    if world == 1 and not force:
         return local
     import torch.distributed as dist
     per = (n_total + world - 1) // world
