@@ -105,6 +105,7 @@ def main():
     torch.cuda.set_device(dev)
     dist = None
     backend = None
+    json_fd = None
     multi = world > 1 or args.force_dist
     if multi:
         import torch.distributed as dist
@@ -112,18 +113,17 @@ def main():
             os.environ.setdefault(k, v)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = args.backend if args.backend != "auto" else ("gloo" if shared else "nccl")
+        # The collective libraries write to the process's stdout themselves (gloo: "[Gloo] Rank ..." at connect; RCCL: a version
+        # banner through C stdio, flushed at exit): file descriptor 1 is pointed at stderr for the whole run and the JSON line goes
+        # to the saved descriptor, so that rank 0's stdout carries exactly one line.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
         else:
-            sys.stdout.flush()
-            keep = os.dup(1)
-            os.dup2(2, 1)                          # gloo prints "[Gloo] Rank ..." notes to stdout: the JSON line must stay alone there
-            try:
-                dist.init_process_group(backend="gloo")
-                dist.barrier()
-            finally:
-                os.dup2(keep, 1)
-                os.close(keep)
+            dist.init_process_group(backend="gloo")
+        dist.barrier()
 
     from diner_amd import ops
     from diner_amd.render import shard_range, gather_tiles
@@ -398,7 +398,10 @@ def main():
         }
         if cpu:
             line["gpu_over_cpu"] = round(rays_per_s / cpu["value"], 1)
-        print(json.dumps(line), flush=True)
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()
 
