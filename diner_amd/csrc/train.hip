@@ -586,6 +586,117 @@ __global__ void k_field_act_bwd(const float* __restrict__ raw, const float* __re
   }
 }
 
+// ---- lin_out (512 -> 4) of the training step as skinny fp32 kernels: the general product spends 47 us on the forward and 62 + 22 us on
+// the two adjoints of a 5120-row batch whose 10 MB are a few microseconds of memory traffic.  One wave per row at a time, a lane holds
+// columns 4 lane .. + 3 and 256 + 4 lane .. + 3 of the row and of the four weight rows; explicit fmaf chains, wave sums by shuffles.
+// forward: raw = relu(x) W^T + b and out = [sigmoid(raw rgb), relu(raw sigma)] (resnetfc.py:157-158 + pixelnerf.py:139-143)
+__global__ __launch_bounds__(256) void k_lin_out_fwd(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                     long long P, float* __restrict__ raw, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  f32x4 w[4][2];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) w[o][h] = *reinterpret_cast<const f32x4*>(W + o * kHidden + 256 * h + 4 * lane);
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(b);
+  for (long long p = blockIdx.x * 4ll + (threadIdx.x >> 6); p < P; p += gridDim.x * 4ll) {
+    f32x4 xv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      xv[h] = *reinterpret_cast<const f32x4*>(x + (size_t)p * kHidden + 256 * h + 4 * lane);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[h][c] = fmaxf(xv[h][c], 0.0f);
+    }
+    float s[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float t = 0.0f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t = fmaf(xv[h][c], w[o][h][c], t);
+      s[o] = t;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) s[o] += __shfl_xor(s[o], off);
+    if (lane == 0) {
+      f32x4 r, a;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) r[o] = s[o] + bias[o];
+      a[0] = 1.0f / (1.0f + expf(-r[0]));
+      a[1] = 1.0f / (1.0f + expf(-r[1]));
+      a[2] = 1.0f / (1.0f + expf(-r[2]));
+      a[3] = fmaxf(r[3], 0.0f);
+      reinterpret_cast<f32x4*>(raw)[p] = r;
+      reinterpret_cast<f32x4*>(out)[p] = a;
+    }
+  }
+}
+// backward: d_raw from (raw, d_out) as k_field_act_bwd computes it; dx = (x > 0) * (d_raw W); dW += d_raw^T relu(x), db += column sums of
+// d_raw (atomics: both zeroed by the caller), one pass over x
+__global__ __launch_bounds__(256) void k_lin_out_bwd(const float* __restrict__ x, const float* __restrict__ raw, const float* __restrict__ dout,
+                                                     const float* __restrict__ W, long long P, float* __restrict__ dx,
+                                                     float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[4][4][kHidden + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 w[4][2], gw[4][2];
+  float gb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      w[o][h] = *reinterpret_cast<const f32x4*>(W + o * kHidden + 256 * h + 4 * lane);
+      gw[o][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  for (long long p = blockIdx.x * 4ll + wave; p < P; p += gridDim.x * 4ll) {
+    const f32x4 r = reinterpret_cast<const f32x4*>(raw)[p];
+    const f32x4 g4 = reinterpret_cast<const f32x4*>(dout)[p];
+    float d[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float sg = 1.0f / (1.0f + expf(-r[c]));
+      d[c] = g4[c] * sg * (1.0f - sg);
+    }
+    d[3] = r[3] > 0.0f ? g4[3] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) gb[o] += d[o];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const size_t at = (size_t)p * kHidden + 256 * h + 4 * lane;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + at);
+      f32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t = d[0] * w[0][h][c];
+#pragma unroll
+        for (int o = 1; o < 4; ++o) t = fmaf(d[o], w[o][h][c], t);
+        v[c] = xv[c] > 0.0f ? t : 0.0f;
+        const float xr = fmaxf(xv[c], 0.0f);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) gw[o][h][c] = fmaf(d[o], xr, gw[o][h][c]);
+      }
+      *reinterpret_cast<f32x4*>(dx + at) = v;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) red[wave][o][256 * h + 4 * lane + c] = gw[o][h][c];
+    if (lane == 0) red[wave][o][kHidden] = gb[o];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * (kHidden + 1); i += 256) {
+    const int o = i / (kHidden + 1), k = i % (kHidden + 1);
+    const float t = (red[0][o][k] + red[1][o][k]) + (red[2][o][k] + red[3][o][k]);
+    if (k < kHidden) atomicAdd(dW + o * kHidden + k, t);
+    else atomicAdd(db + o, t);
+  }
+}
+
 // Adjoint of the compositing arithmetic (nerf_renderer.py:299-301, :341-360) with respect to the field values:
 //   delta_k = z_{k+1} - z_k (last: far - z_K); s_k = relu(sigma_k); a_k = 1 - exp(-delta_k s_k); t_k = 1 - a_k + 1e-10;
 //   T_k = prod_{j<k} t_j; w_k = a_k T_k; rgb = sum w c (+ 1 - sum w); depth = sum w z.
@@ -695,6 +806,17 @@ extern "C" int diner_linear512_f32(const float* X, const float* W, float* Y, lon
   return lin512_launch(a, (hipStream_t)stream);
 }
 
+extern "C" size_t diner_wgrad512_scratch_bytes(void) { return wgrad512_part_bytes(); }
+
+extern "C" int diner_wgrad512_f32(const float* dY, const float* X, float* dW, float* db, long long M, int ldy, int ldx, int relu_x,
+                                  void* scratch, void* stream) {
+  DINER_CHECK_ARG(dY && X && dW && M > 0, "wgrad512: bad arguments");
+  DINER_CHECK_ARG(ldy >= 512 && ldx >= 512 && (ldy & 1) == 0 && (ldx & 3) == 0 && (reinterpret_cast<size_t>(dY) & 7) == 0 &&
+                  (reinterpret_cast<size_t>(X) & 15) == 0, "wgrad512: ldy even, ldx a multiple of 4 (both >= 512), dY 8-byte / X 16-byte aligned");
+  DINER_CHECK_ARG((reinterpret_cast<size_t>(scratch) & 15) == 0, "wgrad512: scratch must be 16-byte aligned");
+  return wgrad512_launch(dY, ldy, X, ldx, relu_x != 0, dW, db, M, (hipStream_t)stream, static_cast<float*>(scratch));
+}
+
 extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P,
                                       float freq_factor, float* feat, int* tap_row, float* tap_w, float* lat, void* stream) {
   DINER_CHECK_ARG(scene && xyz && viewdirs && feat && tap_row && tap_w && lat, "train_inputs: null pointer argument");
@@ -772,7 +894,7 @@ namespace {
 constexpr int kWPackSlots = 2 * 13;
 enum { kSlotFc0 = 0, kSlotFc1 = 5, kSlotLinZ = 10 };
 struct TrainWs {               // float offsets into the workspace
-  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, total;
+  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, wgpart, total;
 };
 TrainWs train_ws(long long P, int nv) {
   TrainWs w;
@@ -795,6 +917,7 @@ TrainWs train_ws(long long P, int nv) {
   w.dH = take(cols * kHidden);
   w.d_lat = take(cols * kLatent);
   w.wpack = take(kWPackSlots * (kL512PackBytes / sizeof(float)));      // packed 512 x 512 weights of train_lin512.hip
+  w.wgpart = take(wgrad512_part_bytes() / sizeof(float));          // per-chunk partial weight gradients (train_wgrad512.hip)
   w.total = o;
   return w;
 }
@@ -802,6 +925,14 @@ int check_train_params(const DinerMlpParams* p, bool poscode) { return check_mlp
 // DINER_TRAIN_LIN512=0 routes the 512 x 512 layer products back to the general kernel (A/B measurement)
 bool use_lin512() {
   static const bool on = [] { const char* e = getenv("DINER_TRAIN_LIN512"); return !(e && *e == '0'); }();
+  return on;
+}
+bool use_lin_out() {            // DINER_TRAIN_LINOUT=0: lin_out and its adjoints back on the general kernel (A/B measurement)
+  static const bool on = [] { const char* e = getenv("DINER_TRAIN_LINOUT"); return !(e && *e == '0'); }();
+  return on;
+}
+bool use_wgrad512() {          // DINER_TRAIN_WGRAD512=0: weight gradients back on the general kernel (A/B measurement)
+  static const bool on = [] { const char* e = getenv("DINER_TRAIN_WGRAD512"); return !(e && *e == '0'); }();
   return on;
 }
 bool lin512_ok(const float* x, int ldx, const float* y, int ldy, const float* resid, const float* mask) {
@@ -814,9 +945,7 @@ void* wpack_slot(float* ws, const TrainWs& w, int slot, bool transposed) {
 // adjoint of y = act(x) W^T + b: dW = dy^T act(x) (split-K atomics into zeroed dW), db = column sums, dx (+)= (dy W) [masked]
 int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, const float* W, float* dW, float* db,
                long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st,
-               const void* Wt_packed = nullptr) {
-  DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
-  DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
+               const void* Wt_packed = nullptr, float* wgpart = nullptr) {
   // split-K so that the 16 output tiles of a 512 x 512 weight gradient become 500-1000 workgroups of >= 15 k-tiles each (measured:
   // 128 / 512 / 2048-ray steps 5.70 / 15.6 / 53.1 ms with M / 1024 capped at 32, 5.07 / 14.5 / 51.8 ms with M / 480 capped at 64);
   // round 3: M / 640 -- the row-sum instance of the kernel runs two workgroups per CU, 16 tiles x 32 chunks fill the chip once for the
@@ -826,6 +955,34 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   static const long long cap = [] { const char* e = getenv("DINER_TRAIN_WGRAD_CAP"); return e ? atoll(e) : 64LL; }();
   long long split = M / rows_per_chunk;
   split = split < 1 ? 1 : (split > cap ? cap : split);
+  if (N == 512 && K == 512 && M >= 256 && use_wgrad512() && (ldy & 1) == 0 && (ldx & 3) == 0 &&
+      (reinterpret_cast<size_t>(dy) & 7) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {
+    // the 512 x 512 layers: persistent feature-sliced kernel (train_wgrad512.hip), bias gradient = row sums of its dy operand
+    // with the scratch: partial tiles + one summing pass that OVERWRITES dW / db (no zeroing, no atomics)
+    if (!wgpart) {
+      DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
+      DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
+    }
+    int rcw = wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, wgpart != nullptr);
+    if (rcw) return rcw;
+    if (dx && Wt_packed && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask)) {
+      Lin512Args a{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+      return lin512_launch(a, st);
+    }
+    if (dx) return gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
+    return 0;
+  }
+  DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
+  DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
+  // few output tiles (lin_in: 512 x 55 = 4 tiles): more row chunks so that the launch still has ~512 workgroups (>= 128 rows each);
+  // 32 chunks = 128 workgroups took 95 us for the reference batch's 20480 rows
+  const long long n_tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
+  if (n_tiles < 16) {
+    long long want = 512 / n_tiles, most = M / 128;
+    if (want > 128) want = 128;
+    if (want > most) want = most;
+    if (split < want) split = want;
+  }
   // the bias gradient (column sums of dy) rides on the weight-gradient product: dy^T is its A operand (no k_colsum pass over dy)
   int rc = gemm_launch(dy, x, dW, N, K, M, ldy, ldx, K, kTA | kAtomic | (relu_in ? kReluB : 0), nullptr, nullptr, (int)split, st,
                        nullptr, db);
@@ -856,13 +1013,18 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
   const long long cols = P * scene->nv;
   rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
   if (rc) return rc;
-  // the 512 x 512 layers: weights packed once per call (three bf16 planes in the consuming wave's order), products on k_lin512
+  // the 512 x 512 layers: weights packed once per step (three bf16 planes in the consuming wave's order; one launch for the 13 matrices
+  // in both orientations -- the backward call of the step reads the transposed ones from the workspace), products on k_lin512
+  if (use_lin512()) {
+    PackMany pm;
+    for (int b = 0; b < 5; ++b) { pm.W[kSlotFc0 + b] = p->fc0_w[b]; pm.W[kSlotFc1 + b] = p->fc1_w[b]; }
+    for (int b = 0; b < 3; ++b) pm.W[kSlotLinZ + b] = p->lin_z_w[b];
+    if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st))) return rc;
+  }
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
                  bool accum, const float* resid = nullptr, int slot = -1) {
     if (slot >= 0 && N == 512 && K == 512 && lin512_ok(x, ldx, y, N, resid, nullptr)) {
       void* wp = wpack_slot(ws, w, slot, false);
-      int prc = lin512_pack(W, 0, wp, st);
-      if (prc) return prc;
       Lin512Args a{x, wp, y, b, resid, nullptr, M, ldx, N, (relu ? kL512ReluIn : 0) | (accum ? kL512Accum : 0)};
       return lin512_launch(a, st);
     }
@@ -881,8 +1043,13 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     if (b == 2)
       hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3]);
   }
-  if ((rc = lin(ws + w.x_last, kHidden, p->lin_out_w, p->lin_out_b, ws + w.raw, P, 4, kHidden, true, false))) return rc;
-  hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, P, 4, out);
+  if (use_lin_out() && (reinterpret_cast<size_t>(p->lin_out_w) & 15) == 0 && (reinterpret_cast<size_t>(p->lin_out_b) & 15) == 0 &&
+      (reinterpret_cast<size_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(k_lin_out_fwd, dim3(grid1d(P, 4, 1024)), dim3(256), 0, st, ws + w.x_last, p->lin_out_w, p->lin_out_b, P, ws + w.raw, out);
+  } else {
+    if ((rc = lin(ws + w.x_last, kHidden, p->lin_out_w, p->lin_out_b, ws + w.raw, P, 4, kHidden, true, false))) return rc;
+    hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, P, 4, out);
+  }
   DINER_LAUNCH_OK();
   return 0;
 }
@@ -903,25 +1070,30 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   const long long cols = P * scene->nv;
   float* dx = ws + w.dx;
   float* dH = ws + w.dH;
-  auto wt = [&](const float* W, int slot) -> const void* {      // W packed transposed for the data gradient (k_lin512), or null
-    if (!use_lin512()) return nullptr;
-    void* wp = wpack_slot(ws, w, slot, true);
-    return lin512_pack(W, 1, wp, st) == 0 ? wp : nullptr;
+  auto wt = [&](const float*, int slot) -> const void* {      // W packed transposed by the forward call of the step (k_lin512), or null
+    return use_lin512() ? wpack_slot(ws, w, slot, true) : nullptr;
   };
-  hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, ws + w.d_raw);
-  if ((rc = linear_bwd(ws + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
-                       (float*)grads->lin_out_b, P, 4, kHidden, dx, ws + w.x_last, false, st))) return rc;
+  if (use_lin_out() && (reinterpret_cast<size_t>(p->lin_out_w) & 15) == 0 && (reinterpret_cast<size_t>(d_out) & 15) == 0) {
+    DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_out_w, 0, (size_t)4 * kHidden * sizeof(float), st));
+    DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_out_b, 0, 4 * sizeof(float), st));
+    hipLaunchKernelGGL(k_lin_out_bwd, dim3(grid1d(P, 4, 256)), dim3(256), 0, st, ws + w.x_last, ws + w.raw, d_out, p->lin_out_w, P, dx,
+                       (float*)grads->lin_out_w, (float*)grads->lin_out_b);
+  } else {
+    hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, ws + w.d_raw);
+    if ((rc = linear_bwd(ws + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
+                         (float*)grads->lin_out_b, P, 4, kHidden, dx, ws + w.x_last, false, st))) return rc;
+  }
   for (int b = 4; b >= 0; --b) {
     const long long M = b < 3 ? cols : P;
     const float* X = ws + w.X[b];
     const float* H = ws + w.H[b];
     if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
-                         kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b)))) return rc;
+                         kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b), ws + w.wgpart))) return rc;
     if ((rc = linear_bwd(dH, kHidden, X, kHidden, true, p->fc0_w[b], (float*)grads->fc0_w[b], (float*)grads->fc0_b[b], M,
-                         kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b)))) return rc;
+                         kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b), ws + w.wgpart))) return rc;
     if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
                                   (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st,
-                                  wt(p->lin_z_w[b], kSlotLinZ + b)))) return rc;
+                                  wt(p->lin_z_w[b], kSlotLinZ + b), ws + w.wgpart))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
       hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P * kHidden)), dim3(256), 0, st, dx, scene->nv, P * kHidden, dH);
       float* t = dx; dx = dH; dH = t;

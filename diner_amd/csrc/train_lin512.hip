@@ -58,7 +58,7 @@ __device__ __forceinline__ void sfor(F&& f) {
 // Weight packing: dst[(((w * 32 + s) * 4 + rt) * 3 + pl) * 64 + lane][j] = plane pl of
 //   W[128 w + 32 rt + (lane & 31)][16 s + 8 (lane >> 5) + j]      (transpose = 0: forward, W is (out, in) as nn.Linear stores it)
 //   W[16 s + 8 (lane >> 5) + j][128 w + 32 rt + (lane & 31)]      (transpose = 1: data gradient, the roles of out / in swap)
-__global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* __restrict__ dst) {
+__device__ __forceinline__ void pack_w512(const float* __restrict__ W, int transpose, __bf16* __restrict__ dst) {
   const int total = 4 * 32 * 4 * 64;              // (w, s, rt, lane) slots of 8 values x 3 planes
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63, rt = (i >> 6) & 3, s = (i >> 8) & 31, w = i >> 13;
@@ -73,6 +73,11 @@ __global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* 
     d[64] = p1;
     d[128] = p2;
   }
+}
+__global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* __restrict__ dst) { pack_w512(W, transpose, dst); }
+// blockIdx.y = matrix, blockIdx.z = orientation: all 512 x 512 weights of a training step in one launch
+__global__ void k_pack_w512_many(PackMany w, char* __restrict__ base) {
+  pack_w512(w.W[blockIdx.y], blockIdx.z, reinterpret_cast<__bf16*>(base + (size_t)(13 * blockIdx.z + blockIdx.y) * kL512PackBytes));
 }
 
 #ifndef DINER_L512_RING
@@ -267,6 +272,12 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
   hipLaunchKernelGGL(k_pack_w512, dim3(128), dim3(256), 0, stream, W, transpose, (__bf16*)dst);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pack_w512_many, dim3(128, n, 2), dim3(256), 0, stream, w, (char*)base);
   DINER_LAUNCH_OK();
   return 0;
 }

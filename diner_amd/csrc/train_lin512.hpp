@@ -21,7 +21,17 @@ struct Lin512Args {
 
 // W (512, 512) row-major fp32 -> packed planes; transpose = 0: y = x W^T (W as nn.Linear stores it), 1: y = x W
 int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream);
+// n <= 13 weight matrices in one launch, both orientations: W[i] -> base + i * kL512PackBytes (transpose 0) and
+// base + (13 + i) * kL512PackBytes (transpose 1)
+struct PackMany { const float* W[13]; };
+int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream);
 int lin512_launch(const Lin512Args& a, hipStream_t stream);
+// train_wgrad512.hip: dW (512, 512) += dY^T act(X), db (512, or null) += column sums of dY over M rows.  part = null: atomics into dW / db
+// (both zeroed by the caller); part = wgrad512_part_bytes() of scratch: per-chunk partial tiles + one summing pass, which overwrites
+// dW / db instead of adding to them when overwrite is set
+int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
+                    hipStream_t stream, float* part = nullptr, bool overwrite = false);
+size_t wgrad512_part_bytes();
 
 }  // namespace train
 }  // namespace diner

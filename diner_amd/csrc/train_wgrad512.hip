@@ -1,0 +1,289 @@
+// Training path, the weight gradients of the 512 x 512 layers: dW[f][k] += sum_m dy[m][f] act(x)[m][k], db[f] += sum_m dy[m][f]
+// (the adjoint of y = act(x) W^T + b with respect to W and b; resnetfc.py:61-69 / :129-159 under torch autograd in DINER.calc_losses,
+// diner.py:217-290) -- the third product of every layer, on the same persistent one-wave-per-SIMD scheme as train_lin512.hip.
+//
+//   * arithmetic: "bf16x6" (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16 products, fp32 accumulation);
+//   * the contraction runs over the ROWS m.  A workgroup owns one 128 (f) x 256 (k) tile of dW -- 8 tiles cover the matrix -- and one
+//     chunk of the rows (8 tiles x up to 32 chunks = one workgroup per CU); the four waves split the tile 2 x 2, 64 f x 128 k each:
+//     2 x 4 MFMA tiles = 128 accumulator registers (18 operand fragments from LDS per k16 step for 48 MFMAs), added to dW with atomics at the end (dW is zeroed by the caller);
+//   * both operands are stored with the contraction index OUTERMOST (row-major (M, 512) matrices), but an MFMA lane wants 8 consecutive
+//     contraction indices of ONE column.  No transpose is needed: a lane that loads the same 4 (x) or 2 (dy) columns of 8 consecutive
+//     rows holds exactly four / two such lane-fragments.  Per 32-row slab a wave requests 8 x 16 B + 8 x 8 B per lane (its own 64
+//     columns of x and 32 columns of dy), converts them to bf16 planes as a side task of the previous slab's MFMAs and writes them to
+//     LDS in fragment order; two 72 KB slab buffers, one barrier per slab (96 MFMAs per wave);
+//   * the bias gradient is the row sum of the dy operand: the staging lanes of the workgroups with k-tile 0 keep it in two registers.
+// Replaces k_gemm_bf16x6<2> (train.hip) for these shapes: 128 x 128 x 32 tiles with two barriers per k-tile and 64-way split-K
+// reached 138-142 TFLOP/s on 327680 rows and 93 us per product on the reference batch's 20480 rows.
+#include <atomic>
+#include <utility>
+#include "field_common.hpp"
+#include "train_lin512.hpp"
+
+namespace diner {
+namespace train {
+
+typedef __bf16 bf8w __attribute__((ext_vector_type(8)));
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+constexpr int kWgFragsPerStep = (4 + 8) * 3;                     // [A: 4 f tiles | B: 8 k tiles][plane 3] fragments of 1 KB per k16 step
+constexpr int kWgSlabBytes = 2 * kWgFragsPerStep * 1024;         // two steps (32 rows) per slab: 72 KB
+constexpr size_t kLdsBytesWgrad = (size_t)2 * kWgSlabBytes;      // two slab buffers
+constexpr int kWgMaxChunks = 32;                                 // row chunks (the scratch holds one partial dW + db per chunk)
+
+struct Wgrad512Args {
+  const float* dY;       // (M, ldy)
+  const float* X;        // (M, ldx)
+  float* dW;             // (512, 512), atomically accumulated (zeroed by the caller)
+  float* db;             // 512 or null, atomically accumulated
+  float* part;           // null, or (n_chunks, 512, 512) scratch: every chunk STORES its partial dW there and k_wgrad512_reduce sums them
+                         // (32 atomics per element of dW cost as much as the products of the reference batch's 20480 rows)
+  long long M;
+  int ldy, ldx, relu_x;
+  int n_chunks;          // row chunks (grid = 8 * n_chunks)
+  long long rows_per_chunk;      // multiple of 32
+};
+
+template <class F, int... I>
+__device__ __forceinline__ void wfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wfor(F&& f) {
+  wfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+#define DINER_WG_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
+
+__global__ __launch_bounds__(256, 1) void k_wgrad512(Wgrad512Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  typedef __attribute__((address_space(3))) bf8w* lds_bf8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  // workgroup b: tile (b / 8) % 8, chunk b % 8 + 8 (b / 64) -- the 8 tiles of one chunk read the same rows and run on one XCD
+  const int tile = (blockIdx.x >> 3) & 7, chunk = (blockIdx.x & 7) + 8 * (blockIdx.x >> 6);
+  const int ft = tile >> 1, kt2 = tile & 1;                  // f range [128 ft, +128), k range [256 kt2, +256)
+  const long long m_begin = (long long)chunk * a.rows_per_chunk;
+  long long m_end = m_begin + a.rows_per_chunk;
+  if (m_end > a.M) m_end = a.M;
+  if (m_begin >= a.M) return;
+  const int n_slabs = (int)((m_end - m_begin + 31) / 32);
+
+  // ---- staging: wave w owns columns [64 w, +64) of the tile's x range and [32 w, +32) of its dy range, all 32 rows of a slab.
+  // Request j (0..7) of x: lanes 16 g .. 16 g + 15 read row 8 g + j (g = row group = (step, half)), 4 columns each;
+  // of dy: the same rows, 2 columns each.  After the 8 requests a lane holds rows 8 g .. 8 g + 7 of its columns.
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 xr[8];
+  f32x2w yr[8];
+  const float* xbase = a.X + 256 * kt2 + 64 * wave + 4 * li;
+  const float* ybase = a.dY + 128 * ft + 32 * wave + 2 * li;
+  auto request = [&](int j, long long m0) {                  // rows of the slab that starts at m0
+    long long row = m0 + 8 * g + j;
+    const bool ok = row < m_end;
+    if (!ok) row = m_begin;
+    f32x4 xv = *reinterpret_cast<const f32x4*>(xbase + (size_t)row * a.ldx);
+    f32x2w yv = *reinterpret_cast<const f32x2w*>(ybase + (size_t)row * a.ldy);
+    if (!ok) {                                               // rows past the chunk contribute zeros
+      xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      yv = (f32x2w){0.f, 0.f};
+    }
+    xr[j] = xv;
+    yr[j] = yv;
+  };
+  // LDS slots of this lane's fragments inside a slab buffer: step s = g >> 1, lane' = column & 31 + 32 (g & 1)
+  lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kWgFragsPerStep * 1024) + (32 * (g & 1)) * 16;
+  // x columns 64 w + 4 li + c -> B tile 2 w + (li >> 3), lane' += 4 (li & 7) + c;   dy columns 32 w + 2 li + c -> A tile w, lane' += 2 li + c
+  const int xslot = ((4 + 2 * wave + (li >> 3)) * 3) * 1024 + (4 * (li & 7)) * 16;
+  const int yslot = (wave * 3) * 1024 + (2 * li) * 16;
+  float rs0 = 0.0f, rs1 = 0.0f;                              // row sums of this lane's two dy columns (bias gradient)
+  bf8w sp0, sp1, sp2;                                        // the lane-fragment being converted (two halves of 4 rows)
+  auto split_half = [&](const float (&v)[4], int half) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 a0 = (__bf16)v[j];
+      const float r1 = v[j] - (float)a0;
+      const __bf16 a1 = (__bf16)r1;
+      sp0[4 * half + j] = a0;
+      sp1[4 * half + j] = a1;
+      sp2[4 * half + j] = (__bf16)(r1 - (float)a1);
+    }
+  };
+  auto store_frag = [&](lds_ptr d) {
+    *(lds_bf8)(d) = sp0;
+    *(lds_bf8)(d + 1024) = sp1;
+    *(lds_bf8)(d + 2048) = sp2;
+  };
+  // unit i (0..5): columns 0..3 of the lane's x block, then 0..1 of its dy block; half 0 / 1 = rows 0..3 / 4..7 (+ the store)
+  auto stash_half = [&](int buf, int i, int half) {
+    float v[4];
+    if (i < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = xr[4 * half + j][i];
+        v[j] = a.relu_x ? fmaxf(x, 0.0f) : x;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = yr[4 * half + j][i - 4];
+      const float sum = (v[0] + v[1]) + (v[2] + v[3]);
+      if (i == 4) rs0 += sum; else rs1 += sum;
+    }
+    split_half(v, half);
+    if (half == 1) store_frag(sbase + buf * kWgSlabBytes + (i < 4 ? xslot + i * 16 : yslot + (i - 4) * 16));
+  };
+  // ---- prologue: slab 0 staged, slab 1 requested
+#pragma unroll
+  for (int j = 0; j < 8; ++j) request(j, m_begin);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    stash_half(0, i, 0);
+    stash_half(0, i, 1);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) request(j, m_begin + 32);      // (past the chunk: zeros)
+  __syncthreads();
+
+  const int wf = wave >> 1, wk = wave & 1;                    // this wave's 64 f x 128 k quarter of the tile
+  f32x16w acc[2][4];
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[fi][kt][e] = 0.0f;
+  lds_ptr lbase = (lds_ptr)smem + lane * 16;
+#pragma nounroll
+  for (int slab = 0; slab < n_slabs; ++slab) {
+    const int buf = slab & 1;
+    const long long m_next2 = m_begin + 32ll * (slab + 2);    // the slab requested while this one multiplies
+    lds_ptr rb = lbase + buf * kWgSlabBytes;
+    asm volatile("" : "+v"(rb));
+    wfor<2>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      bf8w af[2][3], bfr[2][3];
+#pragma unroll
+      for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[fi][pl] = *(lds_bf8)(rb + (s * kWgFragsPerStep + (2 * wf + fi) * 3 + pl) * 1024);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bfr[0][pl] = *(lds_bf8)(rb + (s * kWgFragsPerStep + (4 + 4 * wk) * 3 + pl) * 1024);
+      wfor<8>([&](auto G) {
+        constexpr int gi = decltype(G)::value, kt = gi >> 1, fi = gi & 1;
+        constexpr int u = s * 8 + gi;                        // 16 groups of 6 MFMAs per slab
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (fi == 0 && kt + 1 < 4) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            bfr[(kt + 1) & 1][pl] = *(lds_bf8)(rb + (s * kWgFragsPerStep + (4 + 4 * wk + kt + 1) * 3 + pl) * 1024);
+        }
+        // staging side task: the next slab's six lane-fragment columns, each in two halves, groups 1..12; requests re-armed in group 13
+        if constexpr (u >= 1 && u <= 12) stash_half(buf ^ 1, (u - 1) >> 1, (u - 1) & 1);
+        if constexpr (u == 13) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) request(j, m_next2);
+        }
+        const bf8w b0 = bfr[kt & 1][0], b1 = bfr[kt & 1][1], b2 = bfr[kt & 1][2];
+        // smallest terms first
+        DINER_WG_MFMA(acc[fi][kt], af[fi][2], b0);
+        DINER_WG_MFMA(acc[fi][kt], af[fi][0], b2);
+        DINER_WG_MFMA(acc[fi][kt], af[fi][1], b1);
+        DINER_WG_MFMA(acc[fi][kt], af[fi][1], b0);
+        DINER_WG_MFMA(acc[fi][kt], af[fi][0], b1);
+        DINER_WG_MFMA(acc[fi][kt], af[fi][0], b0);
+        if constexpr (u >= 1 && u <= 12) {                   // the conversion between the MFMAs: <= 7 vector-ALU slots per 32-clock MFMA
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        }
+        asm volatile("" : "+a"(acc[fi][kt]));
+      });
+    });
+    __syncthreads();                                         // slab buffer `buf` is free, the next one is complete
+  }
+
+  // ---- epilogue: D layout of a 32 x 32 tile: lane holds column (k) = lane & 31, rows (f) = 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = 256 * kt2 + 32 * (4 * wk + kt) + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int f = 128 * ft + 32 * (2 * wf + fi) + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (a.part) a.part[((size_t)chunk * 512 + f) * 512 + k] = acc[fi][kt][e];
+        else atomicAdd(a.dW + (size_t)f * 512 + k, acc[fi][kt][e]);
+      }
+    }
+  if (a.db && kt2 == 0) {                                    // one k tile column of workgroups adds the row sums of dy
+    const int f = 128 * ft + 32 * wave + 2 * li;
+    if (a.part) {                                            // the four row groups of a column summed across lanes, one plain store
+      rs0 += __shfl_xor(rs0, 16); rs0 += __shfl_xor(rs0, 32);
+      rs1 += __shfl_xor(rs1, 16); rs1 += __shfl_xor(rs1, 32);
+      if (lane < 16) {
+        float* pdb = a.part + (size_t)kWgMaxChunks * 512 * 512 + (size_t)chunk * 512;
+        pdb[f] = rs0;
+        pdb[f + 1] = rs1;
+      }
+    } else {
+      atomicAdd(a.db + f, rs0);
+      atomicAdd(a.db + f + 1, rs1);
+    }
+  }
+}
+
+// dW[i] (+)= sum over the chunks of part[c][i]; db likewise from the partial row sums behind the tiles
+__global__ void k_wgrad512_reduce(const float* __restrict__ part, int n_chunks, int overwrite, float* __restrict__ dW, float* __restrict__ db) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= 512 * 512) return;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s = overwrite ? zero : *reinterpret_cast<const f32x4*>(dW + i);
+  for (int c = 0; c < n_chunks; ++c) s += *reinterpret_cast<const f32x4*>(part + (size_t)c * 512 * 512 + i);
+  *reinterpret_cast<f32x4*>(dW + i) = s;
+  if (db && i < 512) {
+    const float* pdb = part + (size_t)kWgMaxChunks * 512 * 512;
+    f32x4 t = overwrite ? zero : *reinterpret_cast<const f32x4*>(db + i);
+    for (int c = 0; c < n_chunks; ++c) t += *reinterpret_cast<const f32x4*>(pdb + (size_t)c * 512 + i);
+    *reinterpret_cast<f32x4*>(db + i) = t;
+  }
+}
+
+size_t wgrad512_part_bytes() { return (size_t)kWgMaxChunks * (512 * 512 + 512) * sizeof(float); }
+
+// dW (512, 512) += dY^T act(X), db (512) += column sums of dY, over M rows; dW / db zeroed by the caller.  part: null (atomics into dW) or
+// wgrad512_part_bytes() of scratch (partial tiles stored per chunk + one reduction pass); with it overwrite = true makes dW / db plain
+// outputs (no zeroing by the caller).
+int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
+                    hipStream_t stream, float* part, bool overwrite) {
+  DINER_CHECK_ARG(part || !overwrite, "wgrad512: overwrite needs the scratch buffer");
+  static std::atomic<int> attr_set[64];
+  int dev = 0;
+  DINER_HIP_OK(hipGetDevice(&dev));
+  dev &= 63;
+  if (!attr_set[dev].load()) {
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesWgrad));
+    attr_set[dev].store(1);
+  }
+  // row chunks: 32 (8 tiles x 32 = 256 workgroups) unless a chunk would be shorter than 4 slabs
+  long long n_chunks = 32;
+  while (n_chunks > 1 && (M + n_chunks - 1) / n_chunks < 128) n_chunks >>= 1;
+  if (n_chunks < 8) n_chunks = n_chunks < 1 ? 1 : n_chunks;
+  long long rows = (M + n_chunks - 1) / n_chunks;
+  rows = (rows + 31) / 32 * 32;
+  // the block -> (tile, chunk) map needs whole groups of 8 chunks when there are more than 8
+  Wgrad512Args a{dY, X, dW, db, part, M, ldy, ldx, relu_x ? 1 : 0, (int)n_chunks, rows};
+  const int grid = 8 * (int)(n_chunks <= 8 ? 8 : n_chunks);
+  hipLaunchKernelGGL(k_wgrad512, dim3(grid), dim3(256), kLdsBytesWgrad, stream, a);
+  if (part) {
+    // chunks that start past M wrote nothing: only the chunks with rows are summed
+    const int used = (int)((M + rows - 1) / rows);
+    hipLaunchKernelGGL(k_wgrad512_reduce, dim3(256), dim3(256), 0, stream, part, used, overwrite ? 1 : 0, dW, db);
+  }
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace train
+}  // namespace diner

@@ -38,6 +38,17 @@ def linear512(x, W, out, transpose=False, relu_in=False, accumulate=False, bias=
     return out
 
 
+def wgrad512(dy, x, dW, db=None, relu_in=False, scratch=None):
+    """dW (512, 512) += dy^T act(x), db (512) += column sums of dy on the persistent training kernel (csrc/train_wgrad512.hip);
+    both are accumulated (zero them first).  scratch: None = the row chunks add into dW with atomics; True = allocate, or a uint8 tensor
+    of diner_wgrad512_scratch_bytes(): per-chunk partial tiles + one summing pass (what the training step does)."""
+    if scratch is True:
+        scratch = torch.empty(lib.diner_wgrad512_scratch_bytes(), dtype=torch.uint8, device=dy.device)
+    _lib.check(lib.diner_wgrad512_f32(_ptr(dy), _ptr(x), _ptr(dW), _ptr(db), int(dy.shape[0]), int(dy.stride(0)), int(x.stride(0)),
+                                      int(bool(relu_in)), _ptr(scratch), _stream()))
+    return dW
+
+
 def _linear(x, W, b, out=None, relu_in=False, accumulate=False):
     """torch.nn.Linear on row-major (M, K) activations: out (M, N) (+)= act(x) W^T + b, K = W.shape[1] <= x row stride."""
     M, N, K = x.shape[0], W.shape[0], W.shape[1]
@@ -101,6 +112,13 @@ class FieldFunction(torch.autograd.Function):
     forward (keeps every pre-activation in `ws`), one for the backward (diner_field_train_{forward,backward}_f32)."""
 
     @staticmethod
+    def _alloc_outputs(params, latent_shape, dev):
+        """Gradient buffers of the 30 parameters + their DinerMlpParams struct + the channels-last latent gradient."""
+        grads = [torch.empty_like(p) for p in params]
+        nv, Cc, Hf, Wf = latent_shape
+        return grads, _param_struct(grads), torch.empty(nv, Hf, Wf, Cc, device=dev)
+
+    @staticmethod
     def forward(ctx, scene: HipScene, xyz, viewdirs, latent, freq_factor, *params):
         import ctypes as C
         _require_hip(xyz, viewdirs, latent)
@@ -114,8 +132,12 @@ class FieldFunction(torch.autograd.Function):
             ps, keep = _param_struct(params, freq_factor)
             _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
                                                          _ptr(ws), _stream()))
+            # the backward's outputs are allocated here, while the device works on the forward: the host is idle now and is the one the
+            # device waits for at the start of the backward (64 us of the reference batch's 3.9 ms step)
+            ctx.ps = (ps, keep)
+            ctx.latent_shape = tuple(latent.shape)
+            ctx.prealloc = FieldFunction._alloc_outputs(params, ctx.latent_shape, dev) if any(ctx.needs_input_grad) else None
         ctx.scene, ctx.P = scene, P
-        ctx.latent_shape = tuple(latent.shape)
         ctx.save_for_backward(ws, *params)
         return out
 
@@ -123,16 +145,14 @@ class FieldFunction(torch.autograd.Function):
     def backward(ctx, d_out):
         import ctypes as C
         ws, params = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
-        dev = d_out.device
-        with torch.cuda.device(dev):
+        with torch.cuda.device(d_out.device):
+            # (a second backward through a retained graph gets fresh buffers: the first call's are the parameters' .grad by now)
+            pre, ctx.prealloc = ctx.prealloc, None
+            grads, (gs, keep_g), d_cl = pre if pre is not None else FieldFunction._alloc_outputs(params, ctx.latent_shape, d_out.device)
+            if not ctx.needs_input_grad[3]:
+                d_cl = None
+            ps, keep = ctx.ps
             d_out = _f32c(d_out)
-            grads = [torch.empty_like(p) for p in params]
-            ps, keep = _param_struct(params)
-            gs, keep_g = _param_struct(grads)
-            d_cl = None
-            if ctx.needs_input_grad[3]:
-                nv, Cc, Hf, Wf = ctx.latent_shape
-                d_cl = torch.empty(nv, Hf, Wf, Cc, device=dev)
             _lib.check(lib.diner_field_train_backward_f32(ctx.scene.ref, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out),
                                                           _ptr(ws), _ptr(d_cl), _stream()))
         return (None, None, None, d_cl.permute(0, 3, 1, 2) if d_cl is not None else None, None) + tuple(grads)

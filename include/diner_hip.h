@@ -234,6 +234,15 @@ int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N,
 size_t diner_linear512_pack_bytes(void);
 int diner_linear512_f32(const float* X, const float* W, float* Y, long long M, int ldx, int ldy, int transpose, int flags,
                         const float* bias, const float* resid, const float* mask, void* wpack, void* stream);
+/* The weight / bias gradient of a 512 x 512 layer on the persistent kernel of train_wgrad512.hip (what diner_field_train_backward_f32 uses):
+ * dW (512, 512) += dY^T act(X), db (512, or NULL) += column sums of dY, over M >= 1 rows of dY (M, ldy) and X (M, ldx); relu_x != 0 applies
+ * relu to X while it is staged.  Both outputs are ACCUMULATED: zero them first.  scratch: NULL (row chunks add into dW with atomics) or
+ * diner_wgrad512_scratch_bytes() bytes of device memory (every chunk stores its partial dW there and one pass sums them: what the training
+ * step uses; 32 atomics per element cost as much as the products of a 20480-row batch).  ldy even, ldx a multiple of 4, dY 8-byte and
+ * X 16-byte aligned.  Six-term split-bf16 products (fp32-class accuracy, no range limits). */
+size_t diner_wgrad512_scratch_bytes(void);
+int diner_wgrad512_f32(const float* dY, const float* X, float* dW, float* db, long long M, int ldy, int ldx, int relu_x, void* scratch,
+                       void* stream);
 /* Per-(view, point) MLP inputs of PixelNeRF.forward (pixelnerf.py:91-128) for explicit points xyz / viewdirs (P,3):
  *   feat (NV*P, 64) the 55 encoded inputs zero-padded, tap_row (NV*P, 4) int32 texel rows of the channels-last latent,
  *   tap_w (NV*P, 4) bilinear weights, lat (NV*P, 512) the interpolated latent (SpatialEncoder.index). */

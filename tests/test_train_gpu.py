@@ -95,7 +95,7 @@ def test_field_forward_and_backward_against_oracle_autograd(ops):
     params, names = module_param_list(msd)
     out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
     e_fwd = max_norm_rel(out.detach().cpu(), g["out"][:P])
-    (out * G.cuda()).sum().backward()
+    (out * G.cuda()).sum().backward(retain_graph=True)
     e_lat = max_norm_rel(latent.grad.cpu(), dlat_o)
     worst = ("", 0.0)
     for p, (k, i) in zip(params, names):
@@ -105,6 +105,12 @@ def test_field_forward_and_backward_against_oracle_autograd(ops):
     print(f"training path: forward {e_fwd:.2e}, d latent {e_lat:.2e}, worst parameter gradient {worst[0]} {worst[1]:.2e}")
     assert e_fwd < 2e-5 and e_lat < TOL_GRAD and worst[1] < TOL_GRAD
     assert (latent.grad != 0).any() and all((p.grad != 0).any() for p in params)
+    # a second backward through the retained graph (the gradient buffers of the first one, allocated during the forward, are the
+    # parameters' .grad by now and must not be written again): everything doubles
+    first = [p.grad.clone() for p in params] + [latent.grad.clone()]
+    (out * G.cuda()).sum().backward()
+    for a, b in zip(first, [p.grad for p in params] + [latent.grad]):
+        assert max_norm_rel(b.cpu(), 2 * a.cpu()) < 1e-5
 
 
 def test_composite_backward_against_oracle_autograd(ops):
@@ -312,3 +318,25 @@ def test_linear512_against_float64():
         err2 = float((dx.double() - want_dx).abs().max() / scale2)
         print(f"linear512 M={M}: forward {err:.2e}, dgrad {err2:.2e} (max error / max sum of |products|)")
         assert err < 1e-6 and err2 < 1e-6
+
+
+def test_wgrad512_against_float64():
+    """The persistent weight-gradient kernel (csrc/train_wgrad512.hip) against float64: dW = dy^T relu(x), db = column sums of dy, ragged
+    row counts (fewer rows than a slab, partial slabs, 1 .. 32 row chunks), operands spanning 1e-8 .. 1e4."""
+    from diner_amd import train
+    g = torch.Generator().manual_seed(4)
+    for M in (1, 31, 257, 4097, 20480, 70001):
+        x = torch.randn(M, 512, generator=g).cuda() * torch.logspace(-6, 3, 512).cuda()[torch.randperm(512, generator=g).cuda()]
+        dy = torch.randn(M, 512, generator=g).cuda() * torch.logspace(-8, 0, 512).cuda()[torch.randperm(512, generator=g).cuda()]
+        want = dy.double().T @ torch.relu(x.double())
+        scale = (dy.double().abs().T @ torch.relu(x.double()).abs()).max()
+        want_b = dy.double().sum(0)
+        scratch = torch.full((train.lib.diner_wgrad512_scratch_bytes(),), 0xFF, dtype=torch.uint8, device="cuda")   # NaN patterns: stale reads show
+        for how, ws in (("atomics", None), ("partials", scratch)):
+            dW = torch.zeros(512, 512, device="cuda")
+            db = torch.zeros(512, device="cuda")
+            train.wgrad512(dy, x, dW, db, relu_in=True, scratch=ws)
+            e_w = float((dW.double() - want).abs().max() / scale)
+            e_b = float((db.double() - want_b).abs().max() / dy.double().abs().sum(0).max())
+            print(f"wgrad512 M={M} ({how}): dW {e_w:.2e}, db {e_b:.2e} (max error / max sum of |products|)")
+            assert e_w < 2e-6 and e_b < 2e-6

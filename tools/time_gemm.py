@@ -22,6 +22,16 @@ for label, fn in (("forward  y = relu(x) W^T     [lin512   ]", lambda: train.lin
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 5
     print(f"{label} {M}x{N}x{K}: {dt*1e3:8.3f} ms = {2.0*M*N*K/dt/1e12:7.1f} TFLOP/s (fp32-equivalent; includes packing W)")
+dW2 = torch.zeros(N, K, device="cuda"); db2 = torch.zeros(N, device="cuda")
+sc = torch.empty(train.lib.diner_wgrad512_scratch_bytes(), dtype=torch.uint8, device="cuda")
+for how, ws in (("atomics", None), ("partials", sc)):
+    fnw = lambda: train.wgrad512(dy, x, dW2, db2, relu_in=True, scratch=ws)
+    fnw(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(20): fnw()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 20
+    print(f"wgrad    dW = dy^T relu(x), db [wgrad512 {how:8s}] {M}x{N}x{K}: {dt*1e3:8.3f} ms = {2.0*M*N*K/dt/1e12:7.1f} TFLOP/s (fp32-equivalent)")
 for name, fn in cases.items():
     for label, flag in (("bf16x6", 0), ("fp32 MFMA", train.EXACT)):
         fn(flag); torch.cuda.synchronize()

@@ -21,7 +21,8 @@ for NR in SIZES:
     t = time.perf_counter()
     n = 10
     for _ in range(n): step()
+    host = (time.perf_counter() - t) / n                   # host time to enqueue a step (the device is still working)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
     flop = 3 * 2 * NR * K * (4 * (55 * 512 + 9 * 512 * 512) + 4 * 512 * 512 + 4 * 512)      # fwd + dgrad + wgrad
-    print(f"{NR} rays x {K} samples: {dt*1e3:.2f} ms per forward+backward step = {NR/dt:.0f} rays/s, {flop/dt/1e12:.1f} TFLOP/s fp32")
+    print(f"{NR} rays x {K} samples: {dt*1e3:.2f} ms per forward+backward step = {NR/dt:.0f} rays/s, {flop/dt/1e12:.1f} TFLOP/s fp32; host enqueue {host*1e3:.2f} ms per step")
