@@ -65,6 +65,7 @@ SIGNATURES = {
     "diner_linear512_pack_bytes": (C.c_size_t, []),
     "diner_linear512_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_channels_last_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_wgrad512_scratch_bytes": (C.c_size_t, []),
     "diner_wgrad512_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p]),

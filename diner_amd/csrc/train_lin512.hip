@@ -88,9 +88,12 @@ __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base) {
 // R: weight ring depth in k16 steps (kStepsPerSlab must be a multiple of it); CT: 32-row halves per tile -- 2 = 64-row tiles (the
 // throughput shape), 1 = 32-row tiles for small M (the reference training batch has 20480 rows: 320 tiles of 64 on 256 CUs is two rounds
 // for 1.25 rounds of work; 640 tiles of 32 balance better although a tile then feeds each weight fragment half as many MFMAs)
-template <int R, int CT>
+// FH: feature halves -- 1: a workgroup computes all 512 features of its rows; 2: workgroup pairs share a tile, each computes 256 features
+// (wave w: 64 features = 2 MFMA row tiles) -- half-cost units for the ragged last round of a small M (lin512_launch)
+template <int R, int CT, int FH>
 __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * 3, NQ = 4 * CT;      // NQ: staging requests per wave and slab
+  constexpr int NRT = 4 / FH, NF = 3 * NRT;                  // MFMA row (= feature) tiles per wave, weight fragments per k16 step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char* lds_ptr;
   typedef __attribute__((address_space(3))) bf8* lds_bf8;
@@ -144,12 +147,15 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
     stash_half(i, 1);
     stash_write(buf, i);
   };
-  // ---- weights: wave-private stream, 12 fragments (4 row tiles x 3 planes) per k16 step
+  // ---- weights: wave-private stream, NF fragments (NRT row tiles x 3 planes) per k16 step out of the 12 of the packed wave slice
   typedef const __attribute__((address_space(1))) char* gptr;
-  const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + (size_t)wave * 32 * 12 * 1024;
+  const int half = FH == 2 ? (int)(blockIdx.x & 1) : 0;
+  const int wslice = FH == 2 ? 2 * half + (wave >> 1) : wave;                // 128-feature slice of the packed weights
+  const int rt0 = FH == 2 ? 2 * (wave & 1) : 0;                              // first of this wave's row tiles inside the slice
+  const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + ((size_t)wslice * 32 * 12 + 3 * rt0) * 1024;
   const unsigned woff = lane * 16;
-  bf8 wr[R][12];
-  auto load_w = [&](bf8 (&dst)[12], int step, int first, int count) {        // fragments [first, first + count) of step (0..31)
+  bf8 wr[R][NF];
+  auto load_w = [&](bf8 (&dst)[NF], int step, int first, int count) {        // fragments [first, first + count) of step (0..31)
 #ifdef DINER_L512_ABL_W       // ablation (wrong results): a 24 KB weight working set per wave, i.e. no L2 latency on the weight stream
     step &= 1;
 #endif
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
     for (int i = first; i < first + count; ++i) dst[i] = *(const __attribute__((address_space(1))) bf8*)(p + woff + i * 1024);
   };
 
-  long long tile = blockIdx.x;
+  long long tile = blockIdx.x / FH;
+  const int tile_stride = gridDim.x / FH;
   if (tile >= n_tiles) return;
   // prologue: slab 0 of the first tile
   request_slab(tile, 0);
@@ -168,13 +175,13 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   request_slab(tile, 1);                                     // rolling: the slab after the next one is always in flight
   __syncthreads();
 
-  f32x16 acc[4][CT];
+  f32x16 acc[NRT][CT];
   int unit = 0;                                              // slabs processed by this workgroup so far (buffer = unit & 1)
   // weight ring: the first R - 1 steps; from then on every step requests the step R - 1 ahead of it (the stream repeats per tile)
-  sfor<R - 1>([&](auto S) { load_w(wr[decltype(S)::value], decltype(S)::value, 0, 12); });
-  for (; tile < n_tiles; tile += gridDim.x) {
+  sfor<R - 1>([&](auto S) { load_w(wr[decltype(S)::value], decltype(S)::value, 0, NF); });
+  for (; tile < n_tiles; tile += tile_stride) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
       // slab ago, in xst) is converted and written to the other buffer, one request per k16 step, and each request register is
       // re-armed at once with the slab after that.  Past the workgroup's last slab the requests repeat valid addresses (harmless).
       const bool last = slab == kSlabs - 1;
-      long long t2 = slab >= kSlabs - 2 ? tile + gridDim.x : tile;            // tile / slab two slabs ahead
+      long long t2 = slab >= kSlabs - 2 ? tile + tile_stride : tile;          // tile / slab two slabs ahead
       const int s2 = (slab + 2) & (kSlabs - 1);
       if (t2 >= n_tiles) t2 = tile;
       (void)last;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
       sfor<kStepsPerSlab>([&](auto S) {
         constexpr int s = decltype(S)::value;
         const int gstep = slab * kStepsPerSlab + s;
-        bf8 (&wc)[12] = wr[s % R];
+        bf8 (&wc)[NF] = wr[s % R];
         // 12 quarter-groups (row half ct, product term t): one MFMA on each of the four row tiles -- consecutive MFMAs never share an
         // accumulator, and the next step's weights are requested in the first 6 of them (12 fragments, two per group)
         sfor<6 * CT>([&](auto G) {
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
           constexpr int ia = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;          // smallest terms first: (a2 b0) (a0 b2) (a1 b1) (a1 b0) (a0 b1) (a0 b0)
           constexpr int ib = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (g < 6) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, 2 * g, 2);
+          if constexpr (2 * g < NF) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, 2 * g, 2);
           if constexpr (g == (CT == 2 ? 7 : 3) && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
           // staging side task: two of the slab's eight requests per step, steps 4..7 (requested at step 0)
           // // (which four steps makes no measurable difference)
@@ -226,16 +233,16 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
 #endif
           const bf8 b = bb[s & 1][ct][ib];
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) DINER_BF16_MFMA(acc[rt][ct], wc[3 * rt + ia], b);
+          for (int rt = 0; rt < NRT; ++rt) DINER_BF16_MFMA(acc[rt][ct], wc[3 * rt + ia], b);
           if constexpr (s < NQ && (g == (CT == 2 ? 8 : 2) || g == (CT == 2 ? 9 : 3))) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < NRT; ++rt) {
               __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
           }
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) asm volatile("" : "+a"(acc[rt][ct]));
+          for (int rt = 0; rt < NRT; ++rt) asm volatile("" : "+a"(acc[rt][ct]));
         });
       });
       __syncthreads();                                       // slab buffer `buf` is free, the next one is complete
@@ -246,10 +253,10 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
       const long long row = tile * kRows + 32 * ct + (lane & 31);
       if (row >= a.M) continue;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const int f = 128 * wave + 32 * rt + 8 * q4 + 4 * (lane >> 5);
+          const int f = 128 * wslice + 32 * (rt0 + rt) + 8 * q4 + 4 * (lane >> 5);
           f32x4 v;
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = acc[rt][ct][4 * q4 + c];
@@ -289,23 +296,63 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream) {
   DINER_HIP_OK(hipGetDevice(&dev));
   dev &= 63;
   if (!attr_set[dev].load()) {
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
     int cus = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    cu_count[dev].store(cus > 0 ? cus : 256);
+    cu_count[dev].store(cus > 1 ? cus & ~1 : 256);
     attr_set[dev].store(1);
   }
   const int cus = cu_count[dev].load();
-  // tile height: 64 rows unless that leaves fewer than DINER_L512_SMALL (default 4) tiles per CU; DINER_L512_CT = 1 | 2 forces one
+  // one launch of a tile shape over rows [row0, row0 + rows): ct = 32-row halves per tile, fh = workgroups per tile (feature halves)
+  auto launch = [&](long long row0, long long rows, int ct, int fh) {
+    Lin512Args b = a;
+    b.X += (size_t)row0 * a.ldx;
+    b.Y += (size_t)row0 * a.ldy;
+    if (a.resid) b.resid += (size_t)row0 * a.ldy;
+    if (a.mask) b.mask += (size_t)row0 * a.ldy;
+    b.M = rows;
+    const long long units = (rows + 32 * ct - 1) / (32 * ct) * fh;
+    const int grid = (int)(units < cus ? units : cus);
+    if (ct == 2) hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 2, 1>), dim3(grid), dim3(256), kLdsBytes512, stream, b);
+    else if (fh == 2) hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 1, 2>), dim3(grid), dim3(256), kLdsBytes512, stream, b);
+    else hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 1, 1>), dim3(grid), dim3(256), kLdsBytes512, stream, b);
+  };
+  // The plan: rounds of 64-row tiles over all CUs while a whole round is left (a weight fragment feeds twice the MFMAs there), and the
+  // ragged rest in the shape that costs least -- 32-row tiles, or 32-row tiles shared by two workgroups (half the features each).
+  // Costs in units of one round of 32-row tiles, measured on the reference training batch (20480 rows = 2.5 rounds of 32-row tiles: three
+  // rounds as 32-row tiles, 1.85 + 0.55 as one 64-row round + one round of half tiles).  DINER_L512_CT = 1 | 2 forces one shape for
+  // everything, DINER_L512_HALF = 0 keeps the half tiles out of the plan (measurement aids).
   static const int forced = [] { const char* e = getenv("DINER_L512_CT"); return e ? atoi(e) : 0; }();
-  static const int small = [] { const char* e = getenv("DINER_L512_SMALL"); return e ? atoi(e) : 4; }();
-  const long long n64 = (a.M + 63) / 64;
-  const int ct = forced == 1 || forced == 2 ? forced : (n64 < (long long)small * cus ? 1 : 2);
-  const long long n_tiles = (a.M + 32 * ct - 1) / (32 * ct);
-  const int grid = (int)(n_tiles < cus ? n_tiles : cus);
-  if (ct == 2) hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 2>), dim3(grid), dim3(256), kLdsBytes512, stream, a);
-  else hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 1>), dim3(grid), dim3(256), kLdsBytes512, stream, a);
+  static const bool halves = [] { const char* e = getenv("DINER_L512_HALF"); return !(e && *e == '0'); }();
+  if (forced == 1 || forced == 2) {
+    launch(0, a.M, forced, 1);
+    DINER_LAUNCH_OK();
+    return 0;
+  }
+  const double c32 = 1.0, c64 = 1.85, chalf = 0.55, cextra = 0.1;            // cextra: a second launch
+  auto rounds = [&](long long units) { return (double)((units + cus - 1) / cus); };
+  auto rest_cost = [&](long long rows, int* fh) {            // cheapest 32-row shape for `rows` rows
+    const long long t32 = (rows + 31) / 32;
+    const double whole = rounds(t32) * c32, shared = rounds(2 * t32) * chalf;
+    *fh = halves && shared < whole ? 2 : 1;
+    return *fh == 2 ? shared : whole;
+  };
+  const long long round64 = 64ll * cus;
+  const long long main_rows = a.M / round64 * round64, rest = a.M - main_rows;
+  int fh_all = 1, fh_rest = 1;
+  const double all32 = rest_cost(a.M, &fh_all);
+  const double all64 = rounds((a.M + 63) / 64) * c64;
+  const double split = main_rows && rest ? (double)(main_rows / round64) * c64 + rest_cost(rest, &fh_rest) + cextra : 1e30;
+  if (split < all32 && split < all64) {
+    launch(0, main_rows, 2, 1);
+    launch(main_rows, rest, 1, fh_rest);
+  } else if (all64 <= all32) {
+    launch(0, a.M, 2, 1);
+  } else {
+    launch(0, a.M, 1, fh_all);
+  }
   DINER_LAUNCH_OK();
   return 0;
 }

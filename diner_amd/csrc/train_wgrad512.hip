@@ -234,18 +234,25 @@ __global__ __launch_bounds__(256, 1) void k_wgrad512(Wgrad512Args a) {
   }
 }
 
-// dW[i] (+)= sum over the chunks of part[c][i]; db likewise from the partial row sums behind the tiles
-__global__ void k_wgrad512_reduce(const float* __restrict__ part, int n_chunks, int overwrite, float* __restrict__ dW, float* __restrict__ db) {
+// dW[i] (+)= sum over the chunks of part[c][i]; db likewise from the partial row sums behind the tiles.  Four independent running sums:
+// the 32 loads of a thread must not wait for each other (the pass read its 32 MB at 2 TB/s with one)
+__global__ __launch_bounds__(256) void k_wgrad512_reduce(const float* __restrict__ part, int n_chunks, int overwrite, float* __restrict__ dW,
+                                                         float* __restrict__ db) {
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= 512 * 512) return;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 s = overwrite ? zero : *reinterpret_cast<const f32x4*>(dW + i);
-  for (int c = 0; c < n_chunks; ++c) s += *reinterpret_cast<const f32x4*>(part + (size_t)c * 512 * 512 + i);
-  *reinterpret_cast<f32x4*>(dW + i) = s;
+  f32x4 s[4] = {overwrite ? zero : *reinterpret_cast<const f32x4*>(dW + i), zero, zero, zero};
+  int c = 0;
+  for (; c + 4 <= n_chunks; c += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + (size_t)(c + u) * 512 * 512 + i));
+  }
+  for (; c < n_chunks; ++c) s[0] += *reinterpret_cast<const f32x4*>(part + (size_t)c * 512 * 512 + i);
+  *reinterpret_cast<f32x4*>(dW + i) = (s[0] + s[1]) + (s[2] + s[3]);
   if (db && i < 512) {
     const float* pdb = part + (size_t)kWgMaxChunks * 512 * 512;
     f32x4 t = overwrite ? zero : *reinterpret_cast<const f32x4*>(db + i);
-    for (int c = 0; c < n_chunks; ++c) t += *reinterpret_cast<const f32x4*>(pdb + (size_t)c * 512 + i);
+    for (int c2 = 0; c2 < n_chunks; ++c2) t += *reinterpret_cast<const f32x4*>(pdb + (size_t)c2 * 512 + i);
     *reinterpret_cast<f32x4*>(db + i) = t;
   }
 }

@@ -155,7 +155,12 @@ class FieldFunction(torch.autograd.Function):
             d_out = _f32c(d_out)
             _lib.check(lib.diner_field_train_backward_f32(ctx.scene.ref, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out),
                                                           _ptr(ws), _ptr(d_cl), _stream()))
-        return (None, None, None, d_cl.permute(0, 3, 1, 2) if d_cl is not None else None, None) + tuple(grads)
+            d_lat = None
+            if d_cl is not None:             # channels-last -> the encoder's (nv, C, Hf, Wf), contiguous: autograd takes it as it is
+                nv, Cc, Hf, Wf = ctx.latent_shape
+                d_lat = torch.empty(nv, Cc, Hf, Wf, device=d_out.device)
+                _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), nv, Hf * Wf, Cc, _ptr(d_lat), _stream()))
+        return (None, None, None, d_lat, None) + tuple(grads)
 
 
 class CompositeFunction(torch.autograd.Function):

@@ -263,6 +263,10 @@ int diner_field_act_f32(const float* raw, const float* dout, long long P, int ld
 int diner_composite_bwd_f32(const float* field, const float* z, const float* rays, int NR, int K, int white_bkgd,
                             const float* g_rgb, const float* g_depth, float* d_field, void* stream);
 
+/* (n, HW, C) channels-last -> (n, C, HW): the latent gradient of diner_field_train_backward_f32 / diner_scatter_latent_grad_f32 in the
+ * layout of the encoder's feature map (SpatialEncoder.latent, image_encoder.py:82-95), through LDS tiles. */
+int diner_channels_last_to_nchw_f32(const float* src, int n, long long HW, int C, float* dst, void* stream);
+
 /* The whole training forward / backward of the field for one object as one call each (the sequences of the building
  * blocks above that PixelNeRF.forward + ResnetFC.forward and their autograd adjoints amount to; pixelnerf.py:55-145,
  * resnetfc.py:129-159).  `params`: DEVICE parameter tensors in nn.Linear layout (d_in=55, d_latent=d_hidden=512, 5 blocks,

@@ -294,13 +294,13 @@ def test_gradient_reaches_the_image_encoder(ops):
 
 def test_linear512_against_float64():
     """The feature-sliced 512 x 512 training product (csrc/train_lin512.hip) against float64: forward y = relu(x) W^T + b + resid and the
-    data gradient dx = (dy W) * (mask > 0) accumulated onto dx, ragged row counts (1, 63, 65, 1000, 20480: partial tiles, fewer tiles than
-    CUs, several tiles per workgroup), operands spanning 1e-8 .. 1e4 in magnitude (bf16 planes keep fp32's exponent range)."""
+    data gradient dx = (dy W) * (mask > 0) accumulated onto dx, ragged row counts (1, 63, 65, 1000: partial tiles, fewer tiles than CUs;
+    12289: 32-row tiles shared by two workgroups; 20480: one round of 64-row tiles + shared 32-row tiles; 70000: 64-row rounds + 32-row tiles), operands spanning 1e-8 .. 1e4 in magnitude (bf16 planes keep fp32's exponent range)."""
     from diner_amd import train
     g = torch.Generator().manual_seed(3)
     W = (torch.randn(512, 512, generator=g) * 0.05).cuda()
     b = torch.randn(512, generator=g).cuda()
-    for M in (1, 63, 65, 1000, 20480, 70000):
+    for M in (1, 63, 65, 1000, 12289, 20480, 70000):
         x = torch.randn(M, 512, generator=g).cuda() * torch.logspace(-8, 4, 512).cuda()[torch.randperm(512, generator=g).cuda()]
         r = torch.randn(M, 512, generator=g).cuda()
         y = torch.empty(M, 512, device="cuda")
