@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $GRAFT_REPO_ROOT/tools/time_train.py $RAYS > $OUT/plain.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o t -- python $GRAFT_REPO_ROOT/tools/time_train.py $RAYS > $OUT/under_rocprof.txt 2>&1
-python $GRAFT_REPO_ROOT/tools/summarize_rocprof.py $(find $OUT/raw -name "*kernel_stats.csv" | head -1) $OUT/stats.md > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/tools/summarize_rocprof.py $(find $OUT/raw -name "*kernel_stats.csv" | head -1) $OUT/stats.md "python tools/time_train.py $RAYS (11 forward+backward steps)" > /dev/null 2>&1
 python - $(find $OUT/raw -name '*kernel_trace.csv' | head -1) <<'PY' > $OUT/timeline.txt 2>&1
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
