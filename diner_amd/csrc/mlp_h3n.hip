@@ -35,7 +35,13 @@ constexpr size_t kFeatTabBytes = 64 * 16;               // input-feature recipe 
 constexpr size_t kFeatSrcBytes = 256 * kSrcStride * 4;  // per lane: x_c (3), R d (3), dd, 0
 constexpr size_t kLdsBytes = (size_t)kBHalfs * 2 + kTapsBytes + kFeatTabBytes + kFeatSrcBytes;
 static_assert(kLdsBytes <= 160 * 1024, "LDS of one CU");
-constexpr size_t kLdsBytesPost = (size_t)kBHalfs * 2;
+// post kernel: the B buffer + lin_out on the vector ALU: its weights [wave 4][mo 8][q 4][o 4] f32x4 (8 KB) and the per-wave partial
+// outputs [wave 4][g 4][pt 16] f32x4 (4 KB)
+constexpr size_t kLinOutWBytes = 4 * 8 * 4 * 4 * 16, kLinOutPartBytes = 4 * 4 * 16 * 16;
+constexpr size_t kLdsBytesPost = (size_t)kBHalfs * 2 + kLinOutWBytes + kLinOutPartBytes;
+#ifndef DINER_HN_LINOUT_VALU
+#define DINER_HN_LINOUT_VALU 1
+#endif
 
 // LDS operand buffer addressing: a per-lane byte address kept in one register + immediate offsets (the ds offset
 // field holds 16 bits, so the 128 KB buffer is reached from two bases 64 KB apart).  The bases are made opaque at
@@ -834,10 +840,19 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
 struct PostArgsN {
   PostArgs pa;
   const _Float16* w;        // n-split packed fc_0 / fc_1 of blocks 3, 4 (4 layers of 4 * 16 * 16 KB)
-  const _Float16* w_out;    // lin_out fragments [t 16][hl 2][lane 64][8] (rows >= 4 zero), x16
+  const _Float16* w_out;    // lin_out fragments [t 16][hl 2][lane 64][8] (rows >= 4 zero), x16; behind them (32 KB on) the fp32 pack
+                            // [wave 4][mo 8][q 4][o 4][j 4] = Wout[o][128 wave + 16 mo + 4 q + j] / 16 of the vector-ALU lin_out
   unsigned long long* prof; // DINER_HN_PROF builds: phase counters, else unused
   unsigned* tile_counter;   // see TileQueue
 };
+
+// The lane index, opaque to the optimiser: what is derived from it is derived at the point of use.  (Lane-derived values hoisted out
+// of the post kernel's tile loop have to live across GEMMs that use all 512 registers: they come back from scratch.)
+__device__ __forceinline__ int lane_here() {
+  int l = threadIdx.x & 63;
+  asm volatile("" : "+v"(l));
+  return l;
+}
 
 // Blocks 3-4 + lin_out + output activations on the view-averaged hidden state, same feature-sliced scheme: a
 // workgroup takes 64 points (four 16-point tiles = the four column groups), wave w owns features [128 w, 128 w + 128).
@@ -860,6 +875,16 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
   TileQueue tq;
   tq.begin();
   f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
+#if DINER_HN_LINOUT_VALU
+  typedef __attribute__((address_space(3))) f32x4* lds_f4;
+  const lds_f4 lo_w = (lds_f4)((lds_ptr)(reinterpret_cast<char*>(smem)) + (size_t)kBHalfs * 2);
+  const lds_f4 lo_part = (lds_f4)((lds_ptr)(reinterpret_cast<char*>(smem)) + (size_t)kBHalfs * 2 + kLinOutWBytes);
+  {
+    const f32x4* gw = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.w_out) + 32768);
+    for (int i = threadIdx.x; i < (int)(kLinOutWBytes / 16); i += 256) lo_w[i] = gw[i];
+    __syncthreads();
+  }
+#endif
   // The hand-over of a tile (2 KB per point, written by the per-view kernel in accumulator layout) is REQUESTED while the previous
   // tile's lin_out runs, straight into the residual block, which is dead from lin_out's publish on (round 2's attempt at this made the
   // allocator spill the block; with the accumulator accesses pinned it does not).  A tile starts by waiting for it: x16 + block 2's
@@ -869,7 +894,9 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     for (int g = 0; g < kGroups; ++g) {
       long long t16 = t * 4 + g;
       if (t16 >= n_t16) t16 = n_t16 - 1;
-      const f32x4* in = reinterpret_cast<const f32x4*>(pa.xpre) + (size_t)t16 * (kTiles * 64) + lane;
+      const f32x4* xp = reinterpret_cast<const f32x4*>(pa.xpre);
+      asm volatile("" : "+s"(xp));                 // per-tile address arithmetic: hoisted, the 64-bit lane addresses get spilled
+      const f32x4* in = xp + (size_t)t16 * (kTiles * 64) + lane_here();
 #pragma unroll
       for (int mo = 0; mo < kSlice; ++mo) xs[mo][g] = in[(8 * wave + mo) * 64];
     }
@@ -877,10 +904,16 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
   long long tile = blockIdx.x;
   if (tile < n_tiles) request_handover(tile);
   while (tile < n_tiles) {
+    long long tile_next_v = n_tiles;
+    // lane-derived quantities are re-derived per tile from an opaque copy: hoisted out of the tile loop they do not survive the GEMMs in
+    // registers (the kernel uses all 512) and come back from scratch
+    const int q = lane_here() >> 4;
     tq.request(a.tile_counter, n_tiles);
+    const float* bpost = pa.b_post;
+    asm volatile("" : "+s"(bpost));                // (as above)
 #pragma unroll
     for (int mo = 0; mo < kSlice; ++mo) {
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 16 + 128 * wave + 16 * mo + 4 * q);
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(bpost + 4 * kHidden + 16 + 128 * wave + 16 * mo + 4 * q);
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) xs[mo][g] = xs[mo][g] * kScale + b2;
     }
@@ -889,15 +922,105 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     pf.mark(8);
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
-      const float* bias = pa.b_post + 2 * kHidden * b;
+      const float* bias = bpost + 2 * kHidden * b;
       publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
-        set_bias(ns, bias, wave, q);
+        set_bias(ns, bias, wave, lane_here() >> 4);
         pin_acc(xs);                              // the residual stream stays in registers across the fc_0 GEMM
       }, pf, 0);
       pin_acc(xs);
       publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
-                                      [&] { add_bias(xs, bias + kHidden, wave, q); }, pf, 4);
+                                      [&] { add_bias(xs, bias + kHidden, wave, lane_here() >> 4); }, pf, 4);
     }
+#if DINER_HN_LINOUT_VALU
+    pin_acc(xs);                                  // (else the block is copied to vector registers here and back for the reads below)
+    // ---- lin_out on relu(x), fp32 on the vector ALU straight from the accumulators: a lane holds 4 features x 4 columns of each of its 8
+    // row tiles; 512 fused multiply-adds give its share of the four outputs of its four columns, two shuffles sum the four feature
+    // quarters, 4 KB of LDS the four waves.  (Until round 3 the block was published to LDS as fp16 hi / lo like a hidden layer and
+    // multiplied with padded 16 x 16 x 32 MFMAs: 11 k + 8 k clocks per tile, 12 % of the kernel, for 0.4 % of its FLOPs; and an x
+    // beyond the fp16 range -- finite in fp32 -- sent the launch to the exact-fp32 pass for nothing.)
+    tq.offer(&s_tile);
+    f32x4 res;
+    int lane_o = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_o));                 // the section's lane quantities are derived here, not kept alive across the GEMMs
+    const int q_o = lane_o >> 4, pt = lane_o & 15;
+    // Range check of the launch, on the raw bits of the 128 values a lane holds of x (one integer max3 per pair, twice): the largest as
+    // signed integers is the largest positive value (+inf / a NaN with a clear sign bit above all), the largest as unsigned integers is a
+    // NaN with the sign bit set if there is one (then -inf).  An fp16 operand that left the range anywhere in the launch shows here: it
+    // turns the products of its column into NaN / inf of either sign, relu (an integer maximum in every operand conversion) keeps the
+    // positive ones and the next product spreads them to all features of the column, and they stay in the residual stream, which is
+    // only ever added to; a residual value beyond the range (the operands are x / 16: 65504 * 16 here) stays beyond it.  (Until round 3 the test was lin_out's own result being non-finite, which relied on relu letting the NaNs through:
+    // those with the sign bit set became zeros.)
+    bool wave_bad = false;
+    {
+      int m_pos = 0;
+      unsigned m_neg = 0;
+      f32x4 po[kGroups];
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) po[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // the weights of row tile mo + 1 are read while mo is multiplied, no further ahead: left alone the scheduler hoists all 32 reads
+      // (128 registers) and shuffles the sums through the free accumulator registers (1500 instructions for 900)
+      f32x4 wn[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) wn[o] = lo_w[((wave * 8 + 0) * 4 + q_o) * 4 + o];
+#pragma unroll
+      for (int mo = 0; mo < kSlice; ++mo) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 wv[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) wv[o] = wn[o];
+        if (mo + 1 < kSlice) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) wn[o] = lo_w[((wave * 8 + mo + 1) * 4 + q_o) * 4 + o];
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+          float v[4];
+          int xi[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {             // (explicit accumulator reads, see cvt4)
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(xi[jj]) : "a"(xs[mo][g][jj]));
+            v[jj] = __int_as_float(max(xi[jj], 0));
+          }
+          m_pos = max(max(m_pos, xi[0]), xi[1]);
+          m_pos = max(max(m_pos, xi[2]), xi[3]);
+          m_neg = max(max(m_neg, (unsigned)xi[0]), (unsigned)xi[1]);
+          m_neg = max(max(m_neg, (unsigned)xi[2]), (unsigned)xi[3]);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            float t = po[g][o];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) t = fmaf(wv[o][jj], v[jj], t);
+            po[g][o] = t;
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float t = po[g][o];                       // (ds_bpermute by hand: __shfl_xor takes the lane index from mbcnt, hoisted and spilled)
+          t += __int_as_float(__builtin_amdgcn_ds_bpermute((lane_o ^ 16) << 2, __float_as_int(t)));
+          t += __int_as_float(__builtin_amdgcn_ds_bpermute((lane_o ^ 32) << 2, __float_as_int(t)));
+          po[g][o] = t;
+        }
+        if (q_o == 0) lo_part[(wave * kGroups + g) * 16 + pt] = po[g];
+      }
+      // x is held x16: an operand conversion overflows from 65504 * 16 on (0x497fe000); -inf and the sign-bit NaNs from 0xff800000 on
+      wave_bad = __any(m_pos >= 0x497fe000 || m_neg >= 0xff800000u);
+      __syncthreads();
+      const long long tile_nx = tq.take(tile, &s_tile);
+      if (tile_nx < n_tiles) request_handover(tile_nx);
+      pf.mark(9);
+      // wave w finishes column group w (its 16 points): the four waves' shares
+      const lds_f4 lp = lo_part + wave * 16 + pt;
+      res = (lp[0 * kGroups * 16] + lp[1 * kGroups * 16]) + (lp[2 * kGroups * 16] + lp[3 * kGroups * 16]);
+      pf.mark(10);
+      tile_next_v = tile_nx;
+    }
+    {
+#else
+    const int q_o = q, pt = lane & 15;
+    const bool wave_bad = false;
     // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
     // (requesting its 32 weight fragments before the publish moves 4 k clocks from here into the publish and the next tile's
     // hand-over load: measured, no net gain)
@@ -905,8 +1028,8 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     __syncthreads();
     publish<LO>(Bl, wave, lane, xs);
     __syncthreads();
-    const long long tile_next = tq.take(tile, &s_tile);
-    if (tile_next < n_tiles) request_handover(tile_next);
+    tile_next_v = tq.take(tile, &s_tile);
+    if (tile_next_v < n_tiles) request_handover(tile_next_v);
     pf.mark(9);
     {
       typedef const __attribute__((address_space(1))) h8* gh8;
@@ -932,14 +1055,15 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       f32x4 res = ((o[0] + o[1]) + (o[2] + o[3])) * kInvScale;
       asm volatile("" : "+v"(res));
       pf.mark(10);
-      res += *reinterpret_cast<const f32x4*>(pa.b_post + 4 * kHidden + 4 * q);       // lin_out bias kept at scale 1
+#endif
+      res += *reinterpret_cast<const f32x4*>(bpost + 4 * kHidden + 4 * q_o);     // lin_out bias kept at scale 1
       const long long t16 = tile * 4 + wave;
       const long long p = t16 * kPtsPerWave + pt;
-      if (t16 < n_t16 && q == 0 && p < pa.P) {
+      if (t16 < n_t16 && q_o == 0 && p < pa.P) {
         // A hidden activation beyond the fp16 range turns into inf in a B operand and reaches every raw output of the
         // point as inf / NaN (so does a non-finite input): raise the flag that un-gates the exact-fp32 pass (mlp.hip).
         const float probe = (res[0] - res[0]) + (res[1] - res[1]) + (res[2] - res[2]) + (res[3] - res[3]);   // 0 or NaN
-        if (pa.overflow && probe != 0.0f) *pa.overflow = 1;
+        if (pa.overflow && (probe != 0.0f || wave_bad)) *pa.overflow = 1;
         if (!pa.raw) {
           res[0] = 1.0f / (1.0f + expf(-res[0]));
           res[1] = 1.0f / (1.0f + expf(-res[1]));
@@ -950,7 +1074,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       }
     }
     pf.mark(11);
-    tile = tile_next;
+    tile = tile_next_v;
   }
   pf.end(a.prof, lane);
 }
@@ -982,6 +1106,14 @@ __global__ void k_pack_lin_out_h3n(const float* __restrict__ W, int rows, int co
     dst[i] = hl ? (_Float16)(w - (float)h) : h;
   }
 }
+// lin_out for the vector ALU: [wave 4][mo 8][q 4][o 4][j 4] = Wout[o][128 wave + 16 mo + 4 q + j] * scale (the accumulators carry x16)
+__global__ void k_pack_lin_out_valu(const float* __restrict__ W, int rows, int cols, float scale, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2048; i += gridDim.x * blockDim.x) {
+    const int j = i & 3, o = (i >> 2) & 3, q = (i >> 4) & 3, mo = (i >> 6) & 7, w = i >> 9;
+    const int col = 128 * w + 16 * mo + 4 * q + j;
+    dst[i] = (o < rows && col < cols) ? W[(size_t)o * cols + col] * scale : 0.0f;
+  }
+}
 __global__ void k_scale_pad(const float* __restrict__ src, int n, int n_pad, float scale, float* __restrict__ dst) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x)
     dst[i] = i < n ? src[i] * scale : 0.0f;
@@ -995,7 +1127,7 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
   using namespace h3n;
   const size_t halfs = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
   DINER_HIP_OK(hipMalloc(w_out, halfs * sizeof(_Float16)));
-  DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16)));
+  DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16) + kLinOutWBytes));      // MFMA fragments + the fp32 pack of the vector-ALU lin_out
   DINER_HIP_OK(hipMalloc(b_pre, 7 * kHidden * sizeof(float)));
   DINER_HIP_OK(hipMalloc(b_post, (5 * kHidden + 16) * sizeof(float)));
   auto bias = [&](const float* b, int n, int n_pad, float scale, float* dst) {
@@ -1016,6 +1148,8 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
   bias(p->fc1_b[2], kHidden, kHidden, kScale, *b_post + 4 * kHidden + 16);
   hipLaunchKernelGGL(k_pack_lin_out_h3n, dim3(64), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, kScale,
                      (_Float16*)*w_lin_out);
+  hipLaunchKernelGGL(k_pack_lin_out_valu, dim3(8), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, kInvScale,
+                     reinterpret_cast<float*>(reinterpret_cast<char*>(*w_lin_out) + 32768));
   _Float16* wp = (_Float16*)*w_out;
   hipLaunchKernelGGL(k_pack_layer_h3n, dim3(256), dim3(256), 0, stream, p->lin_in_w, kHidden, kDIn, 2, kScale, wp);
   wp += (size_t)4 * 2 * 8192;

@@ -189,12 +189,16 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
         inside = [i for i in packed if 0 < bisect.bisect(idx, i) < len(idx)
                   and i - idx[bisect.bisect(idx, i) - 1] < 30 and idx[bisect.bisect(idx, i)] - i < 30]
         assert len(inside) <= 16, f"{m.group(1)}: {len(inside)} packed-fp32 instructions inside MFMA streams (round 2c start: ~450)"
-    # the post kernel (blocks 3-4 + lin_out) has no front end: no scratch at all, and its MFMAs stay interleaved with
-    # the operand loads (an optimiser that sinks the accumulation chains below the loads shows up as spills)
+    # the post kernel (blocks 3-4 + lin_out on the vector ALU): no scratch between its first and last MFMA (an optimiser that sinks the
+    # accumulation chains below the operand loads shows up as spills there).  It uses all 512 registers inside the GEMMs, so the tile
+    # queue's thread-0 state (the next tile, requested at the top of a tile and handed over at the bottom) crosses them through scratch:
+    # a handful of accesses per tile, outside the MFMA span
     for m in post:
         body = m.group(2).split("\n")
-        assert sum("v_mfma" in l for l in body) > 1000
-        assert not [l for l in body if "scratch_" in l], m.group(1)
+        idx = [i for i, l in enumerate(body) if "v_mfma" in l]
+        assert len(idx) > 1000
+        assert not [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l], m.group(1)
+        assert len([l for l in body if "scratch_" in l]) <= 16, m.group(1)
 
 
 def test_bench_line_contract():

@@ -402,6 +402,17 @@ def test_fp16_overflow_falls_back_to_exact_kernels(ops):
     # the fall-back is visible: the handle counts the launches the exact kernels had to recompute
     assert hm.fallback_launches() == 2 and hm2.fallback_launches() == 0
     assert hm.fallback_launches(reset=True) == 2 and hm.fallback_launches() == 0
+    # a HIDDEN activation beyond the range (the residual stream stays small): in the per-view blocks, in the post blocks.  The operand
+    # that overflows turns its column's products into NaN / inf of either sign; the range check reads the bits of the residual stream in
+    # front of lin_out, whatever the signs (until round 3 only NaNs with a clear sign bit got through relu to the check)
+    for key, mag in (("blocks.1.fc_0.bias", 1.0e5), ("blocks.3.fc_0.bias", 1.0e5), ("blocks.4.fc_0.bias", 3.0e5)):
+        hid = {k: v.clone() for k, v in msd.items()}
+        hid[key] = hid[key] + mag * (torch.arange(512) % 7 == 0)
+        hh = hip_mlp(ops, hid)
+        exact = ops.field_from_points(hs, hh, pts, dirs, precision="fp32")
+        for mode in ("f16x3", "f16"):
+            assert torch.equal(ops.field_from_points(hs, hh, pts, dirs, precision=mode), exact), (key, mode)
+        assert hh.fallback_launches() == 2, key
 
 
 def test_scene_prepared_with_another_handle_is_refused(ops):
