@@ -1034,7 +1034,7 @@ TrainWs train_ws(long long P, int nv) {
   w.dH = take(cols * kHidden);
   w.d_lat = take(cols * kLatent);
   w.wpack = take(kWPackSlots * (kL512PackBytes / sizeof(float)));      // packed 512 x 512 weights of train_lin512.hip
-  w.wgpart = take(wgrad512_part_bytes() / sizeof(float));          // per-chunk partial weight gradients (train_wgrad512.hip)
+  w.wgpart = take(13 * (wgrad512_part_bytes() / sizeof(float)));     // per-chunk partial weight gradients of the 13 512 x 512 layers (train_wgrad512.hip)
   w.total = o;
   return w;
 }
@@ -1062,7 +1062,7 @@ void* wpack_slot(float* ws, const TrainWs& w, int slot, bool transposed) {
 // adjoint of y = act(x) W^T + b: dW = dy^T act(x) (split-K atomics into zeroed dW), db = column sums, dx (+)= (dy W) [masked]
 int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, const float* W, float* dW, float* db,
                long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st,
-               const void* Wt_packed = nullptr, float* wgpart = nullptr) {
+               const void* Wt_packed = nullptr, float* wgpart = nullptr, WgReduceJob* defer = nullptr) {
   // split-K so that the 16 output tiles of a 512 x 512 weight gradient become 500-1000 workgroups of >= 15 k-tiles each (measured:
   // 128 / 512 / 2048-ray steps 5.70 / 15.6 / 53.1 ms with M / 1024 capped at 32, 5.07 / 14.5 / 51.8 ms with M / 480 capped at 64);
   // round 3: M / 640 -- the row-sum instance of the kernel runs two workgroups per CU, 16 tiles x 32 chunks fill the chip once for the
@@ -1080,7 +1080,7 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
       DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
       DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
     }
-    int rcw = wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, wgpart != nullptr);
+    int rcw = wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, wgpart != nullptr, wgpart ? defer : nullptr);
     if (rcw) return rcw;
     if (dx && Wt_packed && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask)) {
       Lin512Args a{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
@@ -1187,6 +1187,15 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   const long long cols = P * scene->nv;
   float* dx = ws + w.dx;
   float* dH = ws + w.dH;
+  // weight gradients of the 512 x 512 layers: every layer keeps its partial tiles in its own slot, one launch sums them all at the end
+  WgReduceJobs jobs;
+  int n_jobs = 0;
+  const size_t part_floats = wgrad512_part_bytes() / sizeof(float);
+  auto part = [&](int slot) { return ws + w.wgpart + (size_t)slot * part_floats; };
+  auto job = [&]() -> WgReduceJob* {
+    jobs.job[n_jobs] = WgReduceJob{nullptr, nullptr, nullptr, 0};
+    return &jobs.job[n_jobs++];
+  };
   auto wt = [&](const float*, int slot) -> const void* {      // W packed transposed by the forward call of the step (k_lin512), or null
     return use_lin512() ? wpack_slot(ws, w, slot, true) : nullptr;
   };
@@ -1205,12 +1214,12 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
     const float* X = ws + w.X[b];
     const float* H = ws + w.H[b];
     if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
-                         kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b), ws + w.wgpart))) return rc;
+                         kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job()))) return rc;
     if ((rc = linear_bwd(dH, kHidden, X, kHidden, true, p->fc0_w[b], (float*)grads->fc0_w[b], (float*)grads->fc0_b[b], M,
-                         kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b), ws + w.wgpart))) return rc;
+                         kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b), part(kSlotFc0 + b), job()))) return rc;
     if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
                                   (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st,
-                                  wt(p->lin_z_w[b], kSlotLinZ + b), ws + w.wgpart))) return rc;
+                                  wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job()))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
       hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P * kHidden)), dim3(256), 0, st, dx, scene->nv, P * kHidden, dH);
       float* t = dx; dx = dH; dH = t;
@@ -1218,6 +1227,12 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   }
   if ((rc = linear_bwd(dx, kHidden, ws + w.feat, kDInPad, false, p->lin_in_w, (float*)grads->lin_in_w,
                        (float*)grads->lin_in_b, cols, kHidden, kDIn, nullptr, nullptr, false, st))) return rc;
+  {   // (a job the general kernel served -- fewer than 256 rows, odd strides -- stays empty: dropped)
+    int n = 0;
+    for (int i = 0; i < n_jobs; ++i)
+      if (jobs.job[i].part) jobs.job[n++] = jobs.job[i];
+    if ((rc = wgrad512_reduce_many(jobs, n, true, st))) return rc;
+  }
   if (d_latent_cl) {
     DINER_HIP_OK(hipMemsetAsync(d_latent_cl, 0, (size_t)scene->nv * scene->Hf * scene->Wf * kLatent * sizeof(float), st));
     if ((rc = scatter_latent_launch(ws + w.d_lat, (const int*)(ws + w.tap_row), ws + w.tap_w, cols, d_latent_cl, st))) return rc;

@@ -29,8 +29,12 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream);
 // train_wgrad512.hip: dW (512, 512) += dY^T act(X), db (512, or null) += column sums of dY over M rows.  part = null: atomics into dW / db
 // (both zeroed by the caller); part = wgrad512_part_bytes() of scratch: per-chunk partial tiles + one summing pass, which overwrites
 // dW / db instead of adding to them when overwrite is set
+// defer: with `part`, leave the summing pass to the caller -- *defer describes it; wgrad512_reduce_many runs up to 13 of them in one launch
+struct WgReduceJob { const float* part; float* dW; float* db; int n_chunks; };
+struct WgReduceJobs { WgReduceJob job[13]; };
 int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
-                    hipStream_t stream, float* part = nullptr, bool overwrite = false);
+                    hipStream_t stream, float* part = nullptr, bool overwrite = false, WgReduceJob* defer = nullptr);
+int wgrad512_reduce_many(const WgReduceJobs& jobs, int n, bool overwrite, hipStream_t stream);
 size_t wgrad512_part_bytes();
 
 }  // namespace train

@@ -257,14 +257,45 @@ __global__ __launch_bounds__(256) void k_wgrad512_reduce(const float* __restrict
   }
 }
 
+// the same for up to 13 layers in one launch (blockIdx.y = layer): the training step sums the partial tiles of all its 512 x 512 layers at
+// the end of the backward instead of behind every product (13 launches of 13 us and their serialisation points -> one)
+__global__ __launch_bounds__(256) void k_wgrad512_reduce_many(WgReduceJobs jobs, int overwrite) {
+  const WgReduceJob j = jobs.job[blockIdx.y];
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= 512 * 512) return;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s[4] = {overwrite ? zero : *reinterpret_cast<const f32x4*>(j.dW + i), zero, zero, zero};
+  int c = 0;
+  for (; c + 4 <= j.n_chunks; c += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(j.part + (size_t)(c + u) * 512 * 512 + i));
+  }
+  for (; c < j.n_chunks; ++c) s[0] += *reinterpret_cast<const f32x4*>(j.part + (size_t)c * 512 * 512 + i);
+  *reinterpret_cast<f32x4*>(j.dW + i) = (s[0] + s[1]) + (s[2] + s[3]);
+  if (j.db && i < 512) {
+    const float* pdb = j.part + (size_t)kWgMaxChunks * 512 * 512;
+    f32x4 t = overwrite ? zero : *reinterpret_cast<const f32x4*>(j.db + i);
+    for (int c2 = 0; c2 < j.n_chunks; ++c2) t += *reinterpret_cast<const f32x4*>(pdb + (size_t)c2 * 512 + i);
+    *reinterpret_cast<f32x4*>(j.db + i) = t;
+  }
+}
+
+int wgrad512_reduce_many(const WgReduceJobs& jobs, int n, bool overwrite, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_wgrad512_reduce_many, dim3(256, n), dim3(256), 0, stream, jobs, overwrite ? 1 : 0);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
 size_t wgrad512_part_bytes() { return (size_t)kWgMaxChunks * (512 * 512 + 512) * sizeof(float); }
 
 // dW (512, 512) += dY^T act(X), db (512) += column sums of dY, over M rows; dW / db zeroed by the caller.  part: null (atomics into dW) or
 // wgrad512_part_bytes() of scratch (partial tiles stored per chunk + one reduction pass); with it overwrite = true makes dW / db plain
 // outputs (no zeroing by the caller).
 int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
-                    hipStream_t stream, float* part, bool overwrite) {
+                    hipStream_t stream, float* part, bool overwrite, WgReduceJob* defer) {
   DINER_CHECK_ARG(part || !overwrite, "wgrad512: overwrite needs the scratch buffer");
+  DINER_CHECK_ARG(part || !defer, "wgrad512: a deferred summing pass needs the scratch buffer");
   static std::atomic<int> attr_set[64];
   int dev = 0;
   DINER_HIP_OK(hipGetDevice(&dev));
@@ -286,7 +317,8 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
   if (part) {
     // chunks that start past M wrote nothing: only the chunks with rows are summed
     const int used = (int)((M + rows - 1) / rows);
-    hipLaunchKernelGGL(k_wgrad512_reduce, dim3(256), dim3(256), 0, stream, part, used, overwrite ? 1 : 0, dW, db);
+    if (defer) *defer = WgReduceJob{part, dW, db, used};        // the caller sums (wgrad512_reduce_many)
+    else hipLaunchKernelGGL(k_wgrad512_reduce, dim3(256), dim3(256), 0, stream, part, used, overwrite ? 1 : 0, dW, db);
   }
   DINER_LAUNCH_OK();
   return 0;
