@@ -185,6 +185,14 @@ struct TileQueue {
     if (threadIdx.x == 0) *slot = nxt;
 #endif
   }
+  // park(): thread 0 puts the answer into an LDS slot as soon as it has surely arrived (the caller places this behind its first GEMM); the
+  // others may read it behind any later barrier, without one of their own.  The caller alternates between two slots: a slot is rewritten
+  // two tiles later, behind many barriers.
+  __device__ __forceinline__ void park(unsigned* slot) {
+#if DINER_HN_DYN
+    if (threadIdx.x == 0) *slot = nxt;
+#endif
+  }
   __device__ __forceinline__ long long take(long long tile, const unsigned* slot) {
 #if DINER_HN_DYN
     const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)*slot);
@@ -871,7 +879,8 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
 
   Prof pf;
   pf.begin();
-  __shared__ unsigned s_tile;
+  __shared__ unsigned s_tile2[2];
+  int par = 0;                                    // slot of the current tile's answer (TileQueue::park)
   TileQueue tq;
   tq.begin();
   f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
@@ -927,6 +936,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
         set_bias(ns, bias, wave, lane_here() >> 4);
         pin_acc(xs);                              // the residual stream stays in registers across the fc_0 GEMM
       }, pf, 0);
+      if (b == 0) tq.park(&s_tile2[par]);           // (the request went out at the top of the tile)
       pin_acc(xs);
       publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
                                       [&] { add_bias(xs, bias + kHidden, wave, lane_here() >> 4); }, pf, 4);
@@ -938,7 +948,6 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     // quarters, 4 KB of LDS the four waves.  (Until round 3 the block was published to LDS as fp16 hi / lo like a hidden layer and
     // multiplied with padded 16 x 16 x 32 MFMAs: 11 k + 8 k clocks per tile, 12 % of the kernel, for 0.4 % of its FLOPs; and an x
     // beyond the fp16 range -- finite in fp32 -- sent the launch to the exact-fp32 pass for nothing.)
-    tq.offer(&s_tile);
     f32x4 res;
     int lane_o = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_o));                 // the section's lane quantities are derived here, not kept alive across the GEMMs
@@ -994,6 +1003,10 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
           }
         }
       }
+      // x is dead from here on: the next tile's hand-over is requested now (its index was parked in LDS behind the first GEMM), ahead of
+      // the sums over lanes and waves and of the barrier, whose wait the loads then fill (the top of a tile waited 5.7 k clocks for them)
+      const long long tile_nx = tq.take(tile, &s_tile2[par]);
+      if (tile_nx < n_tiles) request_handover(tile_nx);
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
 #pragma unroll
@@ -1008,8 +1021,6 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       // x is held x16: an operand conversion overflows from 65504 * 16 on (0x497fe000); -inf and the sign-bit NaNs from 0xff800000 on
       wave_bad = __any(m_pos >= 0x497fe000 || m_neg >= 0xff800000u);
       __syncthreads();
-      const long long tile_nx = tq.take(tile, &s_tile);
-      if (tile_nx < n_tiles) request_handover(tile_nx);
       pf.mark(9);
       // wave w finishes column group w (its 16 points): the four waves' shares
       const lds_f4 lp = lo_part + wave * 16 + pt;
@@ -1024,11 +1035,10 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     // ---- lin_out on relu(x): wave w produces the four outputs of column group w (its 16 points)
     // (requesting its 32 weight fragments before the publish moves 4 k clocks from here into the publish and the next tile's
     // hand-over load: measured, no net gain)
-    tq.offer(&s_tile);
     __syncthreads();
     publish<LO>(Bl, wave, lane, xs);
     __syncthreads();
-    tile_next_v = tq.take(tile, &s_tile);
+    tile_next_v = tq.take(tile, &s_tile2[par]);
     if (tile_next_v < n_tiles) request_handover(tile_next_v);
     pf.mark(9);
     {
@@ -1075,6 +1085,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     }
     pf.mark(11);
     tile = tile_next_v;
+    par ^= 1;
   }
   pf.end(a.prof, lane);
 }
