@@ -90,8 +90,9 @@ __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base) {
 // for 1.25 rounds of work; 640 tiles of 32 balance better although a tile then feeds each weight fragment half as many MFMAs)
 // FH: feature halves -- 1: a workgroup computes all 512 features of its rows; 2: workgroup pairs share a tile, each computes 256 features
 // (wave w: 64 features = 2 MFMA row tiles) -- half-cost units for the ragged last round of a small M (lin512_launch)
+// (bid, nblk: the workgroup's index and count within its launch part -- k_lin512_plan runs two shapes in one launch)
 template <int R, int CT, int FH>
-__global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
+__device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, const int nblk) {
   constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * 3, NQ = 4 * CT;      // NQ: staging requests per wave and slab
   constexpr int NRT = 4 / FH, NF = 3 * NRT;                  // MFMA row (= feature) tiles per wave, weight fragments per k16 step
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   };
   // ---- weights: wave-private stream, NF fragments (NRT row tiles x 3 planes) per k16 step out of the 12 of the packed wave slice
   typedef const __attribute__((address_space(1))) char* gptr;
-  const int half = FH == 2 ? (int)(blockIdx.x & 1) : 0;
+  const int half = FH == 2 ? (bid & 1) : 0;
   const int wslice = FH == 2 ? 2 * half + (wave >> 1) : wave;                // 128-feature slice of the packed weights
   const int rt0 = FH == 2 ? 2 * (wave & 1) : 0;                              // first of this wave's row tiles inside the slice
   const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + ((size_t)wslice * 32 * 12 + 3 * rt0) * 1024;
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
     for (int i = first; i < first + count; ++i) dst[i] = *(const __attribute__((address_space(1))) bf8*)(p + woff + i * 1024);
   };
 
-  long long tile = blockIdx.x / FH;
-  const int tile_stride = gridDim.x / FH;
+  long long tile = bid / FH;
+  const int tile_stride = nblk / FH;
   if (tile >= n_tiles) return;
   // prologue: slab 0 of the first tile
   request_slab(tile, 0);
@@ -276,6 +277,20 @@ __global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
   }
 }
 
+template <int R, int CT, int FH>
+__global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
+  lin512_body<R, CT, FH>(a, blockIdx.x, gridDim.x);
+}
+// One launch, two shapes: workgroups [0, n_main) run 64-row tiles over `main`, the rest the ragged remainder `rest` as 32-row tiles, whole
+// (TFH = 1) or shared by two workgroups (TFH = 2).  The hardware hands out workgroups in index order, one per CU: a remainder workgroup
+// starts on whichever CU finishes its 64-row share first -- no kernel boundary (drain, launch, ramp: ~5 us of the reference batch's 79)
+// between the two parts.
+template <int R, int TFH>
+__global__ __launch_bounds__(256, 1) void k_lin512_plan(Lin512Args main, Lin512Args rest, int n_main) {
+  if ((int)blockIdx.x < n_main) lin512_body<R, 2, 1>(main, blockIdx.x, n_main);
+  else lin512_body<R, 1, TFH>(rest, blockIdx.x - n_main, gridDim.x - n_main);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
   hipLaunchKernelGGL(k_pack_w512, dim3(128), dim3(256), 0, stream, W, transpose, (__bf16*)dst);
@@ -299,6 +314,8 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512_plan<DINER_L512_RING, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512_plan<DINER_L512_RING, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
     int cus = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(cus > 1 ? cus & ~1 : 256);
@@ -306,13 +323,17 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream) {
   }
   const int cus = cu_count[dev].load();
   // one launch of a tile shape over rows [row0, row0 + rows): ct = 32-row halves per tile, fh = workgroups per tile (feature halves)
-  auto launch = [&](long long row0, long long rows, int ct, int fh) {
+  auto part = [&](long long row0, long long rows) {
     Lin512Args b = a;
     b.X += (size_t)row0 * a.ldx;
     b.Y += (size_t)row0 * a.ldy;
     if (a.resid) b.resid += (size_t)row0 * a.ldy;
     if (a.mask) b.mask += (size_t)row0 * a.ldy;
     b.M = rows;
+    return b;
+  };
+  auto launch = [&](long long row0, long long rows, int ct, int fh) {
+    const Lin512Args b = part(row0, rows);
     const long long units = (rows + 32 * ct - 1) / (32 * ct) * fh;
     const int grid = (int)(units < cus ? units : cus);
     if (ct == 2) hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 2, 1>), dim3(grid), dim3(256), kLdsBytes512, stream, b);
@@ -345,9 +366,21 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream) {
   const double all32 = rest_cost(a.M, &fh_all);
   const double all64 = rounds((a.M + 63) / 64) * c64;
   const double split = main_rows && rest ? (double)(main_rows / round64) * c64 + rest_cost(rest, &fh_rest) + cextra : 1e30;
+  static const bool fused = [] { const char* e = getenv("DINER_L512_FUSED"); return !(e && *e == '0'); }();      // 0: the two shapes as two launches
   if (split < all32 && split < all64) {
-    launch(0, main_rows, 2, 1);
-    launch(main_rows, rest, 1, fh_rest);
+    if (fused) {
+      const Lin512Args bm = part(0, main_rows), br = part(main_rows, rest);
+      const long long n_main = main_rows / 64 < cus ? main_rows / 64 : cus;
+      const long long units = (rest + 31) / 32 * fh_rest;
+      const int n_rest = (int)(units < cus ? units : cus);
+      if (fh_rest == 2)
+        hipLaunchKernelGGL((k_lin512_plan<DINER_L512_RING, 2>), dim3((int)n_main + n_rest), dim3(256), kLdsBytes512, stream, bm, br, (int)n_main);
+      else
+        hipLaunchKernelGGL((k_lin512_plan<DINER_L512_RING, 1>), dim3((int)n_main + n_rest), dim3(256), kLdsBytes512, stream, bm, br, (int)n_main);
+    } else {
+      launch(0, main_rows, 2, 1);
+      launch(main_rows, rest, 1, fh_rest);
+    }
   } else if (all64 <= all32) {
     launch(0, a.M, 2, 1);
   } else {
