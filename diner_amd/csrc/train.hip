@@ -1080,12 +1080,14 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
       DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
       DINER_HIP_OK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
     }
-    int rcw = wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, wgpart != nullptr, wgpart ? defer : nullptr);
+    // the data gradient of the layer rides in the same launch (train_512.hip): dx = dy W on k_lin512's bodies, W packed transposed
+    static const bool one_launch = [] { const char* e = getenv("DINER_TRAIN_BWD_FUSED"); return !(e && *e == '0'); }();
+    const bool dgrad512 = dx && Wt_packed && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask);
+    const Lin512Args da{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+    int rcw = wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, wgpart != nullptr, wgpart ? defer : nullptr,
+                              dgrad512 && one_launch ? &da : nullptr);
     if (rcw) return rcw;
-    if (dx && Wt_packed && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask)) {
-      Lin512Args a{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
-      return lin512_launch(a, st);
-    }
+    if (dgrad512) return one_launch ? 0 : lin512_launch(da, st);
     if (dx) return gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
     return 0;
   }

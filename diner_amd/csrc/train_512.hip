@@ -1,0 +1,163 @@
+// Training path: the kernel entry point and the launchers of the 512 x 512 layer products.  The workgroup bodies live in
+// train_lin512.hip (forward / data gradient, three tile shapes) and train_wgrad512.hip (weight / bias gradient), included here: ONE
+// kernel runs up to three independent parts -- workgroups [0, n0) the first row range of a product in its shape, [n0, n0 + n1) the
+// second, the rest the weight-gradient product of the same layer.  The hardware hands out workgroups in index order, one per CU (LDS and
+// registers admit no second one), so a part starts on whichever CU finishes the one before first: no kernel boundary (drain, launch,
+// ramp: ~5 us, of a 75 us product at the reference training batch) between the shapes of a launch plan, nor between the data- and the
+// weight-gradient product of a layer, and the ragged ends of one part are filled by the next (a 5120-row data gradient occupies 160
+// CUs: the weight gradient's workgroups take the other 96 at once).
+#include "train_lin512.hip"
+#include "train_wgrad512.hip"
+
+namespace diner {
+namespace train {
+
+enum : int { kShape64 = 0, kShape32 = 1, kShape32Shared = 2 };      // 64-row tiles; 32-row tiles; 32-row tiles shared by two workgroups
+struct Run512 {
+  Lin512Args part[2];
+  int n[2];              // workgroups of the two parts (0: absent)
+  int shape[2];
+  Wgrad512Args wg;       // weight-gradient part: the remaining workgroups of the grid (none: grid = n[0] + n[1])
+};
+
+__device__ __forceinline__ void lin512_part(const Lin512Args& a, int shape, int bid, int nblk) {
+  if (shape == kShape64) lin512_body<DINER_L512_RING, 2, 1>(a, bid, nblk);
+  else if (shape == kShape32) lin512_body<DINER_L512_RING, 1, 1>(a, bid, nblk);
+  else lin512_body<DINER_L512_RING, 1, 2>(a, bid, nblk);
+}
+
+__global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
+  int b = blockIdx.x;
+  if (b < r.n[0]) return lin512_part(r.part[0], r.shape[0], b, r.n[0]);
+  b -= r.n[0];
+  if (b < r.n[1]) return lin512_part(r.part[1], r.shape[1], b, r.n[1]);
+  wgrad512_body(r.wg, b - r.n[1]);
+}
+
+namespace {
+constexpr size_t kLdsBytesRun = kLdsBytesWgrad > kLdsBytes512 ? kLdsBytesWgrad : kLdsBytes512;
+int device_cus(int* cus) {                                   // per device: dynamic LDS size of the kernel, CU count
+  static std::atomic<int> attr_set[64];
+  static std::atomic<int> cu_count[64];
+  int dev = 0;
+  DINER_HIP_OK(hipGetDevice(&dev));
+  dev &= 63;
+  if (!attr_set[dev].load()) {
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
+    int c = 0;
+    DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+    cu_count[dev].store(c > 1 ? c & ~1 : 256);
+    attr_set[dev].store(1);
+  }
+  *cus = cu_count[dev].load();
+  return 0;
+}
+
+// The plan of a forward / data-gradient product: rounds of 64-row tiles over all CUs while a whole round is left (a weight fragment feeds
+// twice the MFMAs there), and the ragged rest in the shape that costs least -- 32-row tiles, or 32-row tiles shared by two workgroups
+// (half the features each).  Costs in units of one round of 32-row tiles, measured on the reference training batch (20480 rows = 2.5
+// rounds of 32-row tiles: three rounds as 32-row tiles, 1.85 + 0.55 as one 64-row round + one round of shared tiles).
+// DINER_L512_CT = 1 | 2 forces one shape for everything, DINER_L512_HALF = 0 keeps the shared tiles out (measurement aids).
+void plan_lin512(const Lin512Args& a, int cus, Run512* r) {
+  auto part = [&](long long row0, long long rows) {
+    Lin512Args b = a;
+    b.X += (size_t)row0 * a.ldx;
+    b.Y += (size_t)row0 * a.ldy;
+    if (a.resid) b.resid += (size_t)row0 * a.ldy;
+    if (a.mask) b.mask += (size_t)row0 * a.ldy;
+    b.M = rows;
+    return b;
+  };
+  auto set = [&](int i, long long row0, long long rows, int shape) {
+    r->part[i] = part(row0, rows);
+    r->shape[i] = shape;
+    const long long units = shape == kShape64 ? (rows + 63) / 64 : (rows + 31) / 32 * (shape == kShape32Shared ? 2 : 1);
+    r->n[i] = (int)(units < cus ? units : cus);
+  };
+  r->n[0] = r->n[1] = 0;
+  r->part[1] = a;
+  r->shape[1] = kShape32;
+  static const int forced = [] { const char* e = getenv("DINER_L512_CT"); return e ? atoi(e) : 0; }();
+  static const bool halves = [] { const char* e = getenv("DINER_L512_HALF"); return !(e && *e == '0'); }();
+  if (forced == 1 || forced == 2) return set(0, 0, a.M, forced == 2 ? kShape64 : kShape32);
+  const double c32 = 1.0, c64 = 1.85, chalf = 0.55;
+  auto rounds = [&](long long units) { return (double)((units + cus - 1) / cus); };
+  auto rest_cost = [&](long long rows, int* shape) {         // cheapest 32-row shape for `rows` rows
+    const long long t32 = (rows + 31) / 32;
+    const double whole = rounds(t32) * c32, shared = rounds(2 * t32) * chalf;
+    *shape = halves && shared < whole ? kShape32Shared : kShape32;
+    return *shape == kShape32Shared ? shared : whole;
+  };
+  const long long round64 = 64ll * cus;
+  const long long main_rows = a.M / round64 * round64, rest = a.M - main_rows;
+  int shape_all = kShape32, shape_rest = kShape32;
+  const double all32 = rest_cost(a.M, &shape_all);
+  const double all64 = rounds((a.M + 63) / 64) * c64;
+  const double split = main_rows && rest ? (double)(main_rows / round64) * c64 + rest_cost(rest, &shape_rest) : 1e30;
+  if (split < all32 && split < all64) {
+    set(0, 0, main_rows, kShape64);
+    set(1, main_rows, rest, shape_rest);
+  } else if (all64 <= all32) {
+    set(0, 0, a.M, kShape64);
+  } else {
+    set(0, 0, a.M, shape_all);
+  }
+}
+
+// The weight-gradient part: row chunks -- 32 (8 tiles x 32 = 256 workgroups) unless a chunk would be shorter than 4 slabs; returns its
+// workgroups and the chunks that have rows (the ones the summing pass reads)
+int plan_wgrad512(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M, float* part,
+                  Wgrad512Args* a, int* used) {
+  long long n_chunks = kWgMaxChunks;
+  while (n_chunks > 1 && (M + n_chunks - 1) / n_chunks < 128) n_chunks >>= 1;
+  long long rows = (M + n_chunks - 1) / n_chunks;
+  rows = (rows + 31) / 32 * 32;
+  *a = Wgrad512Args{dY, X, dW, db, part, M, ldy, ldx, relu_x ? 1 : 0, (int)n_chunks, rows};
+  *used = (int)((M + rows - 1) / rows);
+  return 8 * (int)(n_chunks <= 8 ? 8 : n_chunks);             // the block -> (tile, chunk) map needs whole groups of 8 chunks
+}
+}  // namespace
+
+int lin512_launch(const Lin512Args& a, hipStream_t stream) {
+  int cus = 0;
+  int rc = device_cus(&cus);
+  if (rc) return rc;
+  Run512 r;
+  plan_lin512(a, cus, &r);
+  memset(&r.wg, 0, sizeof(r.wg));
+  hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+// dW (512, 512) += dY^T act(X), db (512) += column sums of dY, over M rows; dW / db zeroed by the caller.  part: null (atomics into dW) or
+// wgrad512_part_bytes() of scratch (partial tiles stored per chunk + one reduction pass); with it overwrite = true makes dW / db plain
+// outputs (no zeroing by the caller).  dgrad: the data-gradient product of the same layer, run by the same launch (or null).
+int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
+                    hipStream_t stream, float* part, bool overwrite, WgReduceJob* defer, const Lin512Args* dgrad) {
+  DINER_CHECK_ARG(part || !overwrite, "wgrad512: overwrite needs the scratch buffer");
+  DINER_CHECK_ARG(part || !defer, "wgrad512: a deferred summing pass needs the scratch buffer");
+  int cus = 0;
+  int rc = device_cus(&cus);
+  if (rc) return rc;
+  Run512 r;
+  r.n[0] = r.n[1] = 0;
+  if (dgrad) plan_lin512(*dgrad, cus, &r);
+  else {
+    memset(r.part, 0, sizeof(r.part));
+    r.shape[0] = r.shape[1] = kShape32;
+  }
+  int used = 0;
+  const int n_wg = plan_wgrad512(dY, ldy, X, ldx, relu_x, dW, db, M, part, &r.wg, &used);
+  hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1] + n_wg), dim3(256), kLdsBytesRun, stream, r);
+  if (part) {
+    // chunks that start past M wrote nothing: only the chunks with rows are summed
+    if (defer) *defer = WgReduceJob{part, dW, db, used};      // the caller sums (wgrad512_reduce_many)
+    else hipLaunchKernelGGL(k_wgrad512_reduce, dim3(256), dim3(256), 0, stream, part, used, overwrite ? 1 : 0, dW, db);
+  }
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace train
+}  // namespace diner

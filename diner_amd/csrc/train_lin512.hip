@@ -20,6 +20,7 @@
 #include <utility>
 #include "field_common.hpp"
 #include "train_lin512.hpp"
+// (compiled as part of train_512.hip, which holds the kernel entry points and the launchers)
 
 namespace diner {
 namespace train {
@@ -277,20 +278,6 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   }
 }
 
-template <int R, int CT, int FH>
-__global__ __launch_bounds__(256, 1) void k_lin512(Lin512Args a) {
-  lin512_body<R, CT, FH>(a, blockIdx.x, gridDim.x);
-}
-// One launch, two shapes: workgroups [0, n_main) run 64-row tiles over `main`, the rest the ragged remainder `rest` as 32-row tiles, whole
-// (TFH = 1) or shared by two workgroups (TFH = 2).  The hardware hands out workgroups in index order, one per CU: a remainder workgroup
-// starts on whichever CU finishes its 64-row share first -- no kernel boundary (drain, launch, ramp: ~5 us of the reference batch's 79)
-// between the two parts.
-template <int R, int TFH>
-__global__ __launch_bounds__(256, 1) void k_lin512_plan(Lin512Args main, Lin512Args rest, int n_main) {
-  if ((int)blockIdx.x < n_main) lin512_body<R, 2, 1>(main, blockIdx.x, n_main);
-  else lin512_body<R, 1, TFH>(rest, blockIdx.x - n_main, gridDim.x - n_main);
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
   hipLaunchKernelGGL(k_pack_w512, dim3(128), dim3(256), 0, stream, W, transpose, (__bf16*)dst);
@@ -300,92 +287,6 @@ int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
 
 int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream) {
   hipLaunchKernelGGL(k_pack_w512_many, dim3(128, n, 2), dim3(256), 0, stream, w, (char*)base);
-  DINER_LAUNCH_OK();
-  return 0;
-}
-
-int lin512_launch(const Lin512Args& a, hipStream_t stream) {
-  static std::atomic<int> attr_set[64];                      // per device: dynamic LDS size of the kernels, CU count
-  static std::atomic<int> cu_count[64];
-  int dev = 0;
-  DINER_HIP_OK(hipGetDevice(&dev));
-  dev &= 63;
-  if (!attr_set[dev].load()) {
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512<DINER_L512_RING, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512_plan<DINER_L512_RING, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512_plan<DINER_L512_RING, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
-    int cus = 0;
-    DINER_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    cu_count[dev].store(cus > 1 ? cus & ~1 : 256);
-    attr_set[dev].store(1);
-  }
-  const int cus = cu_count[dev].load();
-  // one launch of a tile shape over rows [row0, row0 + rows): ct = 32-row halves per tile, fh = workgroups per tile (feature halves)
-  auto part = [&](long long row0, long long rows) {
-    Lin512Args b = a;
-    b.X += (size_t)row0 * a.ldx;
-    b.Y += (size_t)row0 * a.ldy;
-    if (a.resid) b.resid += (size_t)row0 * a.ldy;
-    if (a.mask) b.mask += (size_t)row0 * a.ldy;
-    b.M = rows;
-    return b;
-  };
-  auto launch = [&](long long row0, long long rows, int ct, int fh) {
-    const Lin512Args b = part(row0, rows);
-    const long long units = (rows + 32 * ct - 1) / (32 * ct) * fh;
-    const int grid = (int)(units < cus ? units : cus);
-    if (ct == 2) hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 2, 1>), dim3(grid), dim3(256), kLdsBytes512, stream, b);
-    else if (fh == 2) hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 1, 2>), dim3(grid), dim3(256), kLdsBytes512, stream, b);
-    else hipLaunchKernelGGL((k_lin512<DINER_L512_RING, 1, 1>), dim3(grid), dim3(256), kLdsBytes512, stream, b);
-  };
-  // The plan: rounds of 64-row tiles over all CUs while a whole round is left (a weight fragment feeds twice the MFMAs there), and the
-  // ragged rest in the shape that costs least -- 32-row tiles, or 32-row tiles shared by two workgroups (half the features each).
-  // Costs in units of one round of 32-row tiles, measured on the reference training batch (20480 rows = 2.5 rounds of 32-row tiles: three
-  // rounds as 32-row tiles, 1.85 + 0.55 as one 64-row round + one round of half tiles).  DINER_L512_CT = 1 | 2 forces one shape for
-  // everything, DINER_L512_HALF = 0 keeps the half tiles out of the plan (measurement aids).
-  static const int forced = [] { const char* e = getenv("DINER_L512_CT"); return e ? atoi(e) : 0; }();
-  static const bool halves = [] { const char* e = getenv("DINER_L512_HALF"); return !(e && *e == '0'); }();
-  if (forced == 1 || forced == 2) {
-    launch(0, a.M, forced, 1);
-    DINER_LAUNCH_OK();
-    return 0;
-  }
-  const double c32 = 1.0, c64 = 1.85, chalf = 0.55, cextra = 0.1;            // cextra: a second launch
-  auto rounds = [&](long long units) { return (double)((units + cus - 1) / cus); };
-  auto rest_cost = [&](long long rows, int* fh) {            // cheapest 32-row shape for `rows` rows
-    const long long t32 = (rows + 31) / 32;
-    const double whole = rounds(t32) * c32, shared = rounds(2 * t32) * chalf;
-    *fh = halves && shared < whole ? 2 : 1;
-    return *fh == 2 ? shared : whole;
-  };
-  const long long round64 = 64ll * cus;
-  const long long main_rows = a.M / round64 * round64, rest = a.M - main_rows;
-  int fh_all = 1, fh_rest = 1;
-  const double all32 = rest_cost(a.M, &fh_all);
-  const double all64 = rounds((a.M + 63) / 64) * c64;
-  const double split = main_rows && rest ? (double)(main_rows / round64) * c64 + rest_cost(rest, &fh_rest) + cextra : 1e30;
-  static const bool fused = [] { const char* e = getenv("DINER_L512_FUSED"); return !(e && *e == '0'); }();      // 0: the two shapes as two launches
-  if (split < all32 && split < all64) {
-    if (fused) {
-      const Lin512Args bm = part(0, main_rows), br = part(main_rows, rest);
-      const long long n_main = main_rows / 64 < cus ? main_rows / 64 : cus;
-      const long long units = (rest + 31) / 32 * fh_rest;
-      const int n_rest = (int)(units < cus ? units : cus);
-      if (fh_rest == 2)
-        hipLaunchKernelGGL((k_lin512_plan<DINER_L512_RING, 2>), dim3((int)n_main + n_rest), dim3(256), kLdsBytes512, stream, bm, br, (int)n_main);
-      else
-        hipLaunchKernelGGL((k_lin512_plan<DINER_L512_RING, 1>), dim3((int)n_main + n_rest), dim3(256), kLdsBytes512, stream, bm, br, (int)n_main);
-    } else {
-      launch(0, main_rows, 2, 1);
-      launch(main_rows, rest, 1, fh_rest);
-    }
-  } else if (all64 <= all32) {
-    launch(0, a.M, 2, 1);
-  } else {
-    launch(0, a.M, 1, fh_all);
-  }
   DINER_LAUNCH_OK();
   return 0;
 }

@@ -1,4 +1,4 @@
-// Interface of train_lin512.hip (the 512 x 512 layer products of the training path) for train.hip.
+// Interface of train_512.hip (the 512 x 512 layer products of the training path: train_lin512.hip + train_wgrad512.hip) for train.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -33,7 +33,8 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream);
 struct WgReduceJob { const float* part; float* dW; float* db; int n_chunks; };
 struct WgReduceJobs { WgReduceJob job[13]; };
 int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
-                    hipStream_t stream, float* part = nullptr, bool overwrite = false, WgReduceJob* defer = nullptr);
+                    hipStream_t stream, float* part = nullptr, bool overwrite = false, WgReduceJob* defer = nullptr,
+                    const Lin512Args* dgrad = nullptr);      // dgrad: the data-gradient product of the same layer in the same launch
 int wgrad512_reduce_many(const WgReduceJobs& jobs, int n, bool overwrite, hipStream_t stream);
 size_t wgrad512_part_bytes();
 

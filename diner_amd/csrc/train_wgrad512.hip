@@ -18,6 +18,7 @@
 #include <utility>
 #include "field_common.hpp"
 #include "train_lin512.hpp"
+// (compiled as part of train_512.hip, which holds the kernel entry points and the launchers)
 
 namespace diner {
 namespace train {
@@ -55,14 +56,15 @@ __device__ __forceinline__ void wfor(F&& f) {
 
 #define DINER_WG_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
 
-__global__ __launch_bounds__(256, 1) void k_wgrad512(Wgrad512Args a) {
+// (bid: the workgroup's index within the weight-gradient part of its launch, train_512.hip)
+__device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int bid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char* lds_ptr;
   typedef __attribute__((address_space(3))) bf8w* lds_bf8;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // workgroup b: tile (b / 8) % 8, chunk b % 8 + 8 (b / 64) -- the 8 tiles of one chunk read the same rows and run on one XCD
-  const int tile = (blockIdx.x >> 3) & 7, chunk = (blockIdx.x & 7) + 8 * (blockIdx.x >> 6);
+  const int tile = (bid >> 3) & 7, chunk = (bid & 7) + 8 * (bid >> 6);
   const int ft = tile >> 1, kt2 = tile & 1;                  // f range [128 ft, +128), k range [256 kt2, +256)
   const long long m_begin = (long long)chunk * a.rows_per_chunk;
   long long m_end = m_begin + a.rows_per_chunk;
@@ -288,41 +290,6 @@ int wgrad512_reduce_many(const WgReduceJobs& jobs, int n, bool overwrite, hipStr
 }
 
 size_t wgrad512_part_bytes() { return (size_t)kWgMaxChunks * (512 * 512 + 512) * sizeof(float); }
-
-// dW (512, 512) += dY^T act(X), db (512) += column sums of dY, over M rows; dW / db zeroed by the caller.  part: null (atomics into dW) or
-// wgrad512_part_bytes() of scratch (partial tiles stored per chunk + one reduction pass); with it overwrite = true makes dW / db plain
-// outputs (no zeroing by the caller).
-int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
-                    hipStream_t stream, float* part, bool overwrite, WgReduceJob* defer) {
-  DINER_CHECK_ARG(part || !overwrite, "wgrad512: overwrite needs the scratch buffer");
-  DINER_CHECK_ARG(part || !defer, "wgrad512: a deferred summing pass needs the scratch buffer");
-  static std::atomic<int> attr_set[64];
-  int dev = 0;
-  DINER_HIP_OK(hipGetDevice(&dev));
-  dev &= 63;
-  if (!attr_set[dev].load()) {
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesWgrad));
-    attr_set[dev].store(1);
-  }
-  // row chunks: 32 (8 tiles x 32 = 256 workgroups) unless a chunk would be shorter than 4 slabs
-  long long n_chunks = 32;
-  while (n_chunks > 1 && (M + n_chunks - 1) / n_chunks < 128) n_chunks >>= 1;
-  if (n_chunks < 8) n_chunks = n_chunks < 1 ? 1 : n_chunks;
-  long long rows = (M + n_chunks - 1) / n_chunks;
-  rows = (rows + 31) / 32 * 32;
-  // the block -> (tile, chunk) map needs whole groups of 8 chunks when there are more than 8
-  Wgrad512Args a{dY, X, dW, db, part, M, ldy, ldx, relu_x ? 1 : 0, (int)n_chunks, rows};
-  const int grid = 8 * (int)(n_chunks <= 8 ? 8 : n_chunks);
-  hipLaunchKernelGGL(k_wgrad512, dim3(grid), dim3(256), kLdsBytesWgrad, stream, a);
-  if (part) {
-    // chunks that start past M wrote nothing: only the chunks with rows are summed
-    const int used = (int)((M + rows - 1) / rows);
-    if (defer) *defer = WgReduceJob{part, dW, db, used};        // the caller sums (wgrad512_reduce_many)
-    else hipLaunchKernelGGL(k_wgrad512_reduce, dim3(256), dim3(256), 0, stream, part, used, overwrite ? 1 : 0, dW, db);
-  }
-  DINER_LAUNCH_OK();
-  return 0;
-}
 
 }  // namespace train
 }  // namespace diner

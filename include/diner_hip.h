@@ -225,7 +225,7 @@ int diner_colormap_u8(const float* x, long long n, const unsigned char* lut_u8, 
  *   bias (N) added to every row, mask (M x N, stride ldc): C = 0 where mask <= 0 (relu adjoint). */
 int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc, int flags,
                    const float* bias, const float* mask, int k_split, void* stream);
-/* The 512 x 512 layer products of the training path on the feature-sliced kernel (train_lin512.hip; what the two calls below use for
+/* The 512 x 512 layer products of the training path on the feature-sliced kernel (train_lin512.hip, entry point in train_512.hip; what the two calls below use for
  * the forward and data-gradient products of every fc_0 / fc_1 / lin_z layer): Y (M, ldy) [+]= act(X (M, ldx)) op(W) [+ bias] [+ resid],
  * W (512, 512) row-major fp32; transpose = 0: op(W) = W^T (y = x W^T, the nn.Linear forward), 1: op(W) = W (dx = dy W).
  *   flags: 1 relu on X while it is staged, 2 Y += result;  bias (512) / resid (M, ldy) / mask (M, ldy: Y = 0 where mask <= 0) or NULL;
