@@ -271,7 +271,9 @@ int diner_channels_last_to_nchw_f32(const float* src, int n, long long HW, int C
  * blocks above that PixelNeRF.forward + ResnetFC.forward and their autograd adjoints amount to; pixelnerf.py:55-145,
  * resnetfc.py:129-159).  `params`: DEVICE parameter tensors in nn.Linear layout (d_in=55, d_latent=d_hidden=512, 5 blocks,
  * combine_layer=3); `workspace`: diner_field_train_workspace_bytes(P, nv) bytes, written by the forward (saved
- * pre-activations, taps, interpolated latent) and consumed by the backward of the same call pair.
+ * pre-activations, taps, interpolated latent, the 13 weight matrices of the 512 x 512 layers packed in both orientations) and consumed
+ * by the backward of the same call pair -- which therefore takes `params` with the VALUES the forward saw (an optimiser step belongs
+ * after the backward); it also holds the backward's scratch (partial weight-gradient tiles: 13 x 33.6 MB).
  *   forward : xyz, viewdirs (P,3) -> out (P,4) = [sigmoid rgb, relu sigma]
  *   backward: d_out (P,4) -> `grads` (same structure as `params`, device buffers of the parameters' shapes, overwritten)
  *             and d_latent_cl (nv,Hf,Wf,512) or NULL (gradient of the channels-last feature map, overwritten). */
