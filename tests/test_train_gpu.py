@@ -340,3 +340,40 @@ def test_wgrad512_against_float64():
             e_b = float((db.double() - want_b).abs().max() / dy.double().abs().sum(0).max())
             print(f"wgrad512 M={M} ({how}): dW {e_w:.2e}, db {e_b:.2e} (max error / max sum of |products|)")
             assert e_w < 2e-6 and e_b < 2e-6
+
+
+def test_scatter_latent_merged_and_layout_pass_against_torch():
+    """The two passes the latent gradient leaves through (csrc/train.hip), through their stage entries, against torch index_add / permute:
+    k_scatter_latent_merged on taps that merge (consecutive columns on neighbouring texels), on taps that do not (every tap its own texel:
+    the 56-slot table overflows and the rest goes out as direct atomics), with zero weights and a column count that is no multiple of 64;
+    k_cl_to_nchw on map sizes and channel counts that are no multiples of its 64 x 64 tile."""
+    from diner_amd import train, _lib
+    from diner_amd.ops import _ptr, _stream
+    lib = train.lib
+    g = torch.Generator().manual_seed(11)
+    n_tex = 4 * 24 * 24
+    for name, cols, rows in (("merging", 1000, None), ("distinct", 333, "distinct"), ("one texel", 130, "one")):
+        if rows is None:          # a walk over the texels: consecutive columns share most of their taps
+            base = (torch.arange(cols) // 3) % (n_tex - 30)
+            tap_row = torch.stack([base, base + 1, base + 24, base + 25], 1).int()
+        elif rows == "distinct":
+            tap_row = torch.randperm(n_tex, generator=g)[:cols * 4].view(cols, 4).int()
+        else:
+            tap_row = torch.full((cols, 4), 77, dtype=torch.int32)
+        tap_w = torch.rand(cols, 4, generator=g)
+        tap_w[torch.rand(cols, 4, generator=g) < 0.2] = 0.0
+        d_lat = torch.randn(cols, 512, generator=g)
+        want = torch.zeros(n_tex, 512, dtype=torch.float64)
+        for k in range(4):
+            want.index_add_(0, tap_row[:, k].long(), d_lat.double() * tap_w[:, k:k + 1].double())
+        out = torch.zeros(n_tex, 512, device="cuda")
+        dl, tr, tw = d_lat.cuda(), tap_row.cuda(), tap_w.cuda()
+        _lib.check(lib.diner_scatter_latent_grad_f32(_ptr(dl), _ptr(tr), _ptr(tw), cols, _ptr(out), _stream()))
+        err = float((out.cpu().double() - want).abs().max() / want.abs().max())
+        print(f"scatter ({name}, {cols} columns): {err:.2e}")
+        assert err < 1e-5
+    for n, H, W, C in ((1, 5, 7, 3), (2, 24, 24, 512), (3, 9, 33, 70)):
+        src = torch.randn(n, H, W, C, generator=g).cuda()
+        dst = torch.empty(n, C, H, W, device="cuda")
+        _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(src), n, H * W, C, _ptr(dst), _stream()))
+        assert torch.equal(dst, src.permute(0, 3, 1, 2).contiguous()), (n, H, W, C)
