@@ -79,13 +79,18 @@ def _oracle_grads(scene, w, xyz, dirs, G):
     return out.detach(), scene.latent.grad, {(k, i): t.grad for k, i, t in names}
 
 
-def test_field_forward_and_backward_against_oracle_autograd(ops):
+@pytest.mark.parametrize("P", [200, 5120])
+def test_field_forward_and_backward_against_oracle_autograd(ops, P):
+    """P = 200: 800 / 200 rows per layer (the general kernel serves the post-mean layers).  P = 5120: the reference training batch's row
+    counts (128 rays x 40 samples: 20480 rows per view layer, 5120 behind the view mean) -- the launch plans of k_run512 that the timing
+    runs use: one round of 64-row tiles + shared 32-row tiles, the weight-gradient product in the same launch, the deferred summing pass."""
     from diner_amd import train
     from tests.tests_train_util import module_param_list
     g = load("g6_pixelnerf.npz")
     sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
-    P = 200
-    xyz, dirs = T(g["pts"])[:P], T(g["dirs"])[:P]
+    reps = (P + g["pts"].shape[0] - 1) // g["pts"].shape[0]
+    jit = 1.0 + 1e-3 * torch.arange(reps).repeat_interleave(g["pts"].shape[0])[:P, None]      # the repeats are not exact copies
+    xyz, dirs = T(g["pts"]).repeat(reps, 1)[:P] * jit, T(g["dirs"]).repeat(reps, 1)[:P]
     G = torch.randn(P, 4, generator=torch.Generator().manual_seed(3))
     out_o, dlat_o, gr_o = _oracle_grads(scene, w, xyz, dirs, G)
     hs = ops.HipScene(sc["latent"].detach().cuda(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(),
@@ -94,7 +99,7 @@ def test_field_forward_and_backward_against_oracle_autograd(ops):
     latent = sc["latent"].detach().cuda().requires_grad_(True)
     params, names = module_param_list(msd)
     out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
-    e_fwd = max_norm_rel(out.detach().cpu(), g["out"][:P])
+    e_fwd = max_norm_rel(out.detach().cpu(), out_o)
     (out * G.cuda()).sum().backward(retain_graph=True)
     e_lat = max_norm_rel(latent.grad.cpu(), dlat_o)
     worst = ("", 0.0)
@@ -103,7 +108,18 @@ def test_field_forward_and_backward_against_oracle_autograd(ops):
         if e > worst[1]:
             worst = (f"{k}[{i}]", e)
     print(f"training path: forward {e_fwd:.2e}, d latent {e_lat:.2e}, worst parameter gradient {worst[0]} {worst[1]:.2e}")
-    assert e_fwd < 2e-5 and e_lat < TOL_GRAD and worst[1] < TOL_GRAD
+    if P <= 200:
+        assert e_fwd < 2e-5 and e_lat < TOL_GRAD and worst[1] < TOL_GRAD
+    else:
+        # 20480 rows x 512 units x 13 layers hold a few hundred pre-activations within rounding of zero: two fp32 evaluations (and an fp32
+        # and an fp64 one: the oracle in float64 is 1.4e-2 from the oracle in float32 in this norm) put some of them on different sides of
+        # the relu, and one flipped unit of one row moves a whole row of a weight gradient by one of the ~20480 random-sign terms its
+        # entries are sums of -- ~1e-2 of the largest entry.  The flips are few: in the Frobenius norm the gradients agree.
+        rms = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        r_lat = rms(latent.grad.cpu(), dlat_o)
+        r_par = max(rms(p.grad.cpu(), gr_o[(k, i)]) for p, (k, i) in zip(params, names))
+        print(f"   Frobenius-relative: d latent {r_lat:.2e}, worst parameter gradient {r_par:.2e}")
+        assert e_fwd < 2e-5 and e_lat < 3e-2 and worst[1] < 3e-2 and r_lat < 2e-3 and r_par < 2e-3
     assert (latent.grad != 0).any() and all((p.grad != 0).any() for p in params)
     # a second backward through the retained graph (the gradient buffers of the first one, allocated during the forward, are the
     # parameters' .grad by now and must not be written again): everything doubles
