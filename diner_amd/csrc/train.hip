@@ -908,14 +908,16 @@ extern "C" size_t diner_linear512_pack_bytes(void) { return kL512PackBytes; }
 extern "C" int diner_linear512_f32(const float* X, const float* W, float* Y, long long M, int ldx, int ldy, int transpose, int flags,
                                    const float* bias, const float* resid, const float* mask, void* wpack, void* stream) {
   DINER_CHECK_ARG(X && W && Y && wpack && M > 0, "linear512: bad arguments");
-  DINER_CHECK_ARG((flags & ~3) == 0, "linear512: unknown flags 0x%x", flags);
+  DINER_CHECK_ARG((flags & ~7) == 0, "linear512: unknown flags 0x%x", flags);
+  DINER_CHECK_ARG(!(flags & 4) || !transpose, "linear512: the f16x3 arithmetic (flag 4) is the forward product's (transpose = 0)");
   auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
   DINER_CHECK_ARG(ldx >= 512 && ldy >= 512 && (ldx & 3) == 0 && (ldy & 3) == 0 && al(X) && al(Y) && al(bias) && al(resid) && al(mask) && al(wpack),
                   "linear512: row strides must be multiples of 4 (>= 512) and pointers 16-byte aligned");
-  int rc = lin512_pack(W, transpose != 0, wpack, (hipStream_t)stream);
+  const bool f16 = (flags & 4) != 0;
+  int rc = lin512_pack(W, f16 ? 2 : (transpose != 0 ? 1 : 0), wpack, (hipStream_t)stream);
   if (rc) return rc;
-  Lin512Args a{X, wpack, Y, bias, resid, mask, M, ldx, ldy, flags};
-  return lin512_launch(a, (hipStream_t)stream);
+  Lin512Args a{X, wpack, Y, bias, resid, mask, M, ldx, ldy, flags & 3};
+  return lin512_launch(a, (hipStream_t)stream, f16 ? 1 : 0);
 }
 
 extern "C" size_t diner_wgrad512_scratch_bytes(void) { return wgrad512_part_bytes(); }
@@ -1008,10 +1010,10 @@ extern "C" int diner_composite_bwd_f32(const float* field, const float* z, const
 // saves ~100 host round trips per step, which matter at the reference's 128-ray training batch) -------------------------
 namespace {
 // packed-weights slots of the workspace: fc_0 / fc_1 of the 5 blocks + the 3 lin_z, forward and transposed
-constexpr int kWPackSlots = 2 * 13;
+constexpr int kWPackSlots = 3 * 13;      // forward, transposed, forward in fp16 hi / lo (the f16x3 forward arithmetic)
 enum { kSlotFc0 = 0, kSlotFc1 = 5, kSlotLinZ = 10 };
 struct TrainWs {               // float offsets into the workspace
-  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, wgpart, total;
+  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, wgpart, flags, total;
 };
 TrainWs train_ws(long long P, int nv) {
   TrainWs w;
@@ -1035,6 +1037,7 @@ TrainWs train_ws(long long P, int nv) {
   w.d_lat = take(cols * kLatent);
   w.wpack = take(kWPackSlots * (kL512PackBytes / sizeof(float)));      // packed 512 x 512 weights of train_lin512.hip
   w.wgpart = take(13 * (wgrad512_part_bytes() / sizeof(float)));     // per-chunk partial weight gradients of the 13 512 x 512 layers (train_wgrad512.hip)
+  w.flags = take(64);                                              // range flags of the f16x3 forward products (ints)
   w.total = o;
   return w;
 }
@@ -1046,6 +1049,13 @@ bool use_lin512() {
 }
 bool use_lin_out() {            // DINER_TRAIN_LINOUT=0: lin_out and its adjoints back on the general kernel (A/B measurement)
   static const bool on = [] { const char* e = getenv("DINER_TRAIN_LINOUT"); return !(e && *e == '0'); }();
+  return on;
+}
+// The forward products of the 512 x 512 layers in the f16x3 arithmetic of the inference kernels (two fp16 planes per operand, three product
+// terms: half the MFMAs of bf16x6, same fp32-class accuracy on activations) with a bf16x6 launch behind each that does nothing unless the
+// f16x3 one met an operand beyond the fp16 range.  DINER_TRAIN_FWD_F16X3=0: bf16x6 forward (A/B measurement).
+bool use_fwd_f16() {
+  static const bool on = [] { const char* e = getenv("DINER_TRAIN_FWD_F16X3"); return !(e && *e == '0'); }();
   return on;
 }
 bool use_wgrad512() {          // DINER_TRAIN_WGRAD512=0: weight gradients back on the general kernel (A/B measurement)
@@ -1138,13 +1148,23 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     PackMany pm;
     for (int b = 0; b < 5; ++b) { pm.W[kSlotFc0 + b] = p->fc0_w[b]; pm.W[kSlotFc1 + b] = p->fc1_w[b]; }
     for (int b = 0; b < 3; ++b) pm.W[kSlotLinZ + b] = p->lin_z_w[b];
-    if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st))) return rc;
+    if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st, use_fwd_f16() ? 3 : 2))) return rc;
+    if (use_fwd_f16()) DINER_HIP_OK(hipMemsetAsync(ws + w.flags, 0, 16 * sizeof(int), st));
   }
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
                  bool accum, const float* resid = nullptr, int slot = -1) {
     if (slot >= 0 && N == 512 && K == 512 && lin512_ok(x, ldx, y, N, resid, nullptr)) {
       void* wp = wpack_slot(ws, w, slot, false);
       Lin512Args a{x, wp, y, b, resid, nullptr, M, ldx, N, (relu ? kL512ReluIn : 0) | (accum ? kL512Accum : 0)};
+      if (use_fwd_f16() && !accum) {             // (an accumulating product cannot be run twice: lin_z stays on bf16x6)
+        int* flag = reinterpret_cast<int*>(ws + w.flags) + slot;
+        Lin512Args h = a;
+        h.Wp = reinterpret_cast<char*>(ws + w.wpack) + (size_t)(26 + slot) * kL512PackBytes;
+        h.ovf = flag;
+        int hrc = lin512_launch(h, st, 1);
+        if (hrc) return hrc;
+        a.gate = flag;                           // the bf16x6 product below runs only if the f16x3 one left the range
+      }
       return lin512_launch(a, st);
     }
     return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid);

@@ -26,6 +26,18 @@ __device__ __forceinline__ void lin512_part(const Lin512Args& a, int shape, int 
   else lin512_body<DINER_L512_RING, 1, 2>(a, bid, nblk);
 }
 
+// The forward products in the f16x3 arithmetic (lin512_body<.., AR = 1>: half the MFMAs of bf16x6): the same parts, no weight gradient
+__device__ __forceinline__ void lin512_part_f16(const Lin512Args& a, int shape, int bid, int nblk) {
+  if (shape == kShape64) lin512_body<DINER_L512_RING, 2, 1, 1>(a, bid, nblk);
+  else if (shape == kShape32) lin512_body<DINER_L512_RING, 1, 1, 1>(a, bid, nblk);
+  else lin512_body<DINER_L512_RING, 1, 2, 1>(a, bid, nblk);
+}
+__global__ __launch_bounds__(256, 1) void k_fwd512_f16x3(Run512 r) {
+  int b = blockIdx.x;
+  if (b < r.n[0]) return lin512_part_f16(r.part[0], r.shape[0], b, r.n[0]);
+  lin512_part_f16(r.part[1], r.shape[1], b - r.n[0], r.n[1]);
+}
+
 __global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
   int b = blockIdx.x;
   if (b < r.n[0]) return lin512_part(r.part[0], r.shape[0], b, r.n[0]);
@@ -44,6 +56,7 @@ int device_cus(int* cus) {                                   // per device: dyna
   dev &= 63;
   if (!attr_set[dev].load()) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(c > 1 ? c & ~1 : 256);
@@ -118,14 +131,15 @@ int plan_wgrad512(const float* dY, int ldy, const float* X, int ldx, bool relu_x
 }
 }  // namespace
 
-int lin512_launch(const Lin512Args& a, hipStream_t stream) {
+int lin512_launch(const Lin512Args& a, hipStream_t stream, int arith) {
   int cus = 0;
   int rc = device_cus(&cus);
   if (rc) return rc;
   Run512 r;
   plan_lin512(a, cus, &r);
   memset(&r.wg, 0, sizeof(r.wg));
-  hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
+  if (arith == 1) hipLaunchKernelGGL(k_fwd512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytes512, stream, r);
+  else hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
   DINER_LAUNCH_OK();
   return 0;
 }

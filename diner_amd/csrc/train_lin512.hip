@@ -28,6 +28,8 @@ namespace train {
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+constexpr float kF16Scale = 16.0f, kF16InvScale = 1.0f / 16.0f;      // f16x3 arithmetic: the packed weights carry this factor
 
 constexpr int kStepsPerSlab = 8;                // k16 steps per staged slab (128 contraction indices)
 constexpr int kSlabs = 512 / (16 * kStepsPerSlab);
@@ -59,14 +61,31 @@ __device__ __forceinline__ void sfor(F&& f) {
 // Weight packing: dst[(((w * 32 + s) * 4 + rt) * 3 + pl) * 64 + lane][j] = plane pl of
 //   W[128 w + 32 rt + (lane & 31)][16 s + 8 (lane >> 5) + j]      (transpose = 0: forward, W is (out, in) as nn.Linear stores it)
 //   W[16 s + 8 (lane >> 5) + j][128 w + 32 rt + (lane & 31)]      (transpose = 1: data gradient, the roles of out / in swap)
-__device__ __forceinline__ void pack_w512(const float* __restrict__ W, int transpose, __bf16* __restrict__ dst) {
-  const int total = 4 * 32 * 4 * 64;              // (w, s, rt, lane) slots of 8 values x 3 planes
+// mode 0 / 1: three bf16 planes, forward / transposed; mode 2 (forward, the f16x3 arithmetic of lin512_body<.., AR = 1>): two fp16 planes
+// hi / lo of 16 W -- dst[(((w * 32 + s) * 4 + rt) * 2 + pl) * 64 + lane][j] (the factor keeps the lo parts of small weights normal; the
+// body's epilogue takes it out again)
+__device__ __forceinline__ void pack_w512(const float* __restrict__ W, int mode, __bf16* __restrict__ dst) {
+  const int total = 4 * 32 * 4 * 64;              // (w, s, rt, lane) slots of 8 values x 3 (2) planes
+  const bool transpose = mode == 1;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63, rt = (i >> 6) & 3, s = (i >> 8) & 31, w = i >> 13;
     const int f = 128 * w + 32 * rt + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = transpose ? W[(size_t)(k0 + j) * 512 + f] : W[(size_t)f * 512 + k0 + j];
+    if (mode == 2) {
+      hf8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = v[j] * kF16Scale;
+        hi[j] = (_Float16)x;
+        lo[j] = (_Float16)(x - (float)hi[j]);
+      }
+      hf8* d = reinterpret_cast<hf8*>(dst) + ((((size_t)w * 32 + s) * 4 + rt) * 2) * 64 + lane;
+      d[0] = hi;
+      d[64] = lo;
+      continue;
+    }
     bf8 p0, p1, p2;
     split3x8(v, p0, p1, p2);
     bf8* d = reinterpret_cast<bf8*>(dst) + ((((size_t)w * 32 + s) * 4 + rt) * 3) * 64 + lane;
@@ -76,7 +95,8 @@ __device__ __forceinline__ void pack_w512(const float* __restrict__ W, int trans
   }
 }
 __global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* __restrict__ dst) { pack_w512(W, transpose, dst); }
-// blockIdx.y = matrix, blockIdx.z = orientation: all 512 x 512 weights of a training step in one launch
+// blockIdx.y = matrix, blockIdx.z = pack mode (0 forward, 1 transposed, 2 forward in fp16 hi / lo): all 512 x 512 weights of a training
+// step in one launch
 __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base) {
   pack_w512(w.W[blockIdx.y], blockIdx.z, reinterpret_cast<__bf16*>(base + (size_t)(13 * blockIdx.z + blockIdx.y) * kL512PackBytes));
 }
@@ -85,6 +105,7 @@ __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base) {
 #define DINER_L512_RING 2
 #endif
 #define DINER_BF16_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
+#define DINER_F16_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, A), __builtin_bit_cast(hf8, B), ACC, 0, 0, 0)
 
 // R: weight ring depth in k16 steps (kStepsPerSlab must be a multiple of it); CT: 32-row halves per tile -- 2 = 64-row tiles (the
 // throughput shape), 1 = 32-row tiles for small M (the reference training batch has 20480 rows: 320 tiles of 64 on 256 CUs is two rounds
@@ -92,10 +113,15 @@ __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base) {
 // FH: feature halves -- 1: a workgroup computes all 512 features of its rows; 2: workgroup pairs share a tile, each computes 256 features
 // (wave w: 64 features = 2 MFMA row tiles) -- half-cost units for the ragged last round of a small M (lin512_launch)
 // (bid, nblk: the workgroup's index and count within its launch part -- k_lin512_plan runs two shapes in one launch)
-template <int R, int CT, int FH>
+// AR: arithmetic -- 0 = bf16x6 (three bf16 planes per operand, six product terms: no range limit), 1 = f16x3 (two fp16 planes, three
+// terms, weights x16: the inference kernels' arithmetic; half the MFMAs; an operand beyond the fp16 range raises a.ovf and the caller
+// recomputes the product with AR = 0 -- the training FORWARD only, whose operands are activations)
+template <int R, int CT, int FH, int AR = 0>
 __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, const int nblk) {
-  constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * 3, NQ = 4 * CT;      // NQ: staging requests per wave and slab
-  constexpr int NRT = 4 / FH, NF = 3 * NRT;                  // MFMA row (= feature) tiles per wave, weight fragments per k16 step
+  constexpr int NP = AR == 1 ? 2 : 3, NT = AR == 1 ? 3 : 6;  // planes per operand, product terms
+  constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * NP, NQ = 4 * CT;      // NQ: staging requests per wave and slab
+  constexpr int NRT = 4 / FH, NF = NP * NRT;                 // MFMA row (= feature) tiles per wave, weight fragments per k16 step
+  if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char* lds_ptr;
   typedef __attribute__((address_space(3))) bf8* lds_bf8;
@@ -122,13 +148,23 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   typedef __attribute__((address_space(3))) bf4* lds_bf4;
   // where this lane's 4 values go inside a slab buffer: step s = k / 16, lane' = (row & 31) + 32 ((k / 8) & 1), element k & 7
   const int k4 = 4 * (lane & 31);
-  const int st_off = ((k4 >> 4) * CT * 3) * 1024 + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
+  const int st_off = ((k4 >> 4) * CT * NP) * 1024 + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
   bf4 sp0, sp1, sp2;                                         // the request being converted (two halves, see the slab loop)
+  unsigned x_max = 0;                                        // AR = 1: largest |x| staged by this lane, as bits
   auto stash_half = [&](int i, int half) {
 #pragma unroll
     for (int j = 2 * half; j < 2 * half + 2; ++j) {
       float x = xst[i][j];
       if (relu_in) x = fmaxf(x, 0.0f);
+      if constexpr (AR == 1) {
+        const unsigned bits = __float_as_uint(x) & 0x7fffffffu;
+        x_max = x_max > bits ? x_max : bits;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        sp0[j] = __builtin_bit_cast(__bf16, h);
+        sp1[j] = __builtin_bit_cast(__bf16, l);
+        continue;
+      }
       const __bf16 a0 = (__bf16)x;
       const float r1 = x - (float)a0;
       const __bf16 a1 = (__bf16)r1;
@@ -139,10 +175,10 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   };
   auto stash_write = [&](int buf, int i) {
     const int r = 8 * CT * wave + 2 * i + (lane >> 5);       // row within the tile
-    lds_ptr d = (lds_ptr)smem + buf * (kSlabFrags * 1024) + st_off + ((r >> 5) * 3) * 1024 + (r & 31) * 16;
+    lds_ptr d = (lds_ptr)smem + buf * (kSlabFrags * 1024) + st_off + ((r >> 5) * NP) * 1024 + (r & 31) * 16;
     *(lds_bf4)(d) = sp0;
     *(lds_bf4)(d + 1024) = sp1;
-    *(lds_bf4)(d + 2048) = sp2;
+    if constexpr (NP == 3) *(lds_bf4)(d + 2048) = sp2;
   };
   auto stash_req = [&](int buf, int i) {                     // convert + write request i of the slab in flight
     stash_half(i, 0);
@@ -154,14 +190,14 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   const int half = FH == 2 ? (bid & 1) : 0;
   const int wslice = FH == 2 ? 2 * half + (wave >> 1) : wave;                // 128-feature slice of the packed weights
   const int rt0 = FH == 2 ? 2 * (wave & 1) : 0;                              // first of this wave's row tiles inside the slice
-  const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + ((size_t)wslice * 32 * 12 + 3 * rt0) * 1024;
+  const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + ((size_t)wslice * 32 * (4 * NP) + NP * rt0) * 1024;
   const unsigned woff = lane * 16;
   bf8 wr[R][NF];
   auto load_w = [&](bf8 (&dst)[NF], int step, int first, int count) {        // fragments [first, first + count) of step (0..31)
 #ifdef DINER_L512_ABL_W       // ablation (wrong results): a 24 KB weight working set per wave, i.e. no L2 latency on the weight stream
     step &= 1;
 #endif
-    gptr p = wbase + (size_t)step * 12 * 1024;
+    gptr p = wbase + (size_t)step * (4 * NP) * 1024;
     asm volatile("" : "+s"(p));                  // scalar base + per-lane 32-bit offset + immediate: no address registers per load
 #pragma unroll
     for (int i = first; i < first + count; ++i) dst[i] = *(const __attribute__((address_space(1))) bf8*)(p + woff + i * 1024);
@@ -201,31 +237,33 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
       (void)last;
       lds_ptr rb = lbase + buf * (kSlabFrags * 1024);
       asm volatile("" : "+v"(rb));
-      bf8 bb[2][CT][3];                                      // B fragments [parity][row half][plane]
+      bf8 bb[2][CT][NP];                                     // B fragments [parity][row half][plane]
       auto load_b = [&](int par, int s) {
 #pragma unroll
         for (int h = 0; h < CT; ++h)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * CT + h) * 3 + pl) * 1024);
+          for (int pl = 0; pl < NP; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * CT + h) * NP + pl) * 1024);
       };
       load_b(0, 0);
       sfor<kStepsPerSlab>([&](auto S) {
         constexpr int s = decltype(S)::value;
         const int gstep = slab * kStepsPerSlab + s;
         bf8 (&wc)[NF] = wr[s % R];
-        // 12 quarter-groups (row half ct, product term t): one MFMA on each of the four row tiles -- consecutive MFMAs never share an
-        // accumulator, and the next step's weights are requested in the first 6 of them (12 fragments, two per group)
-        sfor<6 * CT>([&](auto G) {
-          constexpr int g = decltype(G)::value, ct = g / 6, t = g % 6;
-          constexpr int ia = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;          // smallest terms first: (a2 b0) (a0 b2) (a1 b1) (a1 b0) (a0 b1) (a0 b0)
-          constexpr int ib = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+        // NG = NT x CT groups (row half ct, product term t): one MFMA on each of the wave's row tiles -- consecutive MFMAs never share an
+        // accumulator; the next step's weights are requested in the first groups (NF fragments, LW per group)
+        constexpr int NG = NT * CT, LW = (NF + NG - 1) / NG < 2 ? 2 : (NF + NG - 1) / NG;
+        sfor<NG>([&](auto G) {
+          constexpr int g = decltype(G)::value, ct = g / NT, t = g % NT;
+          // smallest terms first.  bf16x6: (a2 b0) (a0 b2) (a1 b1) (a1 b0) (a0 b1) (a0 b0);  f16x3: (lo hi) (hi lo) (hi hi)
+          constexpr int ia = AR == 1 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0);
+          constexpr int ib = AR == 1 ? (t == 1 ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0);
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (2 * g < NF) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, 2 * g, 2);
-          if constexpr (g == (CT == 2 ? 7 : 3) && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
-          // staging side task: two of the slab's eight requests per step, steps 4..7 (requested at step 0)
-          // // (which four steps makes no measurable difference)
+          if constexpr (LW * g < NF) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, LW * g, (LW * g + LW <= NF ? LW : NF - LW * g));
+          if constexpr (g == (NG >= 12 ? 7 : NG >= 6 ? 3 : 1) && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
+          // staging side task: one of the slab's NQ requests per step (steps 0 .. NQ-1), in three groups
+          // // (which steps makes no measurable difference)
+          constexpr int g0 = AR == 1 ? NG - 3 : (CT == 2 ? 8 : 2);
 #ifndef DINER_L512_ABL_X
-          constexpr int g0 = CT == 2 ? 8 : 2;                  // the step's request (steps 0 .. NQ-1 have one) in three groups
           if constexpr (s < NQ && g == g0) stash_half(s, 0);
           if constexpr (s < NQ && g == g0 + 1) stash_half(s, 1);
           if constexpr (s < NQ && g == g0 + 2) {
@@ -235,8 +273,11 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
 #endif
           const bf8 b = bb[s & 1][ct][ib];
 #pragma unroll
-          for (int rt = 0; rt < NRT; ++rt) DINER_BF16_MFMA(acc[rt][ct], wc[3 * rt + ia], b);
-          if constexpr (s < NQ && (g == (CT == 2 ? 8 : 2) || g == (CT == 2 ? 9 : 3))) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
+          for (int rt = 0; rt < NRT; ++rt) {
+            if constexpr (AR == 1) DINER_F16_MFMA(acc[rt][ct], wc[NP * rt + ia], b);
+            else DINER_BF16_MFMA(acc[rt][ct], wc[NP * rt + ia], b);
+          }
+          if constexpr (s < NQ && (g == g0 || g == g0 + 1)) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
               __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
@@ -262,6 +303,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
           f32x4 v;
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = acc[rt][ct][4 * q4 + c];
+          if constexpr (AR == 1) v *= kF16InvScale;
           if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + f);
           const size_t at = (size_t)row * a.ldy + f;
           if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + at);
@@ -276,6 +318,9 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
         }
     }
   }
+  if constexpr (AR == 1) {                                   // an operand beyond the fp16 range (or not finite): the caller's bf16x6 launch recomputes
+    if (a.ovf && x_max >= 0x477fe000u) *a.ovf = 1;           // (65504: from there on the conversion may round to inf)
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -285,8 +330,8 @@ int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
   return 0;
 }
 
-int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream) {
-  hipLaunchKernelGGL(k_pack_w512_many, dim3(128, n, 2), dim3(256), 0, stream, w, (char*)base);
+int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream, int modes) {
+  hipLaunchKernelGGL(k_pack_w512_many, dim3(128, n, modes), dim3(256), 0, stream, w, (char*)base);
   DINER_LAUNCH_OK();
   return 0;
 }

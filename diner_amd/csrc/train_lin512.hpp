@@ -17,15 +17,17 @@ struct Lin512Args {
   const float* mask;     // (M, ldy) or null: Y = 0 where mask <= 0
   long long M;
   int ldx, ldy, flags;
+  int* ovf;              // f16x3 arithmetic: raised when a staged operand leaves the fp16 range (null: not reported)
+  const int* gate;       // null, or: the launch does nothing unless *gate != 0 (the bf16x6 fall-back behind an f16x3 product)
 };
 
 // W (512, 512) row-major fp32 -> packed planes; transpose = 0: y = x W^T (W as nn.Linear stores it), 1: y = x W
-int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream);
-// n <= 13 weight matrices in one launch, both orientations: W[i] -> base + i * kL512PackBytes (transpose 0) and
-// base + (13 + i) * kL512PackBytes (transpose 1)
+int lin512_pack(const float* W, int mode, void* dst, hipStream_t stream);
+// n <= 13 weight matrices in one launch: W[i] -> base + (13 m + i) * kL512PackBytes for the pack modes m < modes (0 forward, 1 transposed,
+// 2 forward as fp16 hi / lo of 16 W for the f16x3 arithmetic)
 struct PackMany { const float* W[13]; };
-int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream);
-int lin512_launch(const Lin512Args& a, hipStream_t stream);
+int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream, int modes = 2);      // modes = 3: + the fp16 hi / lo pack at slot 26 + i
+int lin512_launch(const Lin512Args& a, hipStream_t stream, int arith = 0);      // arith 1: f16x3 (Wp packed with mode 2; a.ovf reports operands out of range)
 // train_wgrad512.hip: dW (512, 512) += dY^T act(X), db (512, or null) += column sums of dY over M rows.  part = null: atomics into dW / db
 // (both zeroed by the caller); part = wgrad512_part_bytes() of scratch: per-chunk partial tiles + one summing pass, which overwrites
 // dW / db instead of adding to them when overwrite is set

@@ -28,12 +28,13 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, flags=0, bias=None, mask=None, k_split
                                   int(flags), _ptr(bias), _ptr(mask), int(k_split), _stream()))
 
 
-def linear512(x, W, out, transpose=False, relu_in=False, accumulate=False, bias=None, resid=None, mask=None):
+def linear512(x, W, out, transpose=False, relu_in=False, accumulate=False, bias=None, resid=None, mask=None, f16x3=False):
     """out (M, 512) (+)= act(x (M, 512)) op(W) (+ bias) (+ resid) [* (mask > 0)] on the feature-sliced training kernel
-    (csrc/train_lin512.hip): transpose False = x W^T (nn.Linear forward), True = x W (data gradient)."""
+    (csrc/train_lin512.hip): transpose False = x W^T (nn.Linear forward), True = x W (data gradient).  f16x3: the forward product in the
+    inference kernels' arithmetic (two fp16 planes per operand, |x| < 65504; no fall-back at this level)."""
     ws = torch.empty(lib.diner_linear512_pack_bytes(), dtype=torch.uint8, device=x.device)
     _lib.check(lib.diner_linear512_f32(_ptr(x), _ptr(W), _ptr(out), int(x.shape[0]), int(x.stride(0)), int(out.stride(0)),
-                                       int(bool(transpose)), (1 if relu_in else 0) | (2 if accumulate else 0), _ptr(bias), _ptr(resid),
+                                       int(bool(transpose)), (1 if relu_in else 0) | (2 if accumulate else 0) | (4 if f16x3 else 0), _ptr(bias), _ptr(resid),
                                        _ptr(mask), _ptr(ws), _stream()))
     return out
 

@@ -334,6 +334,13 @@ def test_linear512_against_float64():
         err2 = float((dx.double() - want_dx).abs().max() / scale2)
         print(f"linear512 M={M}: forward {err:.2e}, dgrad {err2:.2e} (max error / max sum of |products|)")
         assert err < 1e-6 and err2 < 1e-6
+        # the forward product in the f16x3 arithmetic (what the training forward runs first): operands inside the fp16 range
+        xs = torch.randn(M, 512, generator=g).cuda() * torch.logspace(-6, 3, 512).cuda()[torch.randperm(512, generator=g).cuda()]
+        train.linear512(xs, W, y, relu_in=True, bias=b, resid=r, f16x3=True)
+        want3 = torch.relu(xs.double()) @ W.double().T + b.double() + r.double()
+        err3 = float((y.double() - want3).abs().max() / (torch.relu(xs.double()).abs() @ W.double().abs().T).max())
+        print(f"   f16x3 forward {err3:.2e}")
+        assert err3 < 2e-6
 
 
 def test_wgrad512_against_float64():
