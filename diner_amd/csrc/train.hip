@@ -1152,10 +1152,11 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     if (use_fwd_f16()) DINER_HIP_OK(hipMemsetAsync(ws + w.flags, 0, 16 * sizeof(int), st));
   }
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
-                 bool accum, const float* resid = nullptr, int slot = -1) {
+                 bool accum, const float* resid = nullptr, int slot = -1, const float* resid2 = nullptr) {
     if (slot >= 0 && N == 512 && K == 512 && lin512_ok(x, ldx, y, N, resid, nullptr)) {
       void* wp = wpack_slot(ws, w, slot, false);
       Lin512Args a{x, wp, y, b, resid, nullptr, M, ldx, N, (relu ? kL512ReluIn : 0) | (accum ? kL512Accum : 0)};
+      a.resid2 = resid2;
       if (use_fwd_f16() && !accum) {             // (an accumulating product cannot be run twice: lin_z stays on bf16x6)
         int* flag = reinterpret_cast<int*>(ws + w.flags) + slot;
         Lin512Args h = a;
@@ -1167,18 +1168,29 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
       }
       return lin512_launch(a, st);
     }
+    DINER_CHECK_ARG(!resid2, "field_train_forward: second residual off the 512-kernel path");
     return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid);
   };
-  if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, false))) return rc;
+  // The lin_z term of block b, Z_b = lat Wz_b^T + bz_b, is a product of its own into a scratch buffer (d_lat is free in the forward) and
+  // enters the residual stream through the epilogue of the product that writes X[b] -- lin_in for block 0, fc_1 of block b - 1 otherwise
+  // (second residual): no accumulating product is left in the forward, so every 512 x 512 product can run in the f16x3 arithmetic with
+  // its gated bf16x6 repeat.  (Without the 512-kernels: lin_z accumulates onto X[b] as before.)
+  float* Z = ws + w.d_lat;
+  const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, Z, kHidden, nullptr, nullptr);
+  auto lin_z = [&](int b) { return lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], Z, cols, kHidden, kLatent, false, false, nullptr, kSlotLinZ + b); };
+  if (z_sep && (rc = lin_z(0))) return rc;
+  if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, false, z_sep ? Z : nullptr))) return rc;
   for (int b = 0; b < 5; ++b) {
     const long long M = b < 3 ? cols : P;
     float* X = ws + w.X[b];
-    if (b < 3 && (rc = lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], X, M, kHidden, kLatent, false, true, nullptr, kSlotLinZ + b))) return rc;
+    if (!z_sep && b < 3 && (rc = lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], X, M, kHidden, kLatent, false, true, nullptr, kSlotLinZ + b))) return rc;
     if ((rc = lin(X, kHidden, p->fc0_w[b], p->fc0_b[b], ws + w.H[b], M, kHidden, kHidden, true, false, nullptr, kSlotFc0 + b))) return rc;
     // next residual stream: X + fc_1(relu(H)); the view mean comes after block 2
     float* nx = b == 4 ? ws + w.x_last : (b == 2 ? ws + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
+    const bool z_next = z_sep && b + 1 < 3;
+    if (z_next && (rc = lin_z(b + 1))) return rc;
     // (the residual enters through the product's epilogue: no copy of X)
-    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b))) return rc;
+    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b, z_next ? Z : nullptr))) return rc;
     if (b == 2)
       hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3]);
   }

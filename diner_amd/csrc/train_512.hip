@@ -78,6 +78,7 @@ void plan_lin512(const Lin512Args& a, int cus, Run512* r) {
     b.Y += (size_t)row0 * a.ldy;
     if (a.resid) b.resid += (size_t)row0 * a.ldy;
     if (a.mask) b.mask += (size_t)row0 * a.ldy;
+    if (a.resid2) b.resid2 += (size_t)row0 * a.ldy;
     b.M = rows;
     return b;
   };

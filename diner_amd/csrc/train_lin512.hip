@@ -307,6 +307,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
           if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + f);
           const size_t at = (size_t)row * a.ldy + f;
           if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + at);
+          if (a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + at);
           if (a.mask) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + at);
 #pragma unroll

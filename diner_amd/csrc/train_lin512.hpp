@@ -19,6 +19,7 @@ struct Lin512Args {
   int ldx, ldy, flags;
   int* ovf;              // f16x3 arithmetic: raised when a staged operand leaves the fp16 range (null: not reported)
   const int* gate;       // null, or: the launch does nothing unless *gate != 0 (the bf16x6 fall-back behind an f16x3 product)
+  const float* resid2;   // (M, ldy) or null: a second residual (the next block's lin_z term, which then needs no accumulating product)
 };
 
 // W (512, 512) row-major fp32 -> packed planes; transpose = 0: y = x W^T (W as nn.Linear stores it), 1: y = x W

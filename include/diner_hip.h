@@ -228,7 +228,10 @@ int diner_gemm_f32(const float* A, const float* B, float* C, long long M, int N,
 /* The 512 x 512 layer products of the training path on the feature-sliced kernel (train_lin512.hip, entry point in train_512.hip; what the two calls below use for
  * the forward and data-gradient products of every fc_0 / fc_1 / lin_z layer): Y (M, ldy) [+]= act(X (M, ldx)) op(W) [+ bias] [+ resid],
  * W (512, 512) row-major fp32; transpose = 0: op(W) = W^T (y = x W^T, the nn.Linear forward), 1: op(W) = W (dx = dy W).
- *   flags: 1 relu on X while it is staged, 2 Y += result;  bias (512) / resid (M, ldy) / mask (M, ldy: Y = 0 where mask <= 0) or NULL;
+ *   flags: 1 relu on X while it is staged, 2 Y += result, 4 (transpose = 0 only) the f16x3 arithmetic of the inference kernels -- two
+ *   fp16 planes per operand, three product terms: half the MFMAs, the same accuracy class, |X| < 65504 (the training forward runs its
+ *   products this way first and repeats one in bf16x6 when an operand was out of range; this entry does not);
+ *   bias (512) / resid (M, ldy) / mask (M, ldy: Y = 0 where mask <= 0) or NULL;
  *   wpack: diner_linear512_pack_bytes() bytes of device scratch (W is packed into three bf16 planes there, then multiplied).
  * Products as accurate as fp32 rounding (six-term split-bf16, no range limits).  ldx, ldy multiples of 4, pointers 16-byte aligned. */
 size_t diner_linear512_pack_bytes(void);

@@ -226,8 +226,11 @@ def test_module_training_step_against_oracle_autograd(ops):
     print(f"module training step vs float64 autograd: HIP worst parameter gradient {worst[0]} {worst[1]:.2e}, d latent "
           f"{e_lat:.2e}; float32 torch autograd itself: {worst_o[0]} {worst_o[1]:.2e}, d latent {e_lat_o:.2e}")
     # a rgb loss through 40 alpha-composited samples is ill-conditioned in float32: float32 torch autograd itself is
-    # ~2e-3 from the float64 gradient on the worst tensor; the HIP path must be no further than that (and 1e-4 when it is easy)
-    assert worst[1] < max(TOL_GRAD, 1.5 * worst_o[1]) and e_lat < max(TOL_GRAD, 1.5 * e_lat_o)
+    # ~2e-3 from the float64 gradient on the worst tensor (pre-activations within rounding of zero land on either side of the relu, and
+    # one flipped unit of one row is one of the few thousand random-sign terms an entry of a weight gradient sums); the HIP path -- another
+    # fp32-class evaluation with its own roundings, hence its own flips -- must be in that class (twice fp32 autograd's own distance) and
+    # at 1e-4 when it is easy
+    assert worst[1] < max(TOL_GRAD, 2.0 * worst_o[1]) and e_lat < max(TOL_GRAD, 2.0 * e_lat_o)
 
 
 def test_three_adam_steps_track_torch_autograd(ops):
@@ -400,3 +403,42 @@ def test_scatter_latent_merged_and_layout_pass_against_torch():
         dst = torch.empty(n, C, H, W, device="cuda")
         _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(src), n, H * W, C, _ptr(dst), _stream()))
         assert torch.equal(dst, src.permute(0, 3, 1, 2).contiguous()), (n, H, W, C)
+
+
+def test_training_forward_beyond_the_fp16_range(ops):
+    """The training forward runs its 512 x 512 products in the f16x3 arithmetic first; an operand beyond the fp16 range raises the product's
+    flag and the bf16x6 launch behind it recomputes it (no host synchronisation).  One feature of the residual stream sits at 1e5 (the
+    f16x3 products that stage it would turn it into inf and their outputs into NaN): outputs and gradients follow the oracle's autograd."""
+    from diner_amd import train
+    from tests.tests_train_util import module_param_list
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    big = {k: v.clone() for k, v in msd.items()}
+    big["lin_in.bias"][5] += 1.0e5                      # one feature of the residual stream beyond 65504 in every block ...
+    for k in big:                                       # ... that nothing reads with a non-zero weight: the outputs stay ordinary
+        if k.endswith("fc_0.weight") or k == "lin_out.weight":
+            big[k][:, 5] = 0.0
+    wb = O.MLPWeights.from_state_dict(big)
+    P = 300
+    xyz, dirs = T(g["pts"])[:P], T(g["dirs"])[:P]
+    G = torch.randn(P, 4, generator=torch.Generator().manual_seed(5))
+    out_o, dlat_o, gr_o = _oracle_grads(scene, wb, xyz, dirs, G)
+    hs = ops.HipScene(sc["latent"].detach().cuda(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(),
+                      sc["src_extrinsics"], sc["src_intrinsics"][:, [0, 1], [0, 1]], sc["src_intrinsics"][:, :2, -1],
+                      sc["image_shape"], sc["feature_padding"])
+    latent = sc["latent"].detach().cuda().requires_grad_(True)
+    params, names = module_param_list(big)
+    out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
+    assert torch.isfinite(out).all()
+    e_fwd = float((out.detach().cpu() - out_o).abs().max())          # sigmoid / relu outputs of O(1) .. O(1e5): absolute on rgb, relative on sigma
+    (out * G.cuda()).sum().backward()
+    worst = 0.0
+    for p, (k, i) in zip(params, names):
+        want = gr_o[(k, i)]
+        assert torch.isfinite(p.grad).all()
+        if float(want.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, (k, i)
+        else:
+            worst = max(worst, max_norm_rel(p.grad.cpu(), want))
+    print(f"beyond the fp16 range: forward max abs difference {e_fwd:.2e} (sigma up to {float(out_o[:, 3].max()):.3g}), worst parameter gradient {worst:.2e}")
+    assert max_norm_rel(out.detach().cpu(), out_o) < 2e-5 and worst < TOL_GRAD
