@@ -1172,14 +1172,15 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid);
   };
   // The lin_z term of block b, Z_b = lat Wz_b^T + bz_b, is a product of its own into a scratch buffer (d_lat is free in the forward) and
-  // enters the residual stream through the epilogue of the product that writes X[b] -- lin_in for block 0, fc_1 of block b - 1 otherwise
-  // (second residual): no accumulating product is left in the forward, so every 512 x 512 product can run in the f16x3 arithmetic with
+  // enters the residual stream through the epilogue of fc_1 of block b - 1, the product that writes X[b] (second residual; block 0: below): no accumulating product is left in the forward, so every 512 x 512 product can run in the f16x3 arithmetic with
   // its gated bf16x6 repeat.  (Without the 512-kernels: lin_z accumulates onto X[b] as before.)
   float* Z = ws + w.d_lat;
   const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, Z, kHidden, nullptr, nullptr);
-  auto lin_z = [&](int b) { return lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], Z, cols, kHidden, kLatent, false, false, nullptr, kSlotLinZ + b); };
-  if (z_sep && (rc = lin_z(0))) return rc;
-  if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, false, z_sep ? Z : nullptr))) return rc;
+  auto lin_z = [&](int b, float* dst) { return lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], dst, cols, kHidden, kLatent, false, false, nullptr, kSlotLinZ + b); };
+  // block 0: Z_0 is written straight into X[0] and lin_in (general kernel, bf16x6, runs once) accumulates onto it -- the plain instance of
+  // that kernel; its residual instance holds fewer waves per SIMD (0.77 against 0.37 ms for the 2048-ray batch)
+  if (z_sep && (rc = lin_z(0, ws + w.X[0]))) return rc;
+  if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, z_sep))) return rc;
   for (int b = 0; b < 5; ++b) {
     const long long M = b < 3 ? cols : P;
     float* X = ws + w.X[b];
@@ -1188,7 +1189,7 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     // next residual stream: X + fc_1(relu(H)); the view mean comes after block 2
     float* nx = b == 4 ? ws + w.x_last : (b == 2 ? ws + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
     const bool z_next = z_sep && b + 1 < 3;
-    if (z_next && (rc = lin_z(b + 1))) return rc;
+    if (z_next && (rc = lin_z(b + 1, Z))) return rc;
     // (the residual enters through the product's epilogue: no copy of X)
     if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b, z_next ? Z : nullptr))) return rc;
     if (b == 2)
