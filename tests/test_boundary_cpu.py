@@ -201,6 +201,34 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
         assert len([l for l in body if "scratch_" in l]) <= 16, m.group(1)
 
 
+def test_no_spill_code_in_the_training_kernels(tmp_path):
+    """Codegen guard for the 512 x 512 layer products of the training path (csrc/train_512.hip): k_run512 (three tile shapes of the bf16x6
+    forward / data-gradient body + the weight-gradient body in one kernel, one wave per SIMD at 496 registers) and k_fwd512_f16x3 carry no
+    scratch access at all, and their MFMAs are the 32 x 32 x 16 ones of the arithmetic they claim."""
+    import re
+    import shutil
+    import subprocess
+    from diner_amd import build as B
+    hipcc = B._hipcc()
+    if not (hipcc and (shutil.which(hipcc) or os.path.exists(hipcc))):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "train_512.s"
+    subprocess.check_call([hipcc] + B.FLAGS + ["-x", "hip", "-S", "--cuda-device-only",
+                                                os.path.join(B.CSRC, "train_512.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    found = {}
+    for name in ("k_run512", "k_fwd512_f16x3"):
+        m = re.search(r"^(\w*" + name + r"\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
+        assert m, name
+        body = m.group(2).split("\n")
+        assert not [l for l in body if "scratch_" in l], name
+        found[name] = body
+    assert sum("v_mfma_f32_32x32x16_bf16" in l for l in found["k_run512"]) > 1000
+    assert sum("v_mfma_f32_32x32x16_f16" in l for l in found["k_fwd512_f16x3"]) > 500
+    assert not any("v_mfma_f32_32x32x16_bf16" in l for l in found["k_fwd512_f16x3"])
+
+
 def test_bench_line_contract():
     """The committed bench line (profiles/, produced by `python bench.py` on an MI355X) carries every field of the
     driver's contract, the roofline object and the CPU baseline object."""
