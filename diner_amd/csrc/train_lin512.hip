@@ -128,17 +128,23 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const long long n_tiles = (a.M + kRows - 1) / kRows;
-  const bool relu_in = a.flags & kL512ReluIn;
+  const int relu_floor = (a.flags & kL512ReluIn) ? 0 : (int)0x80000000;
   lds_ptr lbase = (lds_ptr)smem + lane * 16;                 // lane's 16 B slot in fragment 0 of slab buffer 0
   // ---- staging share of this wave: rows [8 CT w, 8 CT (w + 1)) of the tile, all 128 contraction indices of the slab.  Request i (0..NQ-1)
   // reads rows 8 CT w + 2 i and + 1 whole: lanes 0..31 one row (512 contiguous bytes), lanes 32..63 the next -- 8 cache lines per
   // instruction (a first version read B-fragment-shaped pieces, 32 rows x 16 B per instruction: 32+ lines each, and the slab
   // staging cost 16 % of the kernel).  A lane then holds 4 consecutive k of one row: three 8-byte pieces of B fragments.
+  // Buffer loads (as in wgrad512_body): a descriptor over the tile's rows made from scalars, the lane's part of the offset in one register
+  // for the whole kernel, request and slab as the scalar offset; rows past M read as zeros (their results are never stored).
   f32x4 xst[NQ];
+  const unsigned xvoff = ((unsigned)(8 * CT * wave + (lane >> 5)) * (unsigned)a.ldx + 4u * (lane & 31)) * 4u;
   auto request_one = [&](int i, long long tile, int slab) {
-    long long row = tile * kRows + 8 * CT * wave + 2 * i + (lane >> 5);
-    if (row >= a.M) row = a.M - 1;
-    xst[i] = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + 128 * slab + 4 * (lane & 31));
+    const long long row0 = tile * kRows;
+    long long left = a.M - row0;
+    left = left < 0 ? 0 : (left > kRows ? kRows : left);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X + (size_t)row0 * a.ldx), 0,
+                                                                        (int)(left * a.ldx * 4), 0x00020000);
+    xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvoff, ((unsigned)(2 * i) * (unsigned)a.ldx + 128u * slab) * 4u, 0));
   };
   auto request_slab = [&](long long tile, int slab) {
 #pragma unroll
@@ -154,8 +160,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   auto stash_half = [&](int i, int half) {
 #pragma unroll
     for (int j = 2 * half; j < 2 * half + 2; ++j) {
-      float x = xst[i][j];
-      if (relu_in) x = fmaxf(x, 0.0f);
+      const float x = __int_as_float(max(__float_as_int(xst[i][j]), relu_floor));      // relu, or the identity (floor INT_MIN): one instruction
       if constexpr (AR == 1) {
         const unsigned bits = __float_as_uint(x) & 0x7fffffffu;
         x_max = x_max > bits ? x_max : bits;

@@ -78,26 +78,28 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
   const int g = lane >> 4, li = lane & 15;
   f32x4 xr[8];
   f32x2w yr[8];
-  const float* xbase = a.X + 256 * kt2 + 64 * wave + 4 * li;
-  const float* ybase = a.dY + 128 * ft + 32 * wave + 2 * li;
+  // Buffer loads: a descriptor per operand over the chunk's rows (base and size in scalar registers), the lane's part of the offset in one
+  // register for the whole kernel, the (slab, request) part as the scalar offset -- no vector-ALU address arithmetic per load, and rows
+  // past the chunk read as zeros through the descriptor's range check instead of a compare and six selects per row (the staging's other
+  // vector-ALU work -- addresses, selects -- was as much as the conversion it exists for).
+  const unsigned x_bytes = (unsigned)((m_end - m_begin) * (long long)a.ldx * 4), y_bytes = (unsigned)((m_end - m_begin) * (long long)a.ldy * 4);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X + (size_t)m_begin * a.ldx), 0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dY + (size_t)m_begin * a.ldy), 0, (int)y_bytes, 0x00020000);
+  const unsigned xvoff = (unsigned)(8 * g) * (unsigned)a.ldx * 4u + (unsigned)(256 * kt2 + 64 * wave + 4 * li) * 4u;
+  const unsigned yvoff = (unsigned)(8 * g) * (unsigned)a.ldy * 4u + (unsigned)(128 * ft + 32 * wave + 2 * li) * 4u;
+  typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
   auto request = [&](int j, long long m0) {                  // rows of the slab that starts at m0
-    long long row = m0 + 8 * g + j;
-    const bool ok = row < m_end;
-    if (!ok) row = m_begin;
-    f32x4 xv = *reinterpret_cast<const f32x4*>(xbase + (size_t)row * a.ldx);
-    f32x2w yv = *reinterpret_cast<const f32x2w*>(ybase + (size_t)row * a.ldy);
-    if (!ok) {                                               // rows past the chunk contribute zeros
-      xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      yv = (f32x2w){0.f, 0.f};
-    }
-    xr[j] = xv;
-    yr[j] = yv;
+    const unsigned row = (unsigned)(m0 - m_begin) + (unsigned)j;               // (+ 8 g in the lane's offset)
+    xr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, row * (unsigned)a.ldx * 4u, 0));
+    yr[j] = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(yrs, yvoff, row * (unsigned)a.ldy * 4u, 0));
   };
   // LDS slots of this lane's fragments inside a slab buffer: step s = g >> 1, lane' = column & 31 + 32 (g & 1)
   lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kWgFragsPerStep * 1024) + (32 * (g & 1)) * 16;
   // x columns 64 w + 4 li + c -> B tile 2 w + (li >> 3), lane' += 4 (li & 7) + c;   dy columns 32 w + 2 li + c -> A tile w, lane' += 2 li + c
   const int xslot = ((4 + 2 * wave + (li >> 3)) * 3) * 1024 + (4 * (li & 7)) * 16;
   const int yslot = (wave * 3) * 1024 + (2 * li) * 16;
+  const int relu_floor = a.relu_x ? 0 : (int)0x80000000;
   float rs0 = 0.0f, rs1 = 0.0f;                              // row sums of this lane's two dy columns (bias gradient)
   bf8w sp0, sp1, sp2;                                        // the lane-fragment being converted (two halves of 4 rows)
   auto split_half = [&](const float (&v)[4], int half) {
@@ -121,10 +123,8 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
     float v[4];
     if (i < 4) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float x = xr[4 * half + j][i];
-        v[j] = a.relu_x ? fmaxf(x, 0.0f) : x;
-      }
+      for (int j = 0; j < 4; ++j)             // relu as an integer maximum with a uniform floor (0, or INT_MIN = the identity): one instruction
+        v[j] = __int_as_float(max(__float_as_int(xr[4 * half + j][i]), relu_floor));
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = yr[4 * half + j][i - 4];
