@@ -295,33 +295,51 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
       });
       __syncthreads();                                       // slab buffer `buf` is free, the next one is complete
     }
-    // ---- epilogue: D layout of a 32 x 32 tile: lane holds row (of x) = lane & 31, features 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+    // ---- epilogue: D layout of a 32 x 32 tile: lane holds row (of x) = lane & 31, features 8 (e >> 2) + 4 (lane >> 5) + (e & 3).
+    // One 32-row half at a time into registers (the weight ring's are free here), then one pass per optional term -- a branch per term and
+    // half, not one per term and four values (130 uniform branches per tile as first written).
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const long long row = tile * kRows + 32 * ct + (lane & 31);
       if (row >= a.M) continue;
+      constexpr int NV = 4 * NRT;
+      f32x4 v[NV];
+      const size_t at0 = (size_t)row * a.ldy + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);        // + 32 rt + 8 q4
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const int f = 128 * wslice + 32 * (rt0 + rt) + 8 * q4 + 4 * (lane >> 5);
-          f32x4 v;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = acc[rt][ct][4 * q4 + c];
-          if constexpr (AR == 1) v *= kF16InvScale;
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + f);
-          const size_t at = (size_t)row * a.ldy + f;
-          if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + at);
-          if (a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + at);
-          if (a.mask) {
-            const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + at);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = m[c] > 0.0f ? v[c] : 0.0f;
-          }
-          f32x4* dst = reinterpret_cast<f32x4*>(a.Y + at);
-          if (a.flags & kL512Accum) v += *dst;
-          *dst = v;
+          for (int c = 0; c < 4; ++c) v[4 * rt + q4][c] = acc[rt][ct][4 * q4 + c];
+          if constexpr (AR == 1) v[4 * rt + q4] *= kF16InvScale;
         }
+      if (a.bias) {
+        const float* bp = a.bias + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(bp + 32 * (n >> 2) + 8 * (n & 3));
+      }
+      if (a.resid) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.resid + at0 + 32 * (n >> 2) + 8 * (n & 3));
+      }
+      if (a.resid2) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.resid2 + at0 + 32 * (n >> 2) + 8 * (n & 3));
+      }
+      if (a.mask) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + at0 + 32 * (n >> 2) + 8 * (n & 3));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[n][c] = m[c] > 0.0f ? v[n][c] : 0.0f;
+        }
+      }
+      if (a.flags & kL512Accum) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3));
+      }
+#pragma unroll
+      for (int n = 0; n < NV; ++n) *reinterpret_cast<f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3)) = v[n];
     }
   }
   if constexpr (AR == 1) {                                   // an operand beyond the fp16 range (or not finite): the caller's bf16x6 launch recomputes
