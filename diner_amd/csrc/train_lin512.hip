@@ -49,6 +49,24 @@ __device__ __forceinline__ void split3x8(const float (&v)[8], bf8& p0, bf8& p1, 
   }
 }
 
+// f16x3 staging in single full-rate instructions (the idiom of the inference kernels' operand conversion, mlp_h3n.hip): two values ->
+// one packed fp16 word, the residuals x - float(half) by v_fma_mix_f32 reading the half in place
+__device__ __forceinline__ unsigned cvt_pk_f16_w(float a, float b) {
+  unsigned d;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float resid_lo_w(unsigned h, float v) {       // v - float(low half of h)
+  float d;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(v));
+  return d;
+}
+__device__ __forceinline__ float resid_hi_w(unsigned h, float v) {       // v - float(high half of h)
+  float d;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(v));
+  return d;
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -156,20 +174,28 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   const int k4 = 4 * (lane & 31);
   const int st_off = ((k4 >> 4) * CT * NP) * 1024 + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
   bf4 sp0, sp1, sp2;                                         // the request being converted (two halves, see the slab loop)
-  unsigned x_max = 0;                                        // AR = 1: largest |x| staged by this lane, as bits
+  unsigned x_max = 0;                                        // AR = 1: packed running maximum of the |hi| halves this lane has produced
   auto stash_half = [&](int i, int half) {
+    if constexpr (AR == 1) {
+      // two values -> one hi word, one lo word; the halves are watched instead of the fp32 values: a half that is inf (0x7c00) or NaN
+      // is an operand that left the fp16 range
+      const float x0 = __int_as_float(max(__float_as_int(xst[i][2 * half]), relu_floor));
+      const float x1 = __int_as_float(max(__float_as_int(xst[i][2 * half + 1]), relu_floor));
+      const unsigned h = cvt_pk_f16_w(x0, x1);
+      const unsigned l = cvt_pk_f16_w(resid_lo_w(h, x0), resid_hi_w(h, x1));
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      x_max = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, x_max), __builtin_bit_cast(us2, h & 0x7fff7fffu)));
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      u2 w0 = __builtin_bit_cast(u2, sp0), w1 = __builtin_bit_cast(u2, sp1);
+      w0[half] = h;
+      w1[half] = l;
+      sp0 = __builtin_bit_cast(bf4, w0);
+      sp1 = __builtin_bit_cast(bf4, w1);
+      return;
+    }
 #pragma unroll
     for (int j = 2 * half; j < 2 * half + 2; ++j) {
       const float x = __int_as_float(max(__float_as_int(xst[i][j]), relu_floor));      // relu, or the identity (floor INT_MIN): one instruction
-      if constexpr (AR == 1) {
-        const unsigned bits = __float_as_uint(x) & 0x7fffffffu;
-        x_max = x_max > bits ? x_max : bits;
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)(x - (float)h);
-        sp0[j] = __builtin_bit_cast(__bf16, h);
-        sp1[j] = __builtin_bit_cast(__bf16, l);
-        continue;
-      }
       const __bf16 a0 = (__bf16)x;
       const float r1 = x - (float)a0;
       const __bf16 a1 = (__bf16)r1;
@@ -343,7 +369,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
     }
   }
   if constexpr (AR == 1) {                                   // an operand beyond the fp16 range (or not finite): the caller's bf16x6 launch recomputes
-    if (a.ovf && x_max >= 0x477fe000u) *a.ovf = 1;           // (65504: from there on the conversion may round to inf)
+    if (a.ovf && ((x_max & 0xffffu) >= 0x7c00u || (x_max >> 16) >= 0x7c00u)) *a.ovf = 1;      // a hi half was inf or NaN
   }
 }
 
