@@ -533,21 +533,24 @@ __global__ __launch_bounds__(256) void k_scatter_latent(const float* __restrict_
   }
 }
 
-// The same adjoint with the taps of 64 consecutive columns merged in LDS first: consecutive columns are samples along a ray in one view,
-// their bilinear taps fall on a few dozen texels of the epipolar segment, and the 42 M atomics of the reference batch (200 us, 5 % of the
-// step; 3.2 ms of the 2048-ray step) become one atomic per distinct texel and channel.  A workgroup finds the distinct texels of its 256
-// taps (first occurrence = leader, compacted by a block prefix sum), accumulates w * d_lat into a (slot, channel) table -- a thread owns two
-// channels, so the read-modify-writes need no atomics -- and flushes the table.  Texels beyond the table go out directly.
+// The same adjoint with the taps of 64 consecutive columns merged first: consecutive columns are samples along a ray in one view, their
+// bilinear taps fall on a few dozen texels of the epipolar segment, and the 42 M atomics of the reference batch (200 us, 5 % of the step;
+// 3.2 ms of the 2048-ray step) become one atomic per distinct texel and channel.  A workgroup (1) finds the distinct texels of its 256 taps
+// (first occurrence = leader, compacted by a block prefix sum) and sorts the taps by texel (counting sort in LDS), (2) brings its 64 x 512
+// block of d_lat into LDS, (3) per distinct texel sums w * d_lat over that texel's taps -- a thread owns two channels, independent LDS
+// reads, no read-modify-write chain (a first version accumulated into a (slot, channel) table in LDS: one dependent LDS round trip per tap)
+// -- and adds the sum to the texel with one atomic per channel.
+constexpr int kScatCols = 64;
 typedef float f32x2s __attribute__((ext_vector_type(2)));
-constexpr int kScatCols = 64, kScatSlots = 56;
 __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __restrict__ d_lat, const int* __restrict__ tap_row,
                                                                const float* __restrict__ tap_w, long long cols,
                                                                float* __restrict__ d_latent_cl) {
   extern __shared__ __attribute__((aligned(16))) char smem_scat[];
-  f32x2s* acc = reinterpret_cast<f32x2s*>(smem_scat);                            // [kScatSlots][256] pairs of channels
-  __shared__ int s_id[256], s_uniq[kScatSlots], s_wave_n[4];
-  __shared__ float s_w[256];
-  __shared__ short s_lead_slot[256], s_slot[256];
+  f32x2s* dl = reinterpret_cast<f32x2s*>(smem_scat);                             // [kScatCols][256] pairs of channels
+  __shared__ int s_id[256], s_uniq[256], s_start[257], s_fill[256], s_wave_n[4];
+  __shared__ float s_w[256], s_tw[256];
+  __shared__ short s_lead_slot[256];
+  __shared__ unsigned char s_tcol[256];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long long col0 = (long long)blockIdx.x * kScatCols;
   const long long mycol = col0 + (t >> 2);
@@ -560,8 +563,13 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   }
   s_id[t] = id;
   s_w[t] = w;
-  for (int i = t; i < kScatSlots * 256; i += 256) acc[i] = (f32x2s){0.f, 0.f};
+  s_fill[t] = 0;
+  // (2) the block of d_lat, 64 rows of 2 KB (rows past the end: never referenced)
+  const long long last = cols - col0 < kScatCols ? cols - col0 : kScatCols;
+  for (int g = 0; g < (int)last; ++g)
+    dl[g * 256 + t] = *reinterpret_cast<const f32x2s*>(d_lat + (size_t)(col0 + g) * kLatent + 2 * t);
   __syncthreads();
+  // (1) leaders, slots
   int leader = t;
   if (id >= 0)
     for (int j = 0; j < t; ++j)
@@ -573,36 +581,40 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   int before = __popcll(ball & ((1ull << lane) - 1));
   for (int i = 0; i < wave; ++i) before += s_wave_n[i];
   if (is_leader) {
-    s_lead_slot[t] = before < kScatSlots ? (short)before : (short)-2;
-    if (before < kScatSlots) s_uniq[before] = id;
+    s_lead_slot[t] = (short)before;
+    s_uniq[before] = id;
   }
+  const int n_unique = s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
   __syncthreads();
-  s_slot[t] = id >= 0 ? s_lead_slot[leader] : (short)-1;
-  int n_unique = s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
-  if (n_unique > kScatSlots) n_unique = kScatSlots;
+  const int slot = id >= 0 ? (int)s_lead_slot[leader] : -1;
+  if (slot >= 0) atomicAdd(&s_fill[slot], 1);               // taps per texel
   __syncthreads();
-  const long long last = cols - col0 < kScatCols ? cols - col0 : kScatCols;
-  for (int g = 0; g < (int)last; ++g) {
-    const f32x2s d = *reinterpret_cast<const f32x2s*>(d_lat + (size_t)(col0 + g) * kLatent + 2 * t);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int sl = s_slot[4 * g + k];
-      if (sl == -1) continue;
-      const float wk = s_w[4 * g + k];
-      if (sl >= 0) {
-        f32x2s a = acc[sl * 256 + t];
-        a[0] = fmaf(wk, d[0], a[0]);
-        a[1] = fmaf(wk, d[1], a[1]);
-        acc[sl * 256 + t] = a;
-      } else {
-        float* dst = d_latent_cl + (size_t)s_id[4 * g + k] * kLatent + 2 * t;
-        atomicAdd(dst, wk * d[0]);
-        atomicAdd(dst + 1, wk * d[1]);
-      }
+  if (t == 0) {                                              // exclusive prefix over <= 256 counts (a few hundred cycles once per workgroup)
+    int run = 0;
+    for (int i = 0; i < n_unique; ++i) {
+      s_start[i] = run;
+      run += s_fill[i];
+      s_fill[i] = 0;
     }
+    s_start[n_unique] = run;
   }
+  __syncthreads();
+  if (slot >= 0) {
+    const int at = s_start[slot] + atomicAdd(&s_fill[slot], 1);
+    s_tcol[at] = (unsigned char)(t >> 2);
+    s_tw[at] = w;
+  }
+  __syncthreads();
+  // (3) one sum and one atomic per distinct texel and channel
   for (int sl = 0; sl < n_unique; ++sl) {
-    const f32x2s a = acc[sl * 256 + t];
+    const int b = s_start[sl], e = s_start[sl + 1];
+    f32x2s a = {0.f, 0.f};
+    for (int i = b; i < e; ++i) {
+      const f32x2s d = dl[(int)s_tcol[i] * 256 + t];
+      const float wk = s_tw[i];
+      a[0] = fmaf(wk, d[0], a[0]);
+      a[1] = fmaf(wk, d[1], a[1]);
+    }
     float* dst = d_latent_cl + (size_t)s_uniq[sl] * kLatent + 2 * t;
     atomicAdd(dst, a[0]);
     atomicAdd(dst + 1, a[1]);
@@ -615,7 +627,7 @@ int scatter_latent_launch(const float* d_lat, const int* tap_row, const float* t
     int dev = 0;
     DINER_HIP_OK(hipGetDevice(&dev));
     dev &= 63;
-    constexpr int lds = kScatSlots * 256 * (int)sizeof(f32x2s);
+    constexpr int lds = kScatCols * 256 * (int)sizeof(f32x2s);      // the 64 x 512 block of d_lat: 128 KB
     if (!attr_set[dev].load()) {
       DINER_HIP_OK(hipFuncSetAttribute((const void*)k_scatter_latent_merged, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       attr_set[dev].store(1);
