@@ -1189,10 +1189,12 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
   float* Z = ws + w.d_lat;
   const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, Z, kHidden, nullptr, nullptr);
   auto lin_z = [&](int b, float* dst) { return lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], dst, cols, kHidden, kLatent, false, false, nullptr, kSlotLinZ + b); };
-  // block 0: Z_0 is written straight into X[0] and lin_in (general kernel, bf16x6, runs once) accumulates onto it -- the plain instance of
-  // that kernel; its residual instance holds fewer waves per SIMD (0.77 against 0.37 ms for the 2048-ray batch)
-  if (z_sep && (rc = lin_z(0, ws + w.X[0]))) return rc;
-  if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, ws + w.X[0], cols, kHidden, kDIn, false, z_sep))) return rc;
+  // block 0: lin_in (general kernel, plain instance, runs once) writes into the scratch buffer and the lin_z product of block 0 takes it as its
+  // residual: X[0] = lat Wz_0^T + bz_0 + lin_in(feat).  (lin_in accumulating onto a Z_0 written first cost 0.88 ms for the 2048-ray batch --
+  // it re-reads and re-writes X[0] -- against 0.37 ms plain; the product's residual pass adds 0.14 ms; the kernel's residual instance holds
+  // fewer waves per SIMD: 0.77 ms.)
+  if ((rc = lin(ws + w.feat, kDInPad, p->lin_in_w, p->lin_in_b, z_sep ? Z : ws + w.X[0], cols, kHidden, kDIn, false, false))) return rc;
+  if (z_sep && (rc = lin(ws + w.lat, kLatent, p->lin_z_w[0], p->lin_z_b[0], ws + w.X[0], cols, kHidden, kLatent, false, false, Z, kSlotLinZ + 0))) return rc;
   for (int b = 0; b < 5; ++b) {
     const long long M = b < 3 ? cols : P;
     float* X = ws + w.X[b];
