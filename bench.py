@@ -2,8 +2,9 @@
 """bench.py -- rendered rays/s of the MI355X-native DINER renderer (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 20 --warmup 2          # launches its own 8 ranks (one per GPU, RCCL over xGMI)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W           # the same ranks under an external launcher
 
 Workload (BASELINE.json north_star / configs[2]-shaped, synthetic): 4-source-view scene, 800x600 source and target
 images, 128 samples/ray (48 gaussian, 1000 depth candidates), fp32 results, random-init MLP of the trained DINER
@@ -12,15 +13,28 @@ per-scene projection of the latent (lin_z hoist) -> ray generation -> depth-guid
 encoding / MLP -> compositing -> assembly of the (rgb, depth) image on rank 0.  Inputs (feature maps, depth / std /
 normal maps, cameras, weights) are resident in HBM before the timed region; nothing is cached across steps.
 
-With N GPUs the SAME frame is sharded (BASELINE configs[3]): rank r generates and renders the contiguous ray range
+With N GPUs the SAME frame is sharded (BASELINE configs[3]; the build's replacement of the serial ray-batch loop of the
+reference's src/models/diner.py:85-92): rank r generates and renders the contiguous ray range
 diner_amd.render.shard_range(H*W, r, N) and one RCCL gather per frame brings the 16 B/ray tiles to rank 0 -- "strong"
 scaling, value = 480,000 rays x steps / max-over-ranks time.  Scene state is replicated, so every rank repeats the
 per-scene hoist (that, the ragged last shard and the gather are inside the timed region).
 
+`--gpus N` without a launcher's WORLD_SIZE in the environment starts the N ranks itself (one child process per rank,
+rendezvous on 127.0.0.1 and a free port); the parent's stdout carries exactly rank 0's JSON line and its exit status is
+non-zero when any rank failed.  After the timed region an N-rank run renders one more frame with a fixed seed and rank 0
+compares the gathered frame BIT FOR BIT with the same frame rendered by itself alone (`frame_check`; a ray's noise is keyed by
+(frame seed, index of the ray in the frame), so the frame cannot depend on the number of ranks): the first run on a
+multi-GPU node is a parity test of the sharded path as well.  `dist` in the line records what the process group was:
+world size, backend, RCCL version, the device of every rank.
+
 The JSON line also carries
   roofline      the dominant kernel (per-view MLP part, ~86 % of the time): executed MFMA FLOP / HIP-event duration
                 measured in this run, against the dense MFMA peak of the dtype the products are issued in
-  modes         rays/s of one extra timed frame in each other arithmetic mode (exact fp32; plain fp16 operands)
+  modes         the same frame in each other arithmetic mode (exact fp32; plain fp16 operands): median of 3 timed frames,
+                each entry with its own roofline figures
+  configs       the other single-GPU BASELINE configurations (400x300; 1024x1024 K=192 in f16 and f16x3) and the 800x600
+                frame rendered THROUGH THE DROP-IN MODULES at the reference's call granularity (118 renderer.forward
+                calls of 4096 rays, diner.py:85): median of 3 timed frames each, with roofline figures
   cpu_baseline  the CPU oracle (torch restatement of the reference renderer, pinned bit-exact against it) timed on the
                 host cores of the same box: 4096 rays of the same frame, one warm-up at size + 3 timed repeats (rank 0,
                 N = 1 only).
@@ -29,19 +43,21 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0      # same guide, dense fp16/bf16 matrix peak (AMD's 5 PF figure is 2:1 sparse)
+CHECK_SEED = 0x5EED0F0F            # frame seed of the sharded-vs-single frame check
+CHILD_ENV = "DINER_BENCH_CHILD"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -57,10 +73,16 @@ def parse():
                     help="every rank renders its own full frame (weak scaling) instead of sharding one frame")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU baseline sample (0 disables)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
-    ap.add_argument("--no-modes", action="store_true", help="skip the extra one-frame passes in the other arithmetic modes")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra passes in the other arithmetic modes")
     ap.add_argument("--no-configs", action="store_true",
-                    help="skip the extra one-frame passes of the other single-GPU BASELINE configs (400x300; 1024x1024 K=192 f16 / f16x3)")
+                    help="skip the extra passes of the other single-GPU BASELINE configs (400x300; 1024x1024 K=192 f16 / f16x3; "
+                         "800x600 through the drop-in modules)")
+    ap.add_argument("--extra-steps", type=int, default=3, help="timed frames (median) of every modes / configs entry")
     ap.add_argument("--ray-batch", type=int, default=8192, help="rays per launch group (bounds the workspace)")
+    ap.add_argument("--via-modules", action="store_true",
+                    help="headline measured through the drop-in modules: src.models.* built by import_obj, "
+                         "diner_amd.render.predict_image with --module-ray-batch rays per renderer.forward call (diner.py:85)")
+    ap.add_argument("--module-ray-batch", type=int, default=4096, help="ray_batch_size of the module path (diner.py:57)")
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="single-GPU measurement aid: render only the ray range rank R of an N-way sharded frame would render "
                          "(no process group, no gather); the line then reports that shard's time and the frame rate N such "
@@ -72,9 +94,13 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives of the N-rank path even with ONE rank (a 1-GPU box can "
                          "then exercise RCCL itself: communicator creation, barrier, gather, all-reduce on device tensors)")
+    ap.add_argument("--check-frame", dest="check_frame", action="store_true", default=None,
+                    help="after the timed region render one frame with a fixed seed sharded and once more on rank 0 alone; compare bit "
+                         "for bit (default: on for N > 1; with one rank the shards are emulated as 8 ray ranges rendered in turn)")
+    ap.add_argument("--no-check-frame", dest="check_frame", action="store_false")
     ap.add_argument("--precision", choices=["f16x3", "fp32", "f16"], default=None,
                     help="MLP GEMM arithmetic of the headline number (default: the library default, f16x3)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def kernel_source_digest():
@@ -86,14 +112,74 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
+# ---- self-launch: `python bench.py --gpus N` starts its own N ranks -------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """One child process per rank (env RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_*: the variables
+    torch.distributed.run would set), rank 0's stdout piped back and re-printed, every other rank's stdout on stderr.
+    -> exit status: 0 when every rank returned 0, else the first non-zero status (remaining ranks are terminated)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), CHILD_ENV: "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: the only mode the host driver supports
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), stderr=None))
+    rc = 0
+    alive = set(range(n))
+    out0 = b""
+    try:
+        while alive:
+            for r in sorted(alive):
+                if r == 0:
+                    try:                                   # drain rank 0's pipe while waiting (it carries one line)
+                        o, _ = procs[0].communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in alive:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lines = [l for l in out0.decode("utf-8", "replace").splitlines() if l.strip()]
+    for l in lines:
+        print(l, flush=True)
+    if rc == 0 and not any(l.lstrip().startswith("{") for l in lines):
+        print("bench.py: rank 0 produced no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get(CHILD_ENV):
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to measure")
     if args.emulate_shard and (args.weak or world > 1):
@@ -126,8 +212,8 @@ def main():
         dist.barrier()
 
     from diner_amd import ops
-    from diner_amd.render import shard_range, gather_tiles
-    from diner_amd.synthetic import make_scene, make_mlp_state_dict, look_at_extrinsics
+    from diner_amd.render import shard_range, gather_tiles, predict_image
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict, look_at_extrinsics, build_modules
 
     if args.precision:
         ops.set_precision(args.precision)
@@ -135,8 +221,9 @@ def main():
     names = {ops.PRECISION_FP32: "fp32", ops.PRECISION_F16X3: "f16x3", ops.PRECISION_F16: "f16"}
     msd = make_mlp_state_dict()
     mlp = ops.HipMlp({k: v.to(dev) for k, v in msd.items()})
+    n_cand = args.candidates
 
-    def workload(W, H, K, facescape, white, lo_hi=None):
+    def workload(W, H, K, facescape, white, lo_hi=None, via_modules=False):
         """Scene resident in HBM + the per-frame step of one configuration -> dict(step, out, frame, ...)."""
         G = int(15 * K / 40)                           # create_prediction_folder.py:44-47
         scene_kw = dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape") if facescape else {}
@@ -144,10 +231,6 @@ def main():
         Kin = sc["src_intrinsics"]
         depths = sc["depths"].to(dev)
         normals = ops.depth2normal(depths, Kin.to(dev))                     # encode-side prep (row f2), not timed
-        scene = ops.HipScene(sc["latent"].to(dev), depths, sc["depths_std"].to(dev), normals,
-                             sc["src_extrinsics"], Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"],
-                             sc["feature_padding"])
-        del sc["latent"]
         NRF = W * H
         s_ = scene_kw.get("scale", 1.0)
         if args.weak:       # every rank renders its own target view of the same scene
@@ -157,21 +240,60 @@ def main():
             tgt = sc["target_extrinsics"]
             lo, hi = lo_hi(NRF) if lo_hi else shard_range(NRF, rank, world)
         tgt_E, tgt_K = tgt[None].contiguous(), sc["target_intrinsics"][None].contiguous()
-        out = torch.empty(hi - lo, 4, device=dev)      # packed (rgb, depth) tile of this rank
         frame = [None]
+        res = dict(frame=frame, sc=sc, normals=normals, Kin=Kin, NRF=NRF, lo=lo, hi=hi, G=G, scene_kw=scene_kw)
+
+        if via_modules:
+            # The product at the API it claims: PixelNeRF / NeRFRendererDGS built through import_obj (diner.py:47-48), the scene
+            # injected into the encoder, predict_image = predict_imgs_from_batch's loop (diner.py:79-92): torch.split of the ray list
+            # into ray_batch_size = 4096 (diner.py:57) and one renderer.forward per batch -- 118 calls per 800x600 frame.
+            nerf, R = build_modules(sc, msd, dev, normals=normals)
+            del sc["latent"]
+            ren = R(n_samples=40, n_depth_candidates=n_cand, n_gaussian=15, white_bkgd=white)
+            ren.n_samples, ren.n_gaussian = K, G                            # create_prediction_folder.py:44-47
+            tE, tK = tgt_E.to(dev), tgt_K.to(dev)
+            grp = dist.group.WORLD if (multi and not args.weak) else None
+
+            def step(seed, precision, max_rays=None):
+                ops.set_precision(precision)
+                try:
+                    nerf.hip_scene(0).prepare(nerf.hip_mlp(), force=True)   # the hoist belongs to the frame (see below)
+                    if max_rays is not None:                                # warm-up on the first rays only
+                        with torch.no_grad():
+                            rr = ops.gen_rays(tE, tK, W, H, sc["znear"], sc["zfar"], dev, ray0=0, n_rays=min(NRF, max_rays))
+                            ren.forward(nerf, rr)
+                        return
+                    rgb, depth = predict_image(nerf, ren, tE, tK, W, H, sc["znear"], sc["zfar"], ray_batch_size=args.module_ray_batch,
+                                               rank=rank if grp is not None else 0, world=world if grp is not None else 1, group=grp, seed=seed)
+                    if rgb is not None:
+                        frame[0] = torch.cat((rgb[0].permute(1, 2, 0).reshape(NRF, 3), depth[0].reshape(NRF, 1)), dim=1)
+                finally:
+                    ops.set_precision(head)
+            res.update(step=step, out=None, scene=nerf.hip_scene(0), nerf=nerf)
+            return res
+
+        scene = ops.HipScene(sc["latent"].to(dev), depths, sc["depths_std"].to(dev), normals,
+                             sc["src_extrinsics"], Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"],
+                             sc["feature_padding"])
+        del sc["latent"]
+        out = torch.empty(hi - lo, 4, device=dev)      # packed (rgb, depth) tile of this rank
+
+        def render_range(a, b, seed, precision, dst):
+            """rays [a, b) of the frame -> dst (b - a, 4); ray generation, sampling, field, compositing."""
+            rays = ops.gen_rays(tgt_E, tgt_K, W, H, sc["znear"], sc["zfar"], dev, ray0=a, n_rays=b - a)[0]
+            for r0 in range(0, b - a, args.ray_batch):
+                r = rays[r0:r0 + args.ray_batch]
+                z = ops.sample_depthguided(scene, r, K, n_cand, G, 0.05, noise=None, seed=seed, ray_index0=a + r0)   # one key per frame
+                _, rgb, depth = ops.render(scene, mlp, r, z, white_bkgd=white, want_weights=False, precision=precision)
+                dst[r0:r0 + args.ray_batch, :3] = rgb
+                dst[r0:r0 + args.ray_batch, 3] = depth
 
         def step(seed, precision, max_rays=None):
             # per-scene preparation (projection of the latent through lin_z[0..2], DESIGN.md section 4) is redone every
             # frame inside the timed region, so that no cached per-scene output is excluded from the measurement
             scene.prepare(mlp, force=True)
             n = hi - lo if max_rays is None else min(hi - lo, max_rays)
-            rays = ops.gen_rays(tgt_E, tgt_K, W, H, sc["znear"], sc["zfar"], dev, ray0=lo, n_rays=n)[0]
-            for r0 in range(0, n, args.ray_batch):
-                r = rays[r0:r0 + args.ray_batch]
-                z = ops.sample_depthguided(scene, r, K, n_cand, G, 0.05, noise=None, seed=seed, ray_index0=lo + r0)   # one key per frame
-                _, rgb, depth = ops.render(scene, mlp, r, z, white_bkgd=white, want_weights=False, precision=precision)
-                out[r0:r0 + args.ray_batch, :3] = rgb
-                out[r0:r0 + args.ray_batch, 3] = depth
+            render_range(lo, lo + n, seed, precision, out)
             if multi and not args.weak:
                 frame[0] = gather_tiles(out, NRF, rank, world, force=args.force_dist)   # one RCCL gather of the rendered tiles per frame
             elif multi:
@@ -180,17 +302,16 @@ def main():
                 dist.gather(src, gat, dst=0)
             else:
                 frame[0] = out
-        return dict(step=step, out=out, frame=frame, sc=sc, scene=scene, normals=normals, Kin=Kin, NRF=NRF, lo=lo, hi=hi, G=G,
-                    scene_kw=scene_kw)
+        res.update(step=step, out=out, scene=scene, render_range=render_range)
+        return res
 
     W, H, K = args.width, args.height, args.samples
-    n_cand = args.candidates
     white = bool(args.white_bkgd or args.facescape)
     lo_hi = None
     if args.emulate_shard:
         er, en = (int(x) for x in args.emulate_shard.split("/"))
         lo_hi = lambda n: shard_range(n, er, en)
-    wl_head = workload(W, H, K, args.facescape, white, lo_hi)
+    wl_head = workload(W, H, K, args.facescape, white, lo_hi, via_modules=args.via_modules)
     step, out, frame, sc, scene, normals, Kin = (wl_head[k] for k in ("step", "out", "frame", "sc", "scene", "normals", "Kin"))
     NRF, lo, hi, G = (wl_head[k] for k in ("NRF", "lo", "hi", "G"))
 
@@ -219,41 +340,119 @@ def main():
             el = float(t.item())
         return el, prof
 
+    def mode_facts(m):
+        """(kernel name, MFMA products issued per fp32 product, peak TFLOP/s, dtype label) of arithmetic mode m."""
+        if m == ops.PRECISION_F16X3:
+            return "k_field_pre_h3n<true>", 3, PEAK_F16_MFMA_TFLOPS, "f16 (3 MFMA products per fp32 product, fp32 accumulate)"
+        if m == ops.PRECISION_F16:
+            return "k_field_pre_h3n<false>", 1, PEAK_F16_MFMA_TFLOPS, "f16 operands, fp32 accumulate (reduced precision: ~1e-3, outside the parity bar)"
+        return "k_field_pre", 1, PEAK_FP32_MFMA_TFLOPS, "f32"
+
+    def roof(m, prof, wall_s):
+        """Roofline figures of one measured run: the per-view kernel from its HIP-event time, the whole path from the wall time."""
+        kname, mult, peak, label = mode_facts(m)
+        pre_s = prof["pre_ms"] * 1e-3
+        ach = prof["points"] * ops.FLOP_PRE_PER_POINT * mult / pre_s / 1e12 if pre_s > 0 else 0.0
+        path = prof["points"] * (ops.FLOP_PRE_PER_POINT + ops.FLOP_POST_PER_POINT) * mult / wall_s / 1e12
+        return {"bound": "mfma", "kernel": kname, "mfma_dtype": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "launches": prof["launches"],
+                "avg_launch_ms": round(prof["pre_ms"] / max(prof["launches"], 1), 3),
+                "points_per_launch": round(prof["points"] / max(prof["launches"], 1)),
+                "whole_path_achieved": round(path, 2), "whole_path_frac": round(path / peak, 4)}
+
+    def measure(stepf, m, rays, n):
+        """median-of-n timed frames of `stepf` in mode m (each frame bracketed by barrier + synchronize) + roofline figures."""
+        sync()
+        ops.profile_enable(True)
+        ops.profile_collect()
+        ts = []
+        for i in range(n):
+            el, _ = timed(1, m, 7 + i, step=stepf)
+            ts.append(el)
+        prof = ops.profile_collect()
+        ops.profile_enable(False)
+        med = sorted(ts)[len(ts) // 2]
+        return {"rays_per_s": round(rays / med, 1), "ms_per_step": round(med * 1e3, 2), "steps": n,
+                "ms_all": [round(t * 1e3, 2) for t in ts], "mode": names[m], "roofline": roof(m, prof, sum(ts))}
+
     for i in range(args.warmup):
         step(i, head)
     elapsed, prof = timed(args.steps, head, args.warmup, profile=True)
     if not os.environ.get("DINER_AMD_LIB"):        # (timing experiments with ablated libraries produce garbage)
-        assert torch.isfinite(out).all(), "non-finite render output"
+        if out is not None:
+            assert torch.isfinite(out).all(), "non-finite render output"
         if rank == 0 and not args.weak and not args.emulate_shard:
             assert frame[0].shape == (NRF, 4) and torch.isfinite(frame[0]).all()
 
     rays_per_step = NRF * (world if args.weak else 1)
     if args.emulate_shard:
         rays_per_step = hi - lo
-    scene_kw = wl_head["scene_kw"]
     rays_per_s = rays_per_step * args.steps / elapsed
 
-    # ---- the other arithmetic modes: one extra timed frame each ------------------------------------------
+    # ---- sharded frame == single-rank frame (bit for bit) -----------------------------------------------------------------------
+    frame_check = None
+    do_check = args.check_frame if args.check_frame is not None else (world > 1)
+    if do_check and not args.weak and not args.emulate_shard and not args.via_modules:
+        rr = wl_head["render_range"]
+        if world > 1 or args.force_dist:
+            step(CHECK_SEED, head)                      # every rank its range + the gather
+            sync()
+            how = f"{world} ranks ({backend}) + gather"
+            sharded = frame[0].clone() if rank == 0 else None
+        else:
+            n_em = 8                                    # one rank: the 8 ray ranges of an 8-way shard rendered in turn
+            sharded = torch.empty(NRF, 4, device=dev)
+            scene.prepare(mlp, force=True)
+            for r in range(n_em):
+                a, b = shard_range(NRF, r, n_em)
+                rr(a, b, CHECK_SEED, head, sharded[a:b])
+            how = f"{n_em} ray ranges rendered in turn by one rank (emulation)"
+        if rank == 0:
+            single = torch.empty(NRF, 4, device=dev)
+            scene.prepare(mlp, force=True)
+            rr(0, NRF, CHECK_SEED, head, single)
+            torch.cuda.synchronize()
+            sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16]
+            frame_check = {"bit_equal": bool(torch.equal(sharded, single)), "sharded": how, "seed": CHECK_SEED,
+                           "sha256_sharded": sha(sharded), "sha256_single_rank": sha(single),
+                           "max_abs_diff": float((sharded - single).abs().max().item())}
+            del single, sharded
+        sync()
+
+    # ---- who took part (answerable from the line alone: did RCCL see N ranks, which devices) ----------------------------------
+    dist_info = None
+    if multi:
+        pr = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "local_rank": local_rank, "device": dev.index, "name": pr.name,
+              "pci_bus_id": getattr(pr, "pci_bus_id", None), "uuid": str(getattr(pr, "uuid", "")) or None, "pid": os.getpid()}
+        infos = [None] * world
+        dist.all_gather_object(infos, me)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        dist_info = {"world_size": dist.get_world_size(), "backend": str(dist.get_backend()), "rccl_version": rccl,
+                     "devices_visible_per_rank": n_dev, "distinct_devices": len({(i["device"], i["pci_bus_id"]) for i in infos}),
+                     "ranks": infos, "launcher": "bench.py self-launch" if os.environ.get(CHILD_ENV) else "external (torch.distributed.run)"}
+
+    # ---- the other arithmetic modes ------------------------------------------------------------------------------------------
     modes = {}
     if not args.no_modes:
         for m in (ops.PRECISION_FP32, ops.PRECISION_F16X3, ops.PRECISION_F16):
             if m == head:
                 continue
             step(0, m)                              # warm-up (first launch of that kernel family)
-            el, _ = timed(1, m, 99)
-            modes[names[m]] = {"rays_per_s": round(rays_per_step / el, 1), "ms_per_step": round(el * 1e3, 2),
-                               "steps": 1, "parity": "outside the 1e-4 bar (~1e-3), BASELINE configs[4] only"
-                               if m == ops.PRECISION_F16 else "1e-4 bar (same tests as the headline mode)"}
+            e = measure(step, m, rays_per_step, max(1, args.extra_steps))
+            e["parity"] = ("outside the 1e-4 bar (~1e-3), BASELINE configs[4] only" if m == ops.PRECISION_F16
+                           else "1e-4 bar (same tests as the headline mode)")
+            modes[names[m]] = e
 
     # ---- roofline of the dominant kernel (this rank's launches, HIP events on the launch stream) ----------
     h3 = head == ops.PRECISION_F16X3
     f16 = head == ops.PRECISION_F16
-    pre_kernel = "k_field_pre" if head == ops.PRECISION_FP32 else ("k_field_pre_h3n<true>" if h3 else "k_field_pre_h3n<false>")
+    pre_kernel, mfma_per_product, peak, _ = mode_facts(head)
+    rf = roof(head, prof, elapsed)
     pre_s = prof["pre_ms"] * 1e-3
-    mfma_per_product = 3 if h3 else 1               # f16x3: every fp32 product is three fp16 MFMA products
-    flop_pre = prof["points"] * ops.FLOP_PRE_PER_POINT * mfma_per_product
-    peak = PEAK_F16_MFMA_TFLOPS if (h3 or f16) else PEAK_FP32_MFMA_TFLOPS
-    achieved = flop_pre / pre_s / 1e12 if pre_s > 0 else 0.0
     fp32_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT / pre_s / 1e12 if pre_s > 0 else 0.0
     ref_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT_REFERENCE / pre_s / 1e12 if pre_s > 0 else 0.0
     # HBM traffic per launch: bytes/point from the rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE x2 +
@@ -263,16 +462,14 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             pmc = json.load(f)
-        ent = pmc.get(pre_kernel)
+        ent = pmc.get(f"{pre_kernel} @ {W}x{H}x{K}") or pmc.get(pre_kernel)
         if ent and ent.get("source_digest") == kernel_source_digest() and ent.get("workload") == f"{W}x{H}x{K}":
             traffic = round(ent["hbm_bytes_per_point"] * prof["points"] / max(prof["launches"], 1))
             traffic_note = f"HBM bytes per launch: PMC bytes/point of {ent['source']} x points per launch"
     except Exception:
         pass
-    roofline = {"bound": "mfma", "kernel": pre_kernel,
-                "mfma_dtype": ("f16 (3 MFMA products per fp32 product, fp32 accumulate)" if h3 else
-                               "f16 operands, fp32 accumulate (reduced precision: ~1e-3, outside the parity bar)" if f16 else "f32"),
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+    roofline = {"bound": "mfma", "kernel": pre_kernel, "mfma_dtype": rf["mfma_dtype"],
+                "achieved": rf["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": rf["frac"],
                 "traffic": traffic, "traffic_unit": traffic_note,
                 "launches": prof["launches"],
                 "flop_per_point_executed_fp32_products": ops.FLOP_PRE_PER_POINT,
@@ -280,13 +477,11 @@ def main():
                 "achieved_fp32_equivalent": round(fp32_equiv, 2),
                 "achieved_reference_flops": round(ref_equiv, 2),
                 "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
-                "avg_launch_ms": round(prof["pre_ms"] / max(prof["launches"], 1), 3),
-                "points_per_launch": round(prof["points"] / max(prof["launches"], 1)),
+                "avg_launch_ms": rf["avg_launch_ms"], "points_per_launch": rf["points_per_launch"],
                 "post_kernel_ms_total": round(prof["post_ms"], 2), "pre_kernel_ms_total": round(prof["pre_ms"], 2)}
     # whole path: every MFMA FLOP of the two field kernels over the WALL time of the timed frames (sampler, hoist, compositor, ray
     # generation, launch gaps and -- for N > 1 -- the gather included), against the same peak
-    flop_path = prof["points"] * (ops.FLOP_PRE_PER_POINT + ops.FLOP_POST_PER_POINT) * mfma_per_product
-    roofline["whole_path"] = {"achieved": round(flop_path / elapsed / 1e12, 2), "frac": round(flop_path / elapsed / 1e12 / peak, 4),
+    roofline["whole_path"] = {"achieved": rf["whole_path_achieved"], "frac": rf["whole_path_frac"],
                               "unit": "TFLOP/s", "note": "MFMA FLOP of the per-view and post kernels of this rank / wall time of the "
                               "timed steps (sampler, per-frame hoist, compositor, ray generation and launch gaps included)",
                               "field_kernels_share_of_wall": round((prof["pre_ms"] + prof["post_ms"]) * 1e-3 / elapsed, 4)}
@@ -336,22 +531,32 @@ def main():
                          f"{times[-1]:.1f}); {best} of {hw} hardware threads = fastest of the sweep {sweep} (rays/s on 256 rays)",
                "repeats_s": [round(t, 2) for t in times], "thread_sweep_rays_per_s": sweep, "host_threads": hw}
 
-    # ---- the other single-GPU configurations of BASELINE.json, one timed frame each (N = 1 only) ---------------------
+    # ---- the other single-GPU configurations of BASELINE.json + the module-level API (N = 1 only) ---------------------
     configs = {}
-    if world == 1 and not args.no_configs and not args.emulate_shard and (W, H, K, bool(args.facescape)) == (800, 600, 128, False):
-        for key, (cw, ch, ck, cfs, cmodes) in {
-                "configs[1] 400x300 K=128": (400, 300, 128, False, (ops.PRECISION_F16X3,)),
-                "configs[4] 1024x1024 K=192 Facescape range, white background": (1024, 1024, 192, True, (ops.PRECISION_F16, ops.PRECISION_F16X3))}.items():
-            wl = workload(cw, ch, ck, cfs, cfs)
+    if world == 1 and not args.no_configs and not args.emulate_shard and not args.via_modules \
+            and (W, H, K, bool(args.facescape)) == (800, 600, 128, False):
+        nx = max(1, args.extra_steps)
+        plan = {
+            "800x600 K=128 through src.models (import_obj), 118 renderer.forward calls of 4096 rays per frame (diner.py:85)":
+                (800, 600, 128, False, (head,), True),
+            "configs[1] 400x300 K=128": (400, 300, 128, False, (ops.PRECISION_F16X3,), False),
+            "configs[4] 1024x1024 K=192 Facescape range, white background":
+                (1024, 1024, 192, True, (ops.PRECISION_F16, ops.PRECISION_F16X3), False)}
+        for key, (cw, ch, ck, cfs, cmodes, via) in plan.items():
+            wl = workload(cw, ch, ck, cfs, cfs, via_modules=via)
             for m in cmodes:
                 wl["step"](0, m, max_rays=2 * args.ray_batch)          # warm-up on the first two ray batches
-                el, _ = timed(1, m, 7, step=wl["step"])
-                assert torch.isfinite(wl["out"]).all()
-                configs[f"{key} [{names[m]}]"] = {
-                    "rays_per_s": round(cw * ch / el, 1), "ms_per_frame": round(el * 1e3, 2), "rays_per_frame": cw * ch, "samples_per_ray": ck,
-                    "mode": names[m], "steps": 1,
-                    "parity": "outside the 1e-4 bar (~1e-3; 85.8 dB against the reference image, tests/test_hip_parity.py::test_cfg5_fp16_mlp_psnr)"
-                    if m == ops.PRECISION_F16 else "1e-4 bar (tests/test_hip_parity.py::test_render_at_metric_sample_counts)"}
+                e = measure(wl["step"], m, cw * ch, nx)
+                if wl["out"] is not None:
+                    assert torch.isfinite(wl["out"]).all()
+                else:
+                    assert torch.isfinite(wl["frame"][0]).all()
+                e.update({"ms_per_frame": e["ms_per_step"], "rays_per_frame": cw * ch, "samples_per_ray": ck,
+                          "parity": "outside the 1e-4 bar (~1e-3; 85.8 dB against the reference image, tests/test_hip_parity.py::test_cfg5_fp16_mlp_psnr)"
+                          if m == ops.PRECISION_F16 else "1e-4 bar (tests/test_hip_parity.py::test_render_at_metric_sample_counts)"})
+                if via:
+                    e["vs_ops_level_headline"] = round(e["rays_per_s"] / rays_per_s, 4)
+                configs[f"{key} [{names[m]}]"] = e
             del wl
             torch.cuda.empty_cache()
 
@@ -365,12 +570,19 @@ def main():
             wl = "BASELINE configs[4]-shaped (Facescape range, white background)"
         else:
             wl = "variant of BASELINE configs[2]"
-        par = (f"{world} independent frames (weak)" if args.weak else
-               f"one frame ray-sharded x{world}" + (" (BASELINE configs[3])" if world > 1 else "")) + \
-              (", RCCL gather of (rgb,depth) tiles to rank 0" if backend != "gloo" else
-               ", gloo gather of (rgb,depth) tiles to rank 0 staged through pinned host memory") + \
-              (f"; OVERSUBSCRIBED: {local_world} ranks time-slice {n_dev} GPU(s) -- exercises the N-rank code path, NOT a scaling number"
-               if shared and world > 1 else "")
+        if args.weak:
+            par = f"{world} independent frames (weak), tiles gathered to rank 0 ({backend})"
+        elif world == 1:
+            par = "one frame on one GPU (no collective)" + (
+                f"; --force-dist: the gather / barrier / all-reduce of the N-rank path run through {backend} with one rank" if multi else "")
+        else:
+            par = f"one frame ray-sharded x{world} (BASELINE configs[3]), " + (
+                "one RCCL gather of (rgb,depth) tiles to rank 0 per frame" if backend == "nccl" else
+                "one gloo gather of (rgb,depth) tiles to rank 0 per frame staged through pinned host memory")
+            if shared:
+                par += f"; OVERSUBSCRIBED: {local_world} ranks time-slice {n_dev} GPU(s) -- exercises the N-rank code path, NOT a scaling number"
+        if args.via_modules:
+            par += f"; through src.models.* + diner_amd.render.predict_image, {args.module_ray_batch} rays per renderer.forward call"
         if args.emulate_shard:
             par = (f"EMULATION on one GPU: the ray range of rank {er} of {en} only (rays {lo}..{hi}), scene preparation included, no "
                    f"process group and no gather; {en} GPUs whose slowest shard takes this long render {NRF * args.steps / elapsed:.0f} rays/s")
@@ -391,6 +603,7 @@ def main():
                        "rays_per_step": rays_per_step, "rays_per_gpu_per_step": hi - lo, "samples_per_ray": K, "src_views": 4,
                        "frame": frame_name, "parallelism": par},
             "backend": backend, "ranks_share_gpu": bool(shared and world > 1),
+            "dist": dist_info, "frame_check": frame_check,
             "roofline": roofline,
             "modes": modes,
             "configs": configs,
@@ -404,6 +617,8 @@ def main():
             print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()
+    if frame_check is not None and not frame_check["bit_equal"]:
+        raise SystemExit("bench.py: the sharded frame differs from the single-rank frame (frame_check.bit_equal = false)")
 
 
 if __name__ == "__main__":

@@ -145,3 +145,38 @@ def make_mlp_state_dict(seed=1234, d_in=55, d_latent=512, d_hidden=512, d_out=4,
         sd[f"lin_z.{b}.weight"] = kaiming(d_hidden, d_latent)
         sd[f"lin_z.{b}.bias"] = bias(d_hidden)
     return sd
+
+
+class _Conf:
+    """Stand-in for the omegaconf nodes the reference hands to its constructors (`.module`, `.kwargs`)."""
+
+    def __init__(self, module=None, kwargs=None):
+        self.module, self.kwargs = module, (kwargs or {})
+
+
+def build_modules(sc, msd, device, normals=None):
+    """The drop-in modules exactly as the reference builds them (import_obj of dotted paths, diner.py:47-48 /
+    pixelnerf.py:17-24), with the synthetic scene `sc` injected into the encoder (feature maps and
+    cameras set directly, no ResNet34 weights involved) and the MLP state dict `msd` loaded strictly.
+    -> (PixelNeRF on `device`, NeRFRendererDGS class)."""
+    import torch as _t
+    from src.util.import_helper import import_obj
+    nerf = import_obj("src.models.pixelnerf.PixelNeRF")(
+        poscode_conf=_Conf(kwargs=dict(num_freqs=6, freq_factor=6.28, include_input=True)),
+        encoder_conf=_Conf("src.models.image_encoder.SpatialEncoder", dict(image_padding=64, padding_pe=4, pretrained=False)),
+        mlp_fine_conf=_Conf("src.models.resnetfc.ResnetFC", dict(n_blocks=5, d_hidden=512, combine_layer=3, combine_type="average")))
+    nerf.mlp_fine.load_state_dict(msd, strict=True)
+    nerf = nerf.to(device).eval()
+    enc = nerf.encoder
+    if normals is None:
+        from src.util.depth2normal import depth2normal
+        normals = depth2normal(sc["depths"].to(device), sc["src_intrinsics"].to(device))
+    enc.depths, enc.depths_std = sc["depths"][None].to(device), sc["depths_std"][None].to(device)
+    enc.normals, enc.latent = normals[None].to(device), sc["latent"][None].to(device)
+    enc.nviews, enc.nobjects = int(sc["depths"].shape[0]), 1
+    Kin = sc["src_intrinsics"]
+    nerf.poses = sc["src_extrinsics"][None].to(device)
+    nerf.c = Kin[None, :, :2, -1].to(device)
+    nerf.focal = Kin[None][:, :, [0, 1], [0, 1]].to(device)
+    nerf.image_shape = sc["image_shape"].clone().to(device)
+    return nerf, import_obj("src.models.nerf_renderer.NeRFRendererDGS")
