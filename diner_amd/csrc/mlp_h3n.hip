@@ -136,47 +136,96 @@ __device__ __forceinline__ void frontend_h3n(const SceneDev& sc, const MapDims& 
   bilinear_taps(dm.Wf, dm.Hf, sc.feature_padding, v, u, w, taps);
 }
 
-struct Args {
-  FieldArgs fa;
-  const _Float16* w;       // n-split packed weights: lin_in, then per block b<3: fc_0, fc_1
-  const float* b;          // biases x16: lin_in, then per block: fc_0, fc_1  (7 x 512)
-  unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
-  unsigned* tile_counter;     // 8 counters (one per XCD queue), zeroed per launch: see TileQueue (a workgroup's first tile is blockIdx.x)
-};
-
 #ifndef DINER_HN_DYN            // 1: dynamic tile hand-out (atomic counter); 0: static round-robin tile += gridDim.x
 #define DINER_HN_DYN 1
 #endif
 // Tile hand-out.  The workgroups are persistent (one per CU: LDS and registers admit no second one); with a static round-robin the
 // launch ends when the slowest CU has done its share.  Here thread 0 asks for the NEXT tile at the top of the current one (an atomic
 // on a per-launch counter; the answer is needed ~230 k clocks later) and hands it to the workgroup through LDS at the bottom.
-// One queue per XCD: tile t belongs to queue t % 8 and workgroup b runs on XCD b % 8, so an XCD keeps seeing the tiles the static
-// round-robin gave it -- the same 16-sample depth segment of every ray, whose taps share texel rows in that XCD's L2 (a single
-// global queue was measured at 4x the L2 misses and HBM reads of the per-view kernel: 98 KB instead of 24 KB per point).  An XCD
-// that runs dry takes from the others' queues.
+// One queue per XCD (workgroup b runs on XCD b % 8), and a queue holds the tiles of ONE DEPTH RANGE of every ray: the taps of the same
+// 16-sample segment of neighbouring rays share texel rows, which then stay in that XCD's L2 (a single global queue was measured at 4x
+// the L2 misses and HBM reads of the per-view kernel: 98 KB instead of 24 KB per point).  With S = K / 16 segments per ray the tile of
+// (ray, segment) is ray * S + seg.  S = 8 (K = 128): queue = segment = tile % 8.  Other S (round 4; K = 192 has 12 segments, and
+// tile % 8 handed an XCD four different segments in turn: L2 hit rate 0.59 instead of 0.95, profiles/r04_cfg5_*): rays are taken
+// in groups of R = 8 / gcd(S, 8); the S R (segment, ray phase) slots of a group, ordered segment-major, are dealt to the queues in
+// runs of m = S R / 8 -- every queue gets the same number of tiles and at most two neighbouring segments.  Entry e of queue q:
+// group e / m, slot q m + e % m, segment = slot / R, ray = group R + slot % R.  (No ray structure -- explicit points, K not a
+// multiple of 16 --: S = 8, R = 1, which is tile % 8.)  An XCD that runs dry takes from the others' queues.
+struct QueueMap {
+  unsigned S, R, m;              // segments per ray, rays per group, entries per queue and group
+  unsigned per_queue;            // entries per queue (the last group may hold tiles beyond the launch: skipped)
+  __host__ static QueueMap make(long long n_tiles, int K, bool rays) {
+    QueueMap q{8, 1, 1, 0};
+    if (rays && K >= 16 && K % 16 == 0 && K / 16 <= 4096) {
+      q.S = (unsigned)(K / 16);
+      unsigned g = q.S & (0u - q.S);
+      g = g > 8 ? 8 : g;
+      q.R = 8 / g;
+      q.m = q.S * q.R / 8;
+    }
+    const unsigned long long n_rays = ((unsigned long long)n_tiles + q.S - 1) / q.S;
+    q.per_queue = (unsigned)(((n_rays + q.R - 1) / q.R) * q.m);
+    return q;
+  }
+  __device__ __forceinline__ unsigned long long tile(unsigned q, unsigned e) const {
+    const unsigned group = e / m, slot = q * m + (e - group * m);
+    const unsigned seg = slot / R, phase = slot - seg * R;
+    return (unsigned long long)(group * R + phase) * S + seg;
+  }
+};
+struct Args {
+  FieldArgs fa;
+  const _Float16* w;       // n-split packed weights: lin_in, then per block b<3: fc_0, fc_1
+  const float* b;          // biases x16: lin_in, then per block: fc_0, fc_1  (7 x 512)
+  unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
+  unsigned* tile_counter;     // 8 counters (one per XCD queue), zeroed per launch: see TileQueue
+  QueueMap qmap;              // which tiles a queue holds (h3n_launch_pre fills it in)
+};
+
 struct TileQueue {
   unsigned nxt;
   unsigned done;       // queues seen empty (thread 0)
   __device__ __forceinline__ void begin() { done = 0; }
-  __device__ __forceinline__ void request(unsigned* counters, long long n_tiles) {
-#if DINER_HN_DYN
+  // thread 0: the next tile of this workgroup's XCD queue (of the others' once it is empty), 0xffffffff when nothing is left
+  __device__ __forceinline__ unsigned fetch(unsigned* counters, long long n_tiles, const QueueMap& qm) {
+    const unsigned xcd = blockIdx.x & 7;
+#pragma nounroll
+    for (unsigned s = 0; s < 8; ++s) {
+      const unsigned qn = (xcd + s) & 7;
+      if (done & (1u << qn)) continue;
+      const unsigned taken = gridDim.x > qn ? (gridDim.x - qn + 7) >> 3 : 0;       // entries the workgroups' first requests used up
+#pragma nounroll
+      for (;;) {
+        const unsigned long long e = (unsigned long long)atomicAdd(counters + qn, 1u) + taken;
+        if (e >= qm.per_queue) break;
+        const unsigned long long cand = qm.tile(qn, (unsigned)e);
+        if (cand < (unsigned long long)n_tiles) return (unsigned)cand;
+      }
+      done |= 1u << qn;
+    }
+    return 0xffffffffu;
+  }
+  // the workgroup's first tile: entry blockIdx.x / 8 of queue blockIdx.x % 8 (no atomic), or -- ragged last group -- the next valid one.
+  // Thread 0 writes it to *slot; the caller has a barrier in front of the tile loop.
+  __device__ __forceinline__ void first(unsigned* counters, long long n_tiles, const QueueMap& qm, unsigned* slot) {
     if (threadIdx.x == 0) {
       unsigned t = 0xffffffffu;
-      const unsigned xcd = blockIdx.x & 7;
-#pragma nounroll
-      for (unsigned s = 0; s < 8; ++s) {
-        const unsigned qn = (xcd + s) & 7;
-        if (done & (1u << qn)) continue;
-        const unsigned taken = gridDim.x > qn ? (gridDim.x - qn + 7) >> 3 : 0;       // entries the workgroups' first tiles used up
-        const unsigned long long cand = 8ull * (atomicAdd(counters + qn, 1u) + taken) + qn;
-        if (cand < (unsigned long long)n_tiles) {
-          t = (unsigned)cand;
-          break;
-        }
-        done |= 1u << qn;
+      const unsigned e = blockIdx.x >> 3;
+      if (e < qm.per_queue) {
+        const unsigned long long cand = qm.tile(blockIdx.x & 7, e);
+        if (cand < (unsigned long long)n_tiles) t = (unsigned)cand;
       }
-      nxt = t;
+#if DINER_HN_DYN
+      if (t == 0xffffffffu) t = fetch(counters, n_tiles, qm);
+#else
+      t = blockIdx.x < n_tiles ? blockIdx.x : 0xffffffffu;
+#endif
+      *slot = t;
     }
+  }
+  __device__ __forceinline__ void request(unsigned* counters, long long n_tiles, const QueueMap& qm) {
+#if DINER_HN_DYN
+    if (threadIdx.x == 0) nxt = fetch(counters, n_tiles, qm);
 #endif
   }
   // the same in two halves around a barrier the caller has anyway: offer() in front of it, take() behind it
@@ -192,6 +241,10 @@ struct TileQueue {
 #if DINER_HN_DYN
     if (threadIdx.x == 0) *slot = nxt;
 #endif
+  }
+  __device__ __forceinline__ long long initial(const unsigned* slot) {       // what first() left in *slot (behind a barrier)
+    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)*slot);
+    return t == 0xffffffffu ? 0x7fffffffffffffffll : (long long)t;
   }
   __device__ __forceinline__ long long take(long long tile, const unsigned* slot) {
 #if DINER_HN_DYN
@@ -602,6 +655,17 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
 #ifndef DINER_HN_G0DEPTH        // units in flight for block 0's stand-alone gather (no GEMM buffers live there)
 #define DINER_HN_G0DEPTH 8
 #endif
+// Plain-fp16 instances (LO = false): a half-step is 4 x 4 MFMAs = 256 clocks instead of 768, so the same prefetch distances in half-steps
+// cover a third of the latency, and the lo planes' registers (48 of the weight ring, 16 of the B buffer) are free: deeper rings there.
+#ifndef DINER_HN_RING_F16        // measured (profiles/r04_ab_runs.txt): ring 4 / gather depth 3 is +6.7 % at 800x600, +3.8 % at 1024^2 K=192; 6 / 4 the same, 8 / 4 spills
+#define DINER_HN_RING_F16 4
+#endif
+#ifndef DINER_HN_RING0_F16
+#define DINER_HN_RING0_F16 DINER_HN_RING_F16
+#endif
+#ifndef DINER_HN_GDEPTH_F16
+#define DINER_HN_GDEPTH_F16 3
+#endif
 
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
 // (g, mo) of 4 taps each.  As a GEMM side task (SIDE) one unit's taps are requested per half-step, one per quarter-step, and
@@ -722,6 +786,8 @@ struct GatherSide {
 
 template <bool LO>
 __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
+  constexpr int kRing = LO ? DINER_HN_RING : DINER_HN_RING_F16, kRing0 = LO ? DINER_HN_RING0 : DINER_HN_RING0_F16;
+  constexpr int kGDepth = LO ? DINER_HN_GDEPTH : DINER_HN_GDEPTH_F16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   h8* B = reinterpret_cast<h8*>(smem);
   TapRec* taps_lds = reinterpret_cast<TapRec*>(reinterpret_cast<char*>(smem) + (size_t)kBHalfs * 2);
@@ -735,20 +801,21 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
     const int sl = threadIdx.x & 15;
     feat_tab[threadIdx.x] = feat_recipe(16 * (sl >> 2) + 4 * (threadIdx.x >> 4) + (sl & 3), fa.freq_factor);
   }
+  const long long n_tiles = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
+  __shared__ unsigned s_tile;
+  TileQueue tq;
+  tq.begin();
+  tq.first(a.tile_counter, n_tiles, a.qmap, &s_tile);
   __syncthreads();
   const LdsB Bl = LdsB::make(B, lane);
-  const long long n_tiles = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
   const _Float16* w_in = a.w;                                   // [4][2][8][2][64][8]  = 4 * 2 * 16 KB
   const _Float16* w_blk = a.w + (size_t)4 * 2 * 8192;           // then 6 layers of 4 * 16 * 16 KB
   constexpr size_t kLayerHalfs = (size_t)4 * 16 * 8192;
 
   Prof pf;
   pf.begin();
-  __shared__ unsigned s_tile;
-  TileQueue tq;
-  tq.begin();
-  for (long long tile = blockIdx.x; tile < n_tiles; tile = tq.next(tile, &s_tile)) {
-    tq.request(a.tile_counter, n_tiles);
+  for (long long tile = tq.initial(&s_tile); tile < n_tiles; tile = tq.next(tile, &s_tile)) {
+    tq.request(a.tile_counter, n_tiles, a.qmap);
     long long p = tile * kPtsPerWave + pt;
     if (p >= fa.P) p = fa.P - 1;
     Taps taps;
@@ -803,7 +870,7 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
       {
         NoSide none;
-        publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
+        publish_gemm<kRing0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
             w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] { set_bias(ns, bias, wave, q); }, pf, 6);
       }
       // the next block's lin_z contribution rides on the fc_1 GEMM (additions into xs commute); this block's fc_1 bias comes with it
@@ -811,8 +878,8 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       const _Float16* w1 = w_blk + (size_t)(2 * b + 1) * kLayerHalfs;
 #if DINER_HN_OWNG
       {
-        GatherSide<DINER_HN_GDEPTH> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
-        publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLY1 != 0, true>(w1, Bl, wave, lane, ns, xs, gs, [&] { pin_acc(xs); }, pf, 10);
+        GatherSide<kGDepth> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
+        publish_gemm<kRing, LO, DINER_HN_EARLY1 != 0, true>(w1, Bl, wave, lane, ns, xs, gs, [&] { pin_acc(xs); }, pf, 10);
       }
 #else
       __syncthreads();
@@ -822,17 +889,17 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       __syncthreads();
       pf.mark(12);
       pin_acc(xs);
-      GatherSide<DINER_HN_GDEPTH> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
-      gemm<16, DINER_HN_RING, LO>(w1, Bl, wave, lane, xs, gs);
+      GatherSide<kGDepth> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
+      gemm<16, kRing, LO>(w1, Bl, wave, lane, xs, gs);
       pf.mark(13);
 #endif
     }
     {   // block 2: no gather left (and its fc_1 bias is added by the post kernel)
       const float* bias = a.b + kHidden * 5;
       NoSide none;
-      publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
+      publish_gemm<kRing0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
           w_blk + (size_t)4 * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] { set_bias(ns, bias, wave, q); }, pf, 6);
-      publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLY1 != 0, DINER_HN_OWN != 0>(w_blk + (size_t)5 * kLayerHalfs, Bl, wave, lane, ns, xs, none,
+      publish_gemm<kRing, LO, DINER_HN_EARLY1 != 0, DINER_HN_OWN != 0>(w_blk + (size_t)5 * kLayerHalfs, Bl, wave, lane, ns, xs, none,
                                                                 [&] { pin_acc(xs); }, pf, 10);
     }
     // view mean = mean over the four column groups; hand-over at scale 1 in accumulator layout (row tile 8 w + mo)
@@ -852,6 +919,7 @@ struct PostArgsN {
                             // [wave 4][mo 8][q 4][o 4][j 4] = Wout[o][128 wave + 16 mo + 4 q + j] / 16 of the vector-ALU lin_out
   unsigned long long* prof; // DINER_HN_PROF builds: phase counters, else unused
   unsigned* tile_counter;   // see TileQueue
+  QueueMap qmap;            // the default map (tile % 8): the post kernel's tiles are 64 consecutive points, no taps
 };
 
 // The lane index, opaque to the optimiser: what is derived from it is derived at the point of use.  (Lane-derived values hoisted out
@@ -917,7 +985,7 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
     // lane-derived quantities are re-derived per tile from an opaque copy: hoisted out of the tile loop they do not survive the GEMMs in
     // registers (the kernel uses all 512) and come back from scratch
     const int q = lane_here() >> 4;
-    tq.request(a.tile_counter, n_tiles);
+    tq.request(a.tile_counter, n_tiles, a.qmap);
     const float* bpost = pa.b_post;
     asm volatile("" : "+s"(bpost));                // (as above)
 #pragma unroll
@@ -932,13 +1000,13 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
       const float* bias = bpost + 2 * kHidden * b;
-      publish_gemm<DINER_HN_RING0, LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
+      publish_gemm<(LO ? DINER_HN_RING0 : DINER_HN_RING0_F16), LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
         set_bias(ns, bias, wave, lane_here() >> 4);
         pin_acc(xs);                              // the residual stream stays in registers across the fc_0 GEMM
       }, pf, 0);
       if (b == 0) tq.park(&s_tile2[par]);           // (the request went out at the top of the tile)
       pin_acc(xs);
-      publish_gemm<DINER_HN_RING, LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
+      publish_gemm<(LO ? DINER_HN_RING : DINER_HN_RING_F16), LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
                                       [&] { add_bias(xs, bias + kHidden, wave, lane_here() >> 4); }, pf, 4);
     }
 #if DINER_HN_LINOUT_VALU
@@ -1193,7 +1261,8 @@ int h3n_set_attributes() {
 // split = true: f16x3 split products (hi and lo parts, three MFMAs per product); false: plain fp16 operands
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
                     unsigned* tile_counter, hipStream_t stream) {
-  h3n::Args a{fa, (const _Float16*)w, b, nullptr, tile_counter};
+  h3n::Args a{fa, (const _Float16*)w, b, nullptr, tile_counter,
+              h3n::QueueMap::make((fa.P + kPtsPerWave - 1) / kPtsPerWave, fa.K, fa.rays != nullptr && fa.xyz == nullptr && fa.direct_feat == nullptr)};
 #ifdef DINER_HN_PROF
   static unsigned long long* prof = nullptr;
   if (!prof) hipMalloc(&prof, 32 * sizeof(unsigned long long));
@@ -1223,7 +1292,8 @@ void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out,
                      hipStream_t stream) {
   const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
   const _Float16* wo = (const _Float16*)w_lin_out;
-  h3n::PostArgsN a{pa, wn, wo, nullptr, tile_counter};
+  const long long n_t16 = (pa.P + kPtsPerWave - 1) / kPtsPerWave;
+  h3n::PostArgsN a{pa, wn, wo, nullptr, tile_counter, h3n::QueueMap::make((n_t16 + 3) / 4, 0, false)};
 #ifdef DINER_HN_PROF
   static unsigned long long* prof = nullptr;
   if (!prof) hipMalloc(&prof, 32 * sizeof(unsigned long long));
