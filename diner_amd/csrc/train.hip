@@ -664,8 +664,11 @@ __global__ void k_view_mean(const float* __restrict__ x, int nv, long long PC, f
     y[i] = s / (float)nv;
   }
 }
-__global__ void k_view_bcast(const float* __restrict__ dy, int nv, long long PC, float* __restrict__ dx) {
+// amax_in / amax_out (or null): the maximum of |dx| is that of |dy| / nv (thread 0 writes it)
+__global__ void k_view_bcast(const float* __restrict__ dy, int nv, long long PC, float* __restrict__ dx, const unsigned* __restrict__ amax_in,
+                             unsigned* __restrict__ amax_out) {
   const float inv = 1.0f / (float)nv;
+  if (amax_out && blockIdx.x == 0 && threadIdx.x == 0) *amax_out = __float_as_uint(fabsf(__uint_as_float(*amax_in) * inv));
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < PC; i += (long long)gridDim.x * blockDim.x) {
     const float gv = dy[i] * inv;
     for (int v = 0; v < nv; ++v) dx[(size_t)v * PC + i] = gv;
@@ -760,11 +763,13 @@ __global__ __launch_bounds__(256) void k_lin_out_fwd(const float* __restrict__ x
 }
 // backward: d_raw from (raw, d_out) as k_field_act_bwd computes it; dx = (x > 0) * (d_raw W); dW += d_raw^T relu(x), db += column sums of
 // d_raw (atomics: both zeroed by the caller), one pass over x
+// amax_out (or null): atomic maximum of the bit patterns of |dx| (the scale of the f16x3 products that consume dx)
 __global__ __launch_bounds__(256) void k_lin_out_bwd(const float* __restrict__ x, const float* __restrict__ raw, const float* __restrict__ dout,
                                                      const float* __restrict__ W, long long P, float* __restrict__ dx,
-                                                     float* __restrict__ dW, float* __restrict__ db) {
+                                                     float* __restrict__ dW, float* __restrict__ db, unsigned* __restrict__ amax_out) {
   __shared__ float red[4][4][kHidden + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned dmax = 0;
   f32x4 w[4][2], gw[4][2];
   float gb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(256) void k_lin_out_bwd(const float* __restrict__ x
 #pragma unroll
         for (int o = 1; o < 4; ++o) t = fmaf(d[o], w[o][h][c], t);
         v[c] = xv[c] > 0.0f ? t : 0.0f;
+        dmax = max(dmax, __float_as_uint(v[c]) & 0x7fffffffu);
         const float xr = fmaxf(xv[c], 0.0f);
 #pragma unroll
         for (int o = 0; o < 4; ++o) gw[o][h][c] = fmaf(d[o], xr, gw[o][h][c]);
@@ -818,6 +824,11 @@ __global__ __launch_bounds__(256) void k_lin_out_bwd(const float* __restrict__ x
     const float t = (red[0][o][k] + red[1][o][k]) + (red[2][o][k] + red[3][o][k]);
     if (k < kHidden) atomicAdd(dW + o * kHidden + k, t);
     else atomicAdd(db + o, t);
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o, 64));
+    if (lane == 0 && dmax) atomicMax(amax_out, dmax);
   }
 }
 
@@ -985,7 +996,7 @@ extern "C" int diner_channels_last_to_nchw_f32(const float* src, int n, long lon
 
 extern "C" int diner_view_mean_f32(const float* x, int nv, long long PC, float* y, int adjoint, void* stream) {
   DINER_CHECK_ARG(x && y && nv > 0 && PC > 0, "view_mean: bad arguments");
-  if (adjoint) hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y);
+  if (adjoint) hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y, (const unsigned*)nullptr, (unsigned*)nullptr);
   else hipLaunchKernelGGL(k_view_mean, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y);
   DINER_LAUNCH_OK();
   return 0;
@@ -1022,7 +1033,11 @@ extern "C" int diner_composite_bwd_f32(const float* field, const float* z, const
 // saves ~100 host round trips per step, which matter at the reference's 128-ray training batch) -------------------------
 namespace {
 // packed-weights slots of the workspace: fc_0 / fc_1 of the 5 blocks + the 3 lin_z, forward and transposed
-constexpr int kWPackSlots = 3 * 13;      // forward, transposed, forward in fp16 hi / lo (the f16x3 forward arithmetic)
+constexpr int kWPackSlots = 4 * 13;      // forward, transposed (bf16x6); forward, transposed in fp16 hi / lo (f16x3)
+// ints of the flag block: [0, 13) range flags of the forward's f16x3 products (per weight slot; also raised when the step's weights do not
+// fit, kFlagWBad) -- the weight gradient of a slot runs in f16x3 only if its flag stayed down (its x operand is that product's);
+// kFlagWBad: some 16 |w| is no finite fp16 value (set while packing); [kAmax0, +64): bit patterns of max |dy| of the backward's operands
+enum { kFlagWBad = 13, kAmax0 = 32, kFlagInts = 128 };
 enum { kSlotFc0 = 0, kSlotFc1 = 5, kSlotLinZ = 10 };
 struct TrainWs {               // float offsets into the workspace
   size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, wgpart, flags, total;
@@ -1049,7 +1064,7 @@ TrainWs train_ws(long long P, int nv) {
   w.d_lat = take(cols * kLatent);
   w.wpack = take(kWPackSlots * (kL512PackBytes / sizeof(float)));      // packed 512 x 512 weights of train_lin512.hip
   w.wgpart = take(13 * (wgrad512_part_bytes() / sizeof(float)));     // per-chunk partial weight gradients of the 13 512 x 512 layers (train_wgrad512.hip)
-  w.flags = take(64);                                              // range flags of the f16x3 forward products (ints)
+  w.flags = take(kFlagInts);                                       // flag block (ints), see kFlagWBad
   w.total = o;
   return w;
 }
@@ -1070,6 +1085,15 @@ bool use_fwd_f16() {
   static const bool on = [] { const char* e = getenv("DINER_TRAIN_FWD_F16X3"); return !(e && *e == '0'); }();
   return on;
 }
+// Round 4: the data- and weight-gradient products of the 512 x 512 layers in the f16x3 arithmetic as well (3 MFMAs per fp32 product instead of
+// bf16x6's 6, on two thirds of the step's FLOPs).  Loss gradients span many decades, so dy is staged times a power of two taken from its
+// maximum (tracked by the epilogue of the product that wrote it): nothing leaves the fp16 range, no repeat is needed for the operand.  What
+// can still not fit: the weights (16 |w| beyond fp16, kFlagWBad) and an activation operand of a weight gradient (the forward flag of that
+// layer) -- those launches return at once and their bf16x6 twins, issued behind them, do the work.  DINER_TRAIN_BWD_F16X3=0: bf16x6 backward.
+bool use_bwd_f16() {
+  static const bool on = [] { const char* e = getenv("DINER_TRAIN_BWD_F16X3"); return !(e && *e == '0'); }();
+  return on;
+}
 bool use_wgrad512() {          // DINER_TRAIN_WGRAD512=0: weight gradients back on the general kernel (A/B measurement)
   static const bool on = [] { const char* e = getenv("DINER_TRAIN_WGRAD512"); return !(e && *e == '0'); }();
   return on;
@@ -1078,13 +1102,21 @@ bool lin512_ok(const float* x, int ldx, const float* y, int ldy, const float* re
   auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
   return use_lin512() && (ldx & 3) == 0 && (ldy & 3) == 0 && al(x) && al(y) && al(resid) && al(mask);
 }
-void* wpack_slot(float* ws, const TrainWs& w, int slot, bool transposed) {
-  return reinterpret_cast<char*>(ws + w.wpack) + (size_t)(slot + (transposed ? 13 : 0)) * kL512PackBytes;
+void* wpack_slot(float* ws, const TrainWs& w, int slot, bool transposed, bool f16 = false) {
+  return reinterpret_cast<char*>(ws + w.wpack) + (size_t)(slot + (transposed ? 13 : 0) + (f16 ? 26 : 0)) * kL512PackBytes;
 }
+// f16x3 arithmetic of one backward layer (linear_bwd): operand scale source, where the maximum of dx goes, the two flags, the f16 pack of W^T
+struct BwdArith {
+  const unsigned* amax_dy;
+  unsigned* amax_dx;
+  const int* wflag;      // kFlagWBad
+  const int* xflag;      // the forward flag of the layer (its x operand left the fp16 range, or wflag)
+  const void* Wt_f16;
+};
 // adjoint of y = act(x) W^T + b: dW = dy^T act(x) (split-K atomics into zeroed dW), db = column sums, dx (+)= (dy W) [masked]
 int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, const float* W, float* dW, float* db,
                long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st,
-               const void* Wt_packed = nullptr, float* wgpart = nullptr, WgReduceJob* defer = nullptr) {
+               const void* Wt_packed = nullptr, float* wgpart = nullptr, WgReduceJob* defer = nullptr, const BwdArith* f16 = nullptr) {
   // split-K so that the 16 output tiles of a 512 x 512 weight gradient become 500-1000 workgroups of >= 15 k-tiles each (measured:
   // 128 / 512 / 2048-ray steps 5.70 / 15.6 / 53.1 ms with M / 1024 capped at 32, 5.07 / 14.5 / 51.8 ms with M / 480 capped at 64);
   // round 3: M / 640 -- the row-sum instance of the kernel runs two workgroups per CU, 16 tiles x 32 chunks fill the chip once for the
@@ -1105,7 +1137,24 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
     // the data gradient of the layer rides in the same launch (train_512.hip): dx = dy W on k_lin512's bodies, W packed transposed
     static const bool one_launch = [] { const char* e = getenv("DINER_TRAIN_BWD_FUSED"); return !(e && *e == '0'); }();
     const bool dgrad512 = dx && Wt_packed && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask);
-    const Lin512Args da{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+    Lin512Args da{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+    if (f16 && wgpart && defer && one_launch && (dgrad512 || !dx)) {
+      // the f16x3 launch (works unless a flag is up) and its bf16x6 twin (works only then); an accumulating data gradient is safe: exactly
+      // one of the two runs, decided by a flag that does not change during the step
+      Lin512Args dh = da;
+      dh.Wp = f16->Wt_f16;
+      dh.amax_in = f16->amax_dy;
+      dh.amax_out = f16->amax_dx;
+      dh.skip = f16->wflag;
+      const WgradArith wa{1, f16->amax_dy, f16->xflag, nullptr};
+      int rcf = wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, true, defer, dx ? &dh : nullptr, &wa);
+      if (rcf) return rcf;
+      da.gate = f16->wflag;
+      da.amax_out = f16->amax_dx;
+      const WgradArith wb{0, nullptr, nullptr, f16->xflag};
+      return wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, true, defer, dx ? &da : nullptr, &wb);
+    }
+    if (f16) da.amax_out = f16->amax_dx;          // (bf16x6 here, but a later product may still want the maximum)
     int rcw = wgrad512_launch(dy, ldy, x, ldx, relu_in, dW, db, M, st, wgpart, wgpart != nullptr, wgpart ? defer : nullptr,
                               dgrad512 && one_launch ? &da : nullptr);
     if (rcw) return rcw;
@@ -1160,8 +1209,9 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     PackMany pm;
     for (int b = 0; b < 5; ++b) { pm.W[kSlotFc0 + b] = p->fc0_w[b]; pm.W[kSlotFc1 + b] = p->fc1_w[b]; }
     for (int b = 0; b < 3; ++b) pm.W[kSlotLinZ + b] = p->lin_z_w[b];
-    if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st, use_fwd_f16() ? 3 : 2))) return rc;
-    if (use_fwd_f16()) DINER_HIP_OK(hipMemsetAsync(ws + w.flags, 0, 16 * sizeof(int), st));
+    const bool f16_packs = use_fwd_f16() || use_bwd_f16();
+    if (f16_packs) DINER_HIP_OK(hipMemsetAsync(ws + w.flags, 0, 16 * sizeof(int), st));
+    if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st, f16_packs ? 4 : 2, reinterpret_cast<int*>(ws + w.flags) + kFlagWBad))) return rc;
   }
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
                  bool accum, const float* resid = nullptr, int slot = -1, const float* resid2 = nullptr) {
@@ -1172,8 +1222,9 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
       if (use_fwd_f16() && !accum) {             // (an accumulating product cannot be run twice: lin_z stays on bf16x6)
         int* flag = reinterpret_cast<int*>(ws + w.flags) + slot;
         Lin512Args h = a;
-        h.Wp = reinterpret_cast<char*>(ws + w.wpack) + (size_t)(26 + slot) * kL512PackBytes;
+        h.Wp = wpack_slot(ws, w, slot, false, true);
         h.ovf = flag;
+        h.skip = reinterpret_cast<int*>(ws + w.flags) + kFlagWBad;      // weights beyond the fp16 split: raises the flag and returns
         int hrc = lin512_launch(h, st, 1);
         if (hrc) return hrc;
         a.gate = flag;                           // the bf16x6 product below runs only if the f16x3 one left the range
@@ -1248,12 +1299,26 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   auto wt = [&](const float*, int slot) -> const void* {      // W packed transposed by the forward call of the step (k_lin512), or null
     return use_lin512() ? wpack_slot(ws, w, slot, true) : nullptr;
   };
+  // f16x3 backward (use_bwd_f16): every dy operand carries the maximum of its magnitudes in an amax slot, written by its producer
+  int* flags = reinterpret_cast<int*>(ws + w.flags);
+  unsigned* amax = reinterpret_cast<unsigned*>(flags) + kAmax0;
+  const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, ws + w.d_lat, kHidden, nullptr, nullptr);   // as the forward decided
+  const bool bwd16 = use_bwd_f16() && use_fwd_f16() && use_lin512() && use_wgrad512() && z_sep && (reinterpret_cast<size_t>(workspace) & 15) == 0;
+  if (bwd16) DINER_HIP_OK(hipMemsetAsync(amax, 0, 64 * sizeof(unsigned), st));
+  int a_cur = 0, a_next = 1;                                  // slot of the current dx; next free slot
+  BwdArith ar_store;
+  auto arith = [&](int slot, int a_dy, int a_dx) -> const BwdArith* {
+    if (!bwd16) return nullptr;
+    ar_store = BwdArith{amax + a_dy, a_dx >= 0 ? amax + a_dx : nullptr, flags + kFlagWBad, flags + slot, wpack_slot(ws, w, slot, true, true)};
+    return &ar_store;
+  };
   if (use_lin_out() && (reinterpret_cast<size_t>(p->lin_out_w) & 15) == 0 && (reinterpret_cast<size_t>(d_out) & 15) == 0) {
     DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_out_w, 0, (size_t)4 * kHidden * sizeof(float), st));
     DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_out_b, 0, 4 * sizeof(float), st));
     hipLaunchKernelGGL(k_lin_out_bwd, dim3(grid1d(P, 4, 256)), dim3(256), 0, st, ws + w.x_last, ws + w.raw, d_out, p->lin_out_w, P, dx,
-                       (float*)grads->lin_out_w, (float*)grads->lin_out_b);
+                       (float*)grads->lin_out_w, (float*)grads->lin_out_b, bwd16 ? amax + 0 : nullptr);
   } else {
+    DINER_CHECK_ARG(!bwd16, "field_train_backward: lin_out off its skinny kernel with the f16x3 backward (set DINER_TRAIN_BWD_F16X3=0)");
     hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, ws + w.d_raw);
     if ((rc = linear_bwd(ws + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
                          (float*)grads->lin_out_b, P, 4, kHidden, dx, ws + w.x_last, false, st))) return rc;
@@ -1262,15 +1327,23 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
     const long long M = b < 3 ? cols : P;
     const float* X = ws + w.X[b];
     const float* H = ws + w.H[b];
+    const int a_h = a_next++;                                 // dH = (dx W1) masked
     if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
-                         kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job()))) return rc;
+                         kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job(),
+                         arith(kSlotFc1 + b, a_cur, a_h)))) return rc;
+    const int a_x = a_next++;                                 // dx += (dH W0) masked
     if ((rc = linear_bwd(dH, kHidden, X, kHidden, true, p->fc0_w[b], (float*)grads->fc0_w[b], (float*)grads->fc0_b[b], M,
-                         kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b), part(kSlotFc0 + b), job()))) return rc;
+                         kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b), part(kSlotFc0 + b), job(),
+                         arith(kSlotFc0 + b, a_h, a_x)))) return rc;
+    a_cur = a_x;
     if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
                                   (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st,
-                                  wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job()))) return rc;
+                                  wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job(), arith(kSlotLinZ + b, a_cur, -1)))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
-      hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P * kHidden)), dim3(256), 0, st, dx, scene->nv, P * kHidden, dH);
+      const int a_b = a_next++;
+      hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P * kHidden)), dim3(256), 0, st, dx, scene->nv, P * kHidden, dH,
+                         bwd16 ? amax + a_cur : nullptr, bwd16 ? amax + a_b : nullptr);
+      a_cur = a_b;
       float* t = dx; dx = dH; dH = t;
     }
   }

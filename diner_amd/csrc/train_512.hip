@@ -37,13 +37,21 @@ __global__ __launch_bounds__(256, 1) void k_fwd512_f16x3(Run512 r) {
   if (b < r.n[0]) return lin512_part_f16(r.part[0], r.shape[0], b, r.n[0]);
   lin512_part_f16(r.part[1], r.shape[1], b - r.n[0], r.n[1]);
 }
+// round 4: the backward's launch (data gradient in its shapes + the weight gradient of the same layer) in the f16x3 arithmetic
+__global__ __launch_bounds__(256, 1) void k_run512_f16x3(Run512 r) {
+  int b = blockIdx.x;
+  if (b < r.n[0]) return lin512_part_f16(r.part[0], r.shape[0], b, r.n[0]);
+  b -= r.n[0];
+  if (b < r.n[1]) return lin512_part_f16(r.part[1], r.shape[1], b, r.n[1]);
+  wgrad512_body<1>(r.wg, b - r.n[1]);
+}
 
 __global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
   int b = blockIdx.x;
   if (b < r.n[0]) return lin512_part(r.part[0], r.shape[0], b, r.n[0]);
   b -= r.n[0];
   if (b < r.n[1]) return lin512_part(r.part[1], r.shape[1], b, r.n[1]);
-  wgrad512_body(r.wg, b - r.n[1]);
+  wgrad512_body<0>(r.wg, b - r.n[1]);
 }
 
 namespace {
@@ -57,6 +65,7 @@ int device_cus(int* cus) {                                   // per device: dyna
   if (!attr_set[dev].load()) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(c > 1 ? c & ~1 : 256);
@@ -126,7 +135,7 @@ int plan_wgrad512(const float* dY, int ldy, const float* X, int ldx, bool relu_x
   while (n_chunks > 1 && (M + n_chunks - 1) / n_chunks < 128) n_chunks >>= 1;
   long long rows = (M + n_chunks - 1) / n_chunks;
   rows = (rows + 31) / 32 * 32;
-  *a = Wgrad512Args{dY, X, dW, db, part, M, ldy, ldx, relu_x ? 1 : 0, (int)n_chunks, rows};
+  *a = Wgrad512Args{dY, X, dW, db, part, M, ldy, ldx, relu_x ? 1 : 0, (int)n_chunks, rows, nullptr, nullptr, nullptr};
   *used = (int)((M + rows - 1) / rows);
   return 8 * (int)(n_chunks <= 8 ? 8 : n_chunks);             // the block -> (tile, chunk) map needs whole groups of 8 chunks
 }
@@ -149,7 +158,7 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream, int arith) {
 // wgrad512_part_bytes() of scratch (partial tiles stored per chunk + one reduction pass); with it overwrite = true makes dW / db plain
 // outputs (no zeroing by the caller).  dgrad: the data-gradient product of the same layer, run by the same launch (or null).
 int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M,
-                    hipStream_t stream, float* part, bool overwrite, WgReduceJob* defer, const Lin512Args* dgrad) {
+                    hipStream_t stream, float* part, bool overwrite, WgReduceJob* defer, const Lin512Args* dgrad, const WgradArith* ar) {
   DINER_CHECK_ARG(part || !overwrite, "wgrad512: overwrite needs the scratch buffer");
   DINER_CHECK_ARG(part || !defer, "wgrad512: a deferred summing pass needs the scratch buffer");
   int cus = 0;
@@ -164,7 +173,13 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
   }
   int used = 0;
   const int n_wg = plan_wgrad512(dY, ldy, X, ldx, relu_x, dW, db, M, part, &r.wg, &used);
-  hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1] + n_wg), dim3(256), kLdsBytesRun, stream, r);
+  if (ar) {
+    r.wg.amax_dy = ar->amax_dy;
+    r.wg.skip = ar->wg_skip;
+    r.wg.gate = ar->wg_gate;
+  }
+  if (ar && ar->arith == 1) hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1] + n_wg), dim3(256), kLdsBytesRun, stream, r);
+  else hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1] + n_wg), dim3(256), kLdsBytesRun, stream, r);
   if (part) {
     // chunks that start past M wrote nothing: only the chunks with rows are summed
     if (defer) *defer = WgReduceJob{part, dW, db, used};      // the caller sums (wgrad512_reduce_many)

@@ -79,25 +79,27 @@ __device__ __forceinline__ void sfor(F&& f) {
 // Weight packing: dst[(((w * 32 + s) * 4 + rt) * 3 + pl) * 64 + lane][j] = plane pl of
 //   W[128 w + 32 rt + (lane & 31)][16 s + 8 (lane >> 5) + j]      (transpose = 0: forward, W is (out, in) as nn.Linear stores it)
 //   W[16 s + 8 (lane >> 5) + j][128 w + 32 rt + (lane & 31)]      (transpose = 1: data gradient, the roles of out / in swap)
-// mode 0 / 1: three bf16 planes, forward / transposed; mode 2 (forward, the f16x3 arithmetic of lin512_body<.., AR = 1>): two fp16 planes
-// hi / lo of 16 W -- dst[(((w * 32 + s) * 4 + rt) * 2 + pl) * 64 + lane][j] (the factor keeps the lo parts of small weights normal; the
-// body's epilogue takes it out again)
-__device__ __forceinline__ void pack_w512(const float* __restrict__ W, int mode, __bf16* __restrict__ dst) {
+// mode 0 / 1: three bf16 planes, forward / transposed; mode 2 / 3 (forward / transposed, the f16x3 arithmetic of lin512_body<.., AR = 1>):
+// two fp16 planes hi / lo of 16 W -- dst[(((w * 32 + s) * 4 + rt) * 2 + pl) * 64 + lane][j] (the factor keeps the lo parts of small weights
+// normal; the body's epilogue takes it out again).  wbad: raised when a hi part is not finite (16 |w| >= 65520 or NaN)
+__device__ __forceinline__ void pack_w512(const float* __restrict__ W, int mode, __bf16* __restrict__ dst, int* __restrict__ wbad = nullptr) {
   const int total = 4 * 32 * 4 * 64;              // (w, s, rt, lane) slots of 8 values x 3 (2) planes
-  const bool transpose = mode == 1;
+  const bool transpose = mode == 1 || mode == 3;
+  bool bad = false;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63, rt = (i >> 6) & 3, s = (i >> 8) & 31, w = i >> 13;
     const int f = 128 * w + 32 * rt + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = transpose ? W[(size_t)(k0 + j) * 512 + f] : W[(size_t)f * 512 + k0 + j];
-    if (mode == 2) {
+    if (mode >= 2) {
       hf8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float x = v[j] * kF16Scale;
         hi[j] = (_Float16)x;
         lo[j] = (_Float16)(x - (float)hi[j]);
+        bad |= !(fabsf((float)hi[j]) <= 65504.0f);
       }
       hf8* d = reinterpret_cast<hf8*>(dst) + ((((size_t)w * 32 + s) * 4 + rt) * 2) * 64 + lane;
       d[0] = hi;
@@ -111,12 +113,13 @@ __device__ __forceinline__ void pack_w512(const float* __restrict__ W, int mode,
     d[64] = p1;
     d[128] = p2;
   }
+  if (bad && wbad) *wbad = 1;
 }
 __global__ void k_pack_w512(const float* __restrict__ W, int transpose, __bf16* __restrict__ dst) { pack_w512(W, transpose, dst); }
-// blockIdx.y = matrix, blockIdx.z = pack mode (0 forward, 1 transposed, 2 forward in fp16 hi / lo): all 512 x 512 weights of a training
+// blockIdx.y = matrix, blockIdx.z = pack mode (0 forward, 1 transposed, 2 / 3 the same in fp16 hi / lo): all 512 x 512 weights of a training
 // step in one launch
-__global__ void k_pack_w512_many(PackMany w, char* __restrict__ base) {
-  pack_w512(w.W[blockIdx.y], blockIdx.z, reinterpret_cast<__bf16*>(base + (size_t)(13 * blockIdx.z + blockIdx.y) * kL512PackBytes));
+__global__ void k_pack_w512_many(PackMany w, char* __restrict__ base, int* __restrict__ wbad) {
+  pack_w512(w.W[blockIdx.y], blockIdx.z, reinterpret_cast<__bf16*>(base + (size_t)(13 * blockIdx.z + blockIdx.y) * kL512PackBytes), wbad);
 }
 
 #ifndef DINER_L512_RING
@@ -140,6 +143,22 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * NP, NQ = 4 * CT;      // NQ: staging requests per wave and slab
   constexpr int NRT = 4 / FH, NF = NP * NRT;                 // MFMA row (= feature) tiles per wave, weight fragments per k16 step
   if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
+  if (a.skip && *a.skip != 0) {                              // f16x3 launch of a step whose weights do not fit: the bf16x6 twin works
+    if (a.ovf && threadIdx.x == 0) *a.ovf = 1;               // (the forward's twin is gated on this product's flag)
+    return;
+  }
+  // AR = 1 with amax_in: the staged operand times sx = 2^(14 - E), E the exponent of the operand's maximum; the epilogue takes it out
+  float sx = 1.0f, inv_scale = kF16InvScale;
+  if constexpr (AR == 1) {
+    if (a.amax_in) {
+      const unsigned e = (*a.amax_in >> 23) & 0xffu;          // (0 / tiny / inf / NaN maxima: no scaling)
+      if (e >= 32u && e < 255u) {
+        sx = __uint_as_float((268u - e) << 23);
+        inv_scale = kF16InvScale * __uint_as_float((e - 14u) << 23);
+      }
+    }
+  }
+  unsigned y_max = 0;                                        // amax_out: running maximum of the |Y| bit patterns this lane has stored
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char* lds_ptr;
   typedef __attribute__((address_space(3))) bf8* lds_bf8;
@@ -179,8 +198,8 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
     if constexpr (AR == 1) {
       // two values -> one hi word, one lo word; the halves are watched instead of the fp32 values: a half that is inf (0x7c00) or NaN
       // is an operand that left the fp16 range
-      const float x0 = __int_as_float(max(__float_as_int(xst[i][2 * half]), relu_floor));
-      const float x1 = __int_as_float(max(__float_as_int(xst[i][2 * half + 1]), relu_floor));
+      const float x0 = __int_as_float(max(__float_as_int(xst[i][2 * half]), relu_floor)) * sx;
+      const float x1 = __int_as_float(max(__float_as_int(xst[i][2 * half + 1]), relu_floor)) * sx;
       const unsigned h = cvt_pk_f16_w(x0, x1);
       const unsigned l = cvt_pk_f16_w(resid_lo_w(h, x0), resid_hi_w(h, x1));
       typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -337,7 +356,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
         for (int q4 = 0; q4 < 4; ++q4) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[4 * rt + q4][c] = acc[rt][ct][4 * q4 + c];
-          if constexpr (AR == 1) v[4 * rt + q4] *= kF16InvScale;
+          if constexpr (AR == 1) v[4 * rt + q4] *= inv_scale;
         }
       if (a.bias) {
         const float* bp = a.bias + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);
@@ -366,7 +385,18 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
       }
 #pragma unroll
       for (int n = 0; n < NV; ++n) *reinterpret_cast<f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3)) = v[n];
+      if (a.amax_out) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) y_max = max(y_max, __float_as_uint(v[n][c]) & 0x7fffffffu);
+      }
     }
+  }
+  if (a.amax_out) {                                          // (a NaN's pattern is the largest: it reaches the consumer, which then does not scale)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) y_max = max(y_max, (unsigned)__shfl_xor((int)y_max, o, 64));
+    if (lane == 0 && y_max) atomicMax(a.amax_out, y_max);
   }
   if constexpr (AR == 1) {                                   // an operand beyond the fp16 range (or not finite): the caller's bf16x6 launch recomputes
     if (a.ovf && ((x_max & 0xffffu) >= 0x7c00u || (x_max >> 16) >= 0x7c00u)) *a.ovf = 1;      // a hi half was inf or NaN
@@ -380,8 +410,8 @@ int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
   return 0;
 }
 
-int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream, int modes) {
-  hipLaunchKernelGGL(k_pack_w512_many, dim3(128, n, modes), dim3(256), 0, stream, w, (char*)base);
+int lin512_pack_many(const PackMany& w, int n, void* base, hipStream_t stream, int modes, int* wbad) {
+  hipLaunchKernelGGL(k_pack_w512_many, dim3(128, n, modes), dim3(256), 0, stream, w, (char*)base, wbad);
   DINER_LAUNCH_OK();
   return 0;
 }

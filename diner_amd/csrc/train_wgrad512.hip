@@ -29,7 +29,7 @@ typedef float f32x2w __attribute__((ext_vector_type(2)));
 
 constexpr int kWgFragsPerStep = (4 + 8) * 3;                     // [A: 4 f tiles | B: 8 k tiles][plane 3] fragments of 1 KB per k16 step
 constexpr int kWgSlabBytes = 2 * kWgFragsPerStep * 1024;         // two steps (32 rows) per slab: 72 KB
-constexpr size_t kLdsBytesWgrad = (size_t)2 * kWgSlabBytes;      // two slab buffers
+constexpr size_t kLdsBytesWgrad = (size_t)2 * kWgSlabBytes;      // two slab buffers (f16x3: two planes, 96 KB)
 constexpr int kWgMaxChunks = 32;                                 // row chunks (the scratch holds one partial dW + db per chunk)
 
 struct Wgrad512Args {
@@ -43,6 +43,11 @@ struct Wgrad512Args {
   int ldy, ldx, relu_x;
   int n_chunks;          // row chunks (grid = 8 * n_chunks)
   long long rows_per_chunk;      // multiple of 32
+  // round 4, the f16x3 instance (AR = 1): dY staged times the power of two that brings *amax_dy into [2^14, 2^15) (Lin512Args.amax_in), X as
+  // it is; skip / gate: the part does nothing when *skip != 0 / unless *gate != 0 (the f16x3 launch and its bf16x6 twin)
+  const unsigned* amax_dy;
+  const int* skip;
+  const int* gate;
 };
 
 template <class F, int... I>
@@ -55,9 +60,26 @@ __device__ __forceinline__ void wfor(F&& f) {
 }
 
 #define DINER_WG_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
+#define DINER_WG_MFMA_F16(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, A), __builtin_bit_cast(hf8, B), ACC, 0, 0, 0)
 
 // (bid: the workgroup's index within the weight-gradient part of its launch, train_512.hip)
+// AR: 0 = bf16x6 (three bf16 planes per operand, six product terms); 1 = f16x3 (two fp16 planes, three terms: half the MFMAs), see Wgrad512Args
+template <int AR = 0>
 __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int bid) {
+  constexpr int NP = AR == 1 ? 2 : 3;                        // planes per operand
+  constexpr int kFrags = (4 + 8) * NP, kSlab = 2 * kFrags * 1024;      // fragments per k16 step, bytes per slab buffer
+  if (a.gate && *a.gate == 0) return;
+  if (a.skip && *a.skip != 0) return;
+  float sy = 1.0f, inv_sy = 1.0f;
+  if constexpr (AR == 1) {
+    if (a.amax_dy) {
+      const unsigned e = (*a.amax_dy >> 23) & 0xffu;
+      if (e >= 32u && e < 255u) {
+        sy = __uint_as_float((268u - e) << 23);
+        inv_sy = __uint_as_float((e - 14u) << 23);
+      }
+    }
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char* lds_ptr;
   typedef __attribute__((address_space(3))) bf8w* lds_bf8;
@@ -95,14 +117,27 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
     yr[j] = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(yrs, yvoff, row * (unsigned)a.ldy * 4u, 0));
   };
   // LDS slots of this lane's fragments inside a slab buffer: step s = g >> 1, lane' = column & 31 + 32 (g & 1)
-  lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kWgFragsPerStep * 1024) + (32 * (g & 1)) * 16;
+  lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kFrags * 1024) + (32 * (g & 1)) * 16;
   // x columns 64 w + 4 li + c -> B tile 2 w + (li >> 3), lane' += 4 (li & 7) + c;   dy columns 32 w + 2 li + c -> A tile w, lane' += 2 li + c
-  const int xslot = ((4 + 2 * wave + (li >> 3)) * 3) * 1024 + (4 * (li & 7)) * 16;
-  const int yslot = (wave * 3) * 1024 + (2 * li) * 16;
+  const int xslot = ((4 + 2 * wave + (li >> 3)) * NP) * 1024 + (4 * (li & 7)) * 16;
+  const int yslot = (wave * NP) * 1024 + (2 * li) * 16;
   const int relu_floor = a.relu_x ? 0 : (int)0x80000000;
   float rs0 = 0.0f, rs1 = 0.0f;                              // row sums of this lane's two dy columns (bias gradient)
   bf8w sp0, sp1, sp2;                                        // the lane-fragment being converted (two halves of 4 rows)
   auto split_half = [&](const float (&v)[4], int half) {
+    if constexpr (AR == 1) {                                 // fp16 hi / lo in single instructions (train_lin512.hip, the inference kernels' idiom)
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      u4 w0 = __builtin_bit_cast(u4, sp0), w1 = __builtin_bit_cast(u4, sp1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned h = cvt_pk_f16_w(v[2 * j], v[2 * j + 1]);
+        w0[2 * half + j] = h;
+        w1[2 * half + j] = cvt_pk_f16_w(resid_lo_w(h, v[2 * j]), resid_hi_w(h, v[2 * j + 1]));
+      }
+      sp0 = __builtin_bit_cast(bf8w, w0);
+      sp1 = __builtin_bit_cast(bf8w, w1);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const __bf16 a0 = (__bf16)v[j];
@@ -116,7 +151,7 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
   auto store_frag = [&](lds_ptr d) {
     *(lds_bf8)(d) = sp0;
     *(lds_bf8)(d + 1024) = sp1;
-    *(lds_bf8)(d + 2048) = sp2;
+    if constexpr (NP == 3) *(lds_bf8)(d + 2048) = sp2;
   };
   // unit i (0..5): columns 0..3 of the lane's x block, then 0..1 of its dy block; half 0 / 1 = rows 0..3 / 4..7 (+ the store)
   auto stash_half = [&](int buf, int i, int half) {
@@ -130,9 +165,13 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
       for (int j = 0; j < 4; ++j) v[j] = yr[4 * half + j][i - 4];
       const float sum = (v[0] + v[1]) + (v[2] + v[3]);
       if (i == 4) rs0 += sum; else rs1 += sum;
+      if constexpr (AR == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= sy;
+      }
     }
     split_half(v, half);
-    if (half == 1) store_frag(sbase + buf * kWgSlabBytes + (i < 4 ? xslot + i * 16 : yslot + (i - 4) * 16));
+    if (half == 1) store_frag(sbase + buf * kSlab + (i < 4 ? xslot + i * 16 : yslot + (i - 4) * 16));
   };
   // ---- prologue: slab 0 staged, slab 1 requested
 #pragma unroll
@@ -159,25 +198,25 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
   for (int slab = 0; slab < n_slabs; ++slab) {
     const int buf = slab & 1;
     const long long m_next2 = m_begin + 32ll * (slab + 2);    // the slab requested while this one multiplies
-    lds_ptr rb = lbase + buf * kWgSlabBytes;
+    lds_ptr rb = lbase + buf * kSlab;
     asm volatile("" : "+v"(rb));
     wfor<2>([&](auto S) {
       constexpr int s = decltype(S)::value;
-      bf8w af[2][3], bfr[2][3];
+      bf8w af[2][NP], bfr[2][NP];
 #pragma unroll
       for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[fi][pl] = *(lds_bf8)(rb + (s * kWgFragsPerStep + (2 * wf + fi) * 3 + pl) * 1024);
+        for (int pl = 0; pl < NP; ++pl) af[fi][pl] = *(lds_bf8)(rb + (s * kFrags + (2 * wf + fi) * NP + pl) * 1024);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bfr[0][pl] = *(lds_bf8)(rb + (s * kWgFragsPerStep + (4 + 4 * wk) * 3 + pl) * 1024);
+      for (int pl = 0; pl < NP; ++pl) bfr[0][pl] = *(lds_bf8)(rb + (s * kFrags + (4 + 4 * wk) * NP + pl) * 1024);
       wfor<8>([&](auto G) {
         constexpr int gi = decltype(G)::value, kt = gi >> 1, fi = gi & 1;
         constexpr int u = s * 8 + gi;                        // 16 groups of 6 MFMAs per slab
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (fi == 0 && kt + 1 < 4) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            bfr[(kt + 1) & 1][pl] = *(lds_bf8)(rb + (s * kWgFragsPerStep + (4 + 4 * wk + kt + 1) * 3 + pl) * 1024);
+          for (int pl = 0; pl < NP; ++pl)
+            bfr[(kt + 1) & 1][pl] = *(lds_bf8)(rb + (s * kFrags + (4 + 4 * wk + kt + 1) * NP + pl) * 1024);
         }
         // staging side task: the next slab's six lane-fragment columns, each in two halves, groups 1..12; requests re-armed in group 13
         if constexpr (u >= 1 && u <= 12) stash_half(buf ^ 1, (u - 1) >> 1, (u - 1) & 1);
@@ -185,18 +224,25 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
 #pragma unroll
           for (int j = 0; j < 8; ++j) request(j, m_next2);
         }
-        const bf8w b0 = bfr[kt & 1][0], b1 = bfr[kt & 1][1], b2 = bfr[kt & 1][2];
         // smallest terms first
-        DINER_WG_MFMA(acc[fi][kt], af[fi][2], b0);
-        DINER_WG_MFMA(acc[fi][kt], af[fi][0], b2);
-        DINER_WG_MFMA(acc[fi][kt], af[fi][1], b1);
-        DINER_WG_MFMA(acc[fi][kt], af[fi][1], b0);
-        DINER_WG_MFMA(acc[fi][kt], af[fi][0], b1);
-        DINER_WG_MFMA(acc[fi][kt], af[fi][0], b0);
+        if constexpr (AR == 1) {
+          const bf8w b0 = bfr[kt & 1][0], b1 = bfr[kt & 1][1];
+          DINER_WG_MFMA_F16(acc[fi][kt], af[fi][1], b0);
+          DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], b1);
+          DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], b0);
+        } else {
+          const bf8w b0 = bfr[kt & 1][0], b1 = bfr[kt & 1][1], b2 = bfr[kt & 1][NP - 1];
+          DINER_WG_MFMA(acc[fi][kt], af[fi][NP - 1], b0);
+          DINER_WG_MFMA(acc[fi][kt], af[fi][0], b2);
+          DINER_WG_MFMA(acc[fi][kt], af[fi][1], b1);
+          DINER_WG_MFMA(acc[fi][kt], af[fi][1], b0);
+          DINER_WG_MFMA(acc[fi][kt], af[fi][0], b1);
+          DINER_WG_MFMA(acc[fi][kt], af[fi][0], b0);
+        }
         if constexpr (u >= 1 && u <= 12) {                   // the conversion between the MFMAs: <= 7 vector-ALU slots per 32-clock MFMA
 #pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          for (int i = 0; i < (AR == 1 ? 3 : 6); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, AR == 1 ? 8 : 6, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           }
         }
@@ -215,8 +261,9 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int f = 128 * ft + 32 * (2 * wf + fi) + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-        if (a.part) a.part[((size_t)chunk * 512 + f) * 512 + k] = acc[fi][kt][e];
-        else atomicAdd(a.dW + (size_t)f * 512 + k, acc[fi][kt][e]);
+        const float val = AR == 1 ? acc[fi][kt][e] * inv_sy : acc[fi][kt][e];
+        if (a.part) a.part[((size_t)chunk * 512 + f) * 512 + k] = val;
+        else atomicAdd(a.dW + (size_t)f * 512 + k, val);
       }
     }
   if (a.db && kt2 == 0) {                                    // one k tile column of workgroups adds the row sums of dy

@@ -156,8 +156,9 @@ class _Conf:
 
 def build_modules(sc, msd, device, normals=None):
     """The drop-in modules exactly as the reference builds them (import_obj of dotted paths, diner.py:47-48 /
-    pixelnerf.py:17-24), with the synthetic scene `sc` injected into the encoder (feature maps and
-    cameras set directly, no ResNet34 weights involved) and the MLP state dict `msd` loaded strictly.
+    pixelnerf.py:17-24), with the synthetic scene `sc` (or a LIST of scenes of one size = the SB objects of a training batch,
+    configs/train_dtu.yaml:16) injected into the encoder (feature maps and cameras set directly, no
+    ResNet34 weights involved) and the MLP state dict `msd` loaded strictly.
     -> (PixelNeRF on `device`, NeRFRendererDGS class)."""
     import torch as _t
     from src.util.import_helper import import_obj
@@ -168,15 +169,19 @@ def build_modules(sc, msd, device, normals=None):
     nerf.mlp_fine.load_state_dict(msd, strict=True)
     nerf = nerf.to(device).eval()
     enc = nerf.encoder
+    scs = list(sc) if isinstance(sc, (list, tuple)) else [sc]
     if normals is None:
         from src.util.depth2normal import depth2normal
-        normals = depth2normal(sc["depths"].to(device), sc["src_intrinsics"].to(device))
-    enc.depths, enc.depths_std = sc["depths"][None].to(device), sc["depths_std"][None].to(device)
-    enc.normals, enc.latent = normals[None].to(device), sc["latent"][None].to(device)
-    enc.nviews, enc.nobjects = int(sc["depths"].shape[0]), 1
-    Kin = sc["src_intrinsics"]
-    nerf.poses = sc["src_extrinsics"][None].to(device)
-    nerf.c = Kin[None, :, :2, -1].to(device)
-    nerf.focal = Kin[None][:, :, [0, 1], [0, 1]].to(device)
-    nerf.image_shape = sc["image_shape"].clone().to(device)
+        normals = [depth2normal(s["depths"].to(device), s["src_intrinsics"].to(device)) for s in scs]
+    elif not isinstance(normals, (list, tuple)):
+        normals = [normals]
+    st = lambda key: _t.stack([s[key] for s in scs]).to(device)
+    enc.depths, enc.depths_std = st("depths"), st("depths_std")
+    enc.normals, enc.latent = _t.stack([n.to(device) for n in normals]), st("latent")
+    enc.nviews, enc.nobjects = int(scs[0]["depths"].shape[0]), len(scs)
+    Kin = st("src_intrinsics")
+    nerf.poses = st("src_extrinsics")
+    nerf.c = Kin[:, :, :2, -1].contiguous()
+    nerf.focal = Kin[:, :, [0, 1], [0, 1]].contiguous()
+    nerf.image_shape = scs[0]["image_shape"].clone().to(device)
     return nerf, import_obj("src.models.nerf_renderer.NeRFRendererDGS")

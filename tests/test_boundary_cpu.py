@@ -203,7 +203,7 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
 
 def test_no_spill_code_in_the_training_kernels(tmp_path):
     """Codegen guard for the 512 x 512 layer products of the training path (csrc/train_512.hip): k_run512 (three tile shapes of the bf16x6
-    forward / data-gradient body + the weight-gradient body in one kernel, one wave per SIMD at 496 registers) and k_fwd512_f16x3 carry no
+    forward / data-gradient body + the weight-gradient body in one kernel, one wave per SIMD at 496 registers), k_fwd512_f16x3 and k_run512_f16x3 carry no
     scratch access at all, and their MFMAs are the 32 x 32 x 16 ones of the arithmetic they claim."""
     import re
     import shutil
@@ -218,8 +218,8 @@ def test_no_spill_code_in_the_training_kernels(tmp_path):
                           stderr=subprocess.DEVNULL)
     txt = out.read_text()
     found = {}
-    for name in ("k_run512", "k_fwd512_f16x3"):
-        m = re.search(r"^(\w*" + name + r"\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
+    for name in ("k_run512", "k_fwd512_f16x3", "k_run512_f16x3"):
+        m = re.search(r"^(\w*\d" + name + r"E\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)      # (Itanium mangling: <length><name>E...)
         assert m, name
         body = m.group(2).split("\n")
         assert not [l for l in body if "scratch_" in l], name
@@ -227,6 +227,9 @@ def test_no_spill_code_in_the_training_kernels(tmp_path):
     assert sum("v_mfma_f32_32x32x16_bf16" in l for l in found["k_run512"]) > 1000
     assert sum("v_mfma_f32_32x32x16_f16" in l for l in found["k_fwd512_f16x3"]) > 500
     assert not any("v_mfma_f32_32x32x16_bf16" in l for l in found["k_fwd512_f16x3"])
+    # round 4: the backward's launch in the f16x3 arithmetic (data gradient in its three shapes + the weight gradient)
+    assert sum("v_mfma_f32_32x32x16_f16" in l for l in found["k_run512_f16x3"]) >= 700
+    assert not any("v_mfma_f32_32x32x16_bf16" in l for l in found["k_run512_f16x3"])
 
 
 def test_bench_line_contract():

@@ -355,6 +355,37 @@ def test_render_at_metric_sample_counts(ops, precision, name):
           f"{e_rgb.max().item():.2e} depth {e_d.max().item():.2e}, PSNR of the image against the reference's {psnr:.1f} dB")
     assert n_a <= max_a and n_b <= max_b, (n_a, n_b)
     assert psnr >= psnr_floor
+    # (4) the denominator (G17, oracle/make_golden_seeds.py): the REFERENCE rendered the same rays with two other noise seeds.  A ray
+    # whose pick set differs is rendered from other stratified samples -- what another seed does to every ray -- so (i) the HIP image must
+    # be at least as close to the reference's image as the reference's own seed-to-seed distance (minus 1 dB), on all rays and on the
+    # differing rays alone, and (ii) the mean colour difference over the differing rays must vanish within the seed-to-seed standard
+    # error of that mean (no bias: PSNR against ground truth is unchanged in expectation).
+    s2s = load("g17_seed_to_seed.npz")
+    key = name.split("_")[0]
+    seeds = [T(s2s[f"{key}_rgb_s{i}"]) for i in (1, 2)]
+    psnr_of = lambda a, b: float(-10.0 * torch.log10((a - b).square().mean().clamp(min=1e-30)))
+    s2s_all = max(psnr_of(sr, ref_rgb) for sr in seeds)
+    assert abs(s2s_all - max(float(s2s[f"{key}_psnr_s1_vs_fixture"]), float(s2s[f"{key}_psnr_s2_vs_fixture"]))) < 1e-3
+    hr = rgb.cpu()
+    msg = f"{name} [{precision}] seed-to-seed (reference, two other noise seeds): all rays {s2s_all:.1f} dB vs HIP {psnr:.1f} dB"
+    assert psnr >= s2s_all - 1.0
+    if len(diff) >= 8:
+        d_hip = (hr[diff] - ref_rgb[diff])                                  # (n, 3)
+        d_seed = [(sr[diff] - ref_rgb[diff]) for sr in seeds]
+        s2s_diff = max(psnr_of(sr[diff], ref_rgb[diff]) for sr in seeds)
+        hip_diff = psnr_of(hr[diff], ref_rgb[diff])
+        # standard error of the per-ray mean difference under a change of seed, from both seeds' per-ray differences
+        per_ray = torch.cat([d.mean(-1) for d in d_seed])
+        se = float(per_ray.std() / np.sqrt(len(diff)))
+        bias = float(d_hip.mean())
+        worst_ray_hip = float(d_hip.abs().max())
+        worst_ray_seed = max(float(d.abs().max()) for d in d_seed)
+        msg += (f"; on the {len(diff)} differing rays {s2s_diff:.1f} dB vs HIP {hip_diff:.1f} dB, mean colour difference {bias:+.2e} against a "
+                f"seed-to-seed standard error of {se:.2e}, largest per-ray difference {worst_ray_hip:.3f} vs {worst_ray_seed:.3f}")
+        assert hip_diff >= s2s_diff - 1.0
+        assert abs(bias) <= 3.0 * se + 1e-6
+        assert worst_ray_hip <= worst_ray_seed * 1.05 + 1e-6
+    print(msg)
 
 
 def test_cfg5_fp16_mlp_psnr(ops):
