@@ -78,6 +78,7 @@ SIGNATURES = {
     "diner_composite_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_train_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
+    "diner_field_train_ws_layout": (C.c_int, [C.c_longlong, C.c_int, C.POINTER(C.c_longlong), C.c_int]),
     "diner_field_train_forward_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams), C.c_void_p, C.c_void_p,
                                                 C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_train_backward_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams),

@@ -1192,6 +1192,20 @@ extern "C" size_t diner_field_train_workspace_bytes(long long P, int nv) {
   return train_ws(P, nv).total * sizeof(float);
 }
 
+// test aid: where the forward keeps the pre-activations inside the workspace (float offsets): X[0..4] (residual stream entering block b;
+// rows = P nv for b < 3, P behind the view mean), H[0..4] (fc_0 outputs), x_last (entering lin_out), raw (lin_out's outputs)
+extern "C" int diner_field_train_ws_layout(long long P, int nv, long long* float_offsets, int n) {
+  DINER_CHECK_ARG(P > 0 && nv > 0 && float_offsets && n >= 12, "field_train_ws_layout: bad arguments (12 offsets)");
+  const TrainWs w = train_ws(P, nv);
+  for (int b = 0; b < 5; ++b) {
+    float_offsets[b] = (long long)w.X[b];
+    float_offsets[5 + b] = (long long)w.H[b];
+  }
+  float_offsets[10] = (long long)w.x_last;
+  float_offsets[11] = (long long)w.raw;
+  return 0;
+}
+
 extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
                                              const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
   DINER_CHECK_ARG(scene && xyz && viewdirs && out && workspace && P > 0, "field_train_forward: bad arguments");

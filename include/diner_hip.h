@@ -285,6 +285,11 @@ int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams*
                                   const float* viewdirs, long long P, float* out, void* workspace, void* stream);
 int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* params, const DinerMlpParams* grads,
                                    long long P, const float* d_out, void* workspace, float* d_latent_cl, void* stream);
+/* Test aid: float offsets into the training workspace of the pre-activations the forward saved -- [0..4] X_b, the residual stream
+ * entering block b (P*nv rows of 512 for b < 3, P rows behind the view mean), [5..9] H_b, the fc_0 outputs of block b, [10] the
+ * stream entering lin_out (P x 512), [11] lin_out's raw outputs (P x 4).  The signs of these values are the relu decisions of the
+ * forward (resnetfc.py:61-69): tests evaluate the reference's backward conditioned on them.  n >= 12. */
+int diner_field_train_ws_layout(long long P, int nv, long long* float_offsets, int n);
 
 /* ---- measurement aid (bench.py): per-kernel durations of the two field kernels ------------------
  * With profiling enabled every field call brackets k_field_pre / k_field_post with HIP events on the

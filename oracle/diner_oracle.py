@@ -289,8 +289,15 @@ def fill_up_uniform_samples(z, rays, noise_fill):
 # --------------------------------------------------------------------------------------
 # a7  ResnetFC                        (resnetfc.py:61-69, :129-159)
 # --------------------------------------------------------------------------------------
-def mlp_forward(w: MLPWeights, zx):
-    """zx (NV, B, d_latent + d_in) -> (B, d_out); views averaged before block `combine_layer`."""
+def mlp_forward(w: MLPWeights, zx, relu_masks=None):
+    """zx (NV, B, d_latent + d_in) -> (B, d_out); views averaged before block `combine_layer`.
+
+    relu_masks (test aid, NOT reference behaviour): dict(X=[5 bool tensors], H=[5], last=bool tensor) -- every relu(t) of
+    resnetfc.py:61-69 / :159 is evaluated as t * mask with the decisions of ANOTHER evaluation of the same network (the HIP
+    training forward's saved pre-activations).  Two fp32 evaluations put a few pre-activations that are within rounding of zero on
+    different sides of the relu; conditioned on one set of decisions, the gradients of the two must agree to round-off."""
+    act = (lambda t, m: torch.relu(t)) if relu_masks is None else (lambda t, m: t * m.to(t.dtype))
+    mk = (lambda k, b=None: None) if relu_masks is None else (lambda k, b=None: relu_masks[k] if b is None else relu_masks[k][b])
     z = zx[..., :w.d_latent]
     x = F.linear(zx[..., w.d_latent:], w.lin_in_w, w.lin_in_b)
     for b in range(len(w.fc0_w)):
@@ -298,9 +305,9 @@ def mlp_forward(w: MLPWeights, zx):
             x = torch.mean(x, dim=0)
         if b < w.combine_layer:
             x = x + F.linear(z, w.lin_z_w[b], w.lin_z_b[b])
-        net = F.linear(torch.relu(x), w.fc0_w[b], w.fc0_b[b])
-        x = x + F.linear(torch.relu(net), w.fc1_w[b], w.fc1_b[b])
-    return F.linear(torch.relu(x), w.lin_out_w, w.lin_out_b)
+        net = F.linear(act(x, mk("X", b)), w.fc0_w[b], w.fc0_b[b])
+        x = x + F.linear(act(net, mk("H", b)), w.fc1_w[b], w.fc1_b[b])
+    return F.linear(act(x, mk("last")), w.lin_out_w, w.lin_out_b)
 
 
 # --------------------------------------------------------------------------------------
@@ -320,9 +327,10 @@ def mlp_input(scene: Scene, xyz, viewdirs, num_freqs=6, freq_factor=6.28):
     return torch.cat((lat, zf, df), dim=-1)                                      # :128
 
 
-def pixelnerf_forward(scene: Scene, w: MLPWeights, xyz, viewdirs):
-    out = mlp_forward(w, mlp_input(scene, xyz, viewdirs))
-    return torch.cat([torch.sigmoid(out[..., :3]), torch.relu(out[..., 3:4])], dim=-1)   # :139-143
+def pixelnerf_forward(scene: Scene, w: MLPWeights, xyz, viewdirs, relu_masks=None):
+    out = mlp_forward(w, mlp_input(scene, xyz, viewdirs), relu_masks)
+    sigma = torch.relu(out[..., 3:4]) if relu_masks is None else out[..., 3:4] * relu_masks["sigma"].to(out.dtype)   # (test aid, see mlp_forward)
+    return torch.cat([torch.sigmoid(out[..., :3]), sigma], dim=-1)                       # :139-143
 
 
 # --------------------------------------------------------------------------------------

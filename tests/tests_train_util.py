@@ -31,3 +31,22 @@ def module_param_list(msd):
         else:
             names.append((f"fc{parts[2][-1]}_{kind}", int(parts[1])))
     return params, names
+
+
+def saved_relu_masks(out, P, nv=4):
+    """The relu decisions of the HIP training forward that produced `out` (diner_amd.train.field_train): signs of the pre-activations it
+    saved in its workspace (diner_field_train_ws_layout) -> the relu_masks dict of oracle.diner_oracle.mlp_forward (CPU bool tensors)."""
+    import ctypes as C
+    from diner_amd import _lib
+    lib = _lib.load()
+    ws = out.grad_fn.saved_tensors[0]
+    off = (C.c_longlong * 12)()
+    _lib.check(lib.diner_field_train_ws_layout(P, nv, off, 12))
+    wf = ws.view(torch.float32)
+
+    def grab(o, rows, cols=512):
+        return (wf[o:o + rows * cols].view(rows, cols) > 0).cpu()
+    X = [grab(off[b], P * nv).view(nv, P, 512) if b < 3 else grab(off[b], P) for b in range(5)]
+    H = [grab(off[5 + b], P * nv).view(nv, P, 512) if b < 3 else grab(off[5 + b], P) for b in range(5)]
+    raw = grab(off[11], P, 4)
+    return dict(X=X, H=H, last=grab(off[10], P), sigma=raw[:, 3:4])
