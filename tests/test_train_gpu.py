@@ -456,3 +456,105 @@ def test_training_forward_beyond_the_fp16_range(ops):
             worst = max(worst, max_norm_rel(p.grad.cpu(), want))
     print(f"beyond the fp16 range: forward max abs difference {e_fwd:.2e} (sigma up to {float(out_o[:, 3].max()):.3g}), worst parameter gradient {worst:.2e}")
     assert max_norm_rel(out.detach().cpu(), out_o) < 2e-5 and worst < TOL_GRAD
+
+
+def _field_nodes(t):
+    """autograd nodes of diner_amd.train.FieldFunction under tensor t, in the order of the objects of the batch (torch.stack keeps it)."""
+    seen, out, stack = set(), [], [t.grad_fn]
+    while stack:
+        n = stack.pop(0)
+        if n is None or n in seen:
+            continue
+        seen.add(n)
+        if "FieldFunction" in type(n).__name__:
+            out.append(n)
+            continue
+        stack.extend(f for f, _ in n.next_functions)
+    return out
+
+
+def test_training_step_two_objects_patch_of_rays(ops):
+    """The step the shipped configs run, in small (DINER.calc_losses, diner.py:217-290 with configs/train_dtu.yaml:16,63: SB objects, a square
+    patch of rays per object, ONE renderer.forward on (SB, B, 8) rays in grad mode): SB = 2 objects with their own source views and
+    feature maps, a 32 x 32 patch each (the shipped patch is 64 x 64 = 4096 rays; the CPU oracle's saved activations are 10 GB per object at
+    32 x 32 already), loss on fine.rgb.  Statements: per-object rgb as the inference path; gradients of every MLP parameter -- SUMMED over the
+    objects by autograd across the per-object gradient sets -- and of each object's slab of encoder.latent against torch autograd through
+    the CPU oracle: in the Frobenius norm unconditioned, at 1e-4 max-norm conditioned on the HIP forward's relu decisions."""
+    from diner_amd import noise
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict, build_modules
+    from tests.tests_train_util import oracle_key, saved_relu_masks
+    from src.util.depth2normal import depth2normal
+    W = H = 64
+    SB, side, K, G, n_cand = 2, 32, 40, 15, 1000
+    NR = side * side
+    scs = [make_scene(W, H, seed=11 + s) for s in range(SB)]
+    msd = make_mlp_state_dict()
+    nerf, R = build_modules(scs, msd, torch.device("cuda", 0))
+    nerf.train()
+    nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+    E = torch.stack([s["target_extrinsics"] for s in scs])
+    Km = torch.stack([s["target_intrinsics"] for s in scs])
+    rays_all = ops.gen_rays(E, Km, W, H, scs[0]["znear"], scs[0]["zfar"], "cuda:0")
+    ys, xs = torch.meshgrid(torch.arange(side) + (H - side) // 2, torch.arange(side) + (W - side) // 2, indexing="ij")
+    idx = (ys * W + xs).reshape(-1).cuda()
+    r = rays_all[:, idx].contiguous()                                       # (SB, NR, 8)
+    gen = torch.Generator().manual_seed(77)
+    inj = (torch.rand(SB, NR, n_cand, generator=gen).cuda(), torch.randn(SB, NR, G, generator=gen).cuda(),
+           torch.rand(SB, NR, K, generator=gen).cuda())
+    ren = R(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=True)
+    with noise.inject(*inj):
+        with torch.no_grad():
+            z = ren.fill_up_uniform_samples(ren.sample_depthguided(r, nerf, K, n_cand, n_gaussian=G), r)
+            ref_out = ren.forward(nerf, r).fine.rgb
+        out = ren.forward(nerf, r)
+    assert out.fine.rgb.shape == (SB, NR, 3) and out.fine.rgb.requires_grad
+    assert max_norm_rel(out.fine.rgb.detach().cpu(), ref_out.cpu()) < 2e-5
+    nodes = _field_nodes(out.fine.rgb)
+    assert len(nodes) == SB
+    masks = [saved_relu_masks(type("o", (), {"grad_fn": n})(), NR * K) for n in nodes]
+    Gm = torch.randn(SB, NR, 3, generator=gen)
+    (out.fine.rgb * Gm.cuda()).sum().backward()
+    assert nerf.encoder.latent.grad.shape == nerf.encoder.latent.shape
+
+    def oracle(cond):
+        w = O.MLPWeights.from_state_dict(msd)
+        leaves = {}
+        for k, v in vars(w).items():
+            for i, t in enumerate(v if isinstance(v, (list, tuple)) else [v]):
+                if torch.is_tensor(t) and t.is_floating_point():
+                    leaves[(k, i if isinstance(v, (list, tuple)) else None)] = t.requires_grad_(True)
+        dlat, rgbs = [], []
+        for sb, sc in enumerate(scs):
+            normals = depth2normal(sc["depths"], sc["src_intrinsics"])
+            Kin = sc["src_intrinsics"]
+            scene = O.Scene(latent=sc["latent"].clone().requires_grad_(True), depths=sc["depths"], depths_std=sc["depths_std"], normals=normals,
+                            poses=sc["src_extrinsics"], focal=Kin[:, [0, 1], [0, 1]], c=Kin[:, :2, -1], image_shape=sc["image_shape"],
+                            feature_padding=sc["feature_padding"])
+            rc, zc = r[sb].cpu(), z[sb].cpu()
+            xyz = (rc[:, None, :3] + zc[..., None] * rc[:, None, 3:6]).reshape(-1, 3)
+            dirs = rc[:, None, 3:6].expand(-1, K, -1).reshape(-1, 3)
+            field = O.pixelnerf_forward(scene, w, xyz, dirs, masks[sb] if cond else None).view(NR, K, 4)
+            _, rgb_o, _ = O.composite_from_field(field, rc, zc, True)
+            (rgb_o * Gm[sb]).sum().backward()                               # weight gradients accumulate over the objects
+            dlat.append(scene.latent.grad)
+            rgbs.append(rgb_o.detach())
+        return leaves, dlat, rgbs
+
+    rms = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+    for cond in (False, True):
+        leaves, dlat, rgbs = oracle(cond)
+        for sb in range(SB):
+            assert max_norm_rel(out.fine.rgb[sb].detach().cpu(), rgbs[sb]) < 2e-5
+        worst = max(((n, max_norm_rel(p.grad.cpu(), leaves[oracle_key(n)].grad), rms(p.grad.cpu(), leaves[oracle_key(n)].grad))
+                     for n, p in nerf.mlp_fine.named_parameters()), key=lambda t: t[1])
+        e_lat = max(max_norm_rel(nerf.encoder.latent.grad[sb].cpu(), dlat[sb]) for sb in range(SB))
+        r_lat = max(rms(nerf.encoder.latent.grad[sb].cpu(), dlat[sb]) for sb in range(SB))
+        r_par = max(rms(p.grad.cpu(), leaves[oracle_key(n)].grad) for n, p in nerf.mlp_fine.named_parameters())
+        print(f"SB=2 x {side}x{side} patch, {'conditioned on the HIP relu decisions' if cond else 'unconditioned'}: worst parameter gradient "
+              f"{worst[0]} max-norm {worst[1]:.2e} (Frobenius {r_par:.2e}), d latent per object max-norm {e_lat:.2e} (Frobenius {r_lat:.2e})")
+        if cond:
+            assert worst[1] < TOL_GRAD and e_lat < TOL_GRAD
+        else:
+            assert r_par < 3e-3 and r_lat < 3e-3
+    # the per-object slabs of the latent gradient are different (each object's own rays and maps)
+    assert not torch.equal(nerf.encoder.latent.grad[0], nerf.encoder.latent.grad[1])
