@@ -1137,6 +1137,10 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
       res += *reinterpret_cast<const f32x4*>(bpost + 4 * kHidden + 4 * q_o);     // lin_out bias kept at scale 1
       const long long t16 = tile * 4 + wave;
       const long long p = t16 * kPtsPerWave + pt;
+      // the residual-stream range test of ANY wave raises the flag, whether or not this wave's column group holds points of the launch (a
+      // ragged last tile repeats its last 16-point group: the repeats are real columns) -- detection does not rest on an overflow having
+      // spread to the features of a wave that stores
+      if (pa.overflow && wave_bad && lane_here() == 0) *pa.overflow = 1;
       if (t16 < n_t16 && q_o == 0 && p < pa.P) {
         // A hidden activation beyond the fp16 range turns into inf in a B operand and reaches every raw output of the
         // point as inf / NaN (so does a non-finite input): raise the flag that un-gates the exact-fp32 pass (mlp.hip).

@@ -1127,7 +1127,8 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   long long split = M / rows_per_chunk;
   split = split < 1 ? 1 : (split > cap ? cap : split);
   if (N == 512 && K == 512 && M >= 256 && use_wgrad512() && (ldy & 1) == 0 && (ldx & 3) == 0 &&
-      (reinterpret_cast<size_t>(dy) & 7) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {
+      (reinterpret_cast<size_t>(dy) & 7) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 &&
+      (reinterpret_cast<size_t>(dW) & 15) == 0 && (reinterpret_cast<size_t>(db) & 15) == 0) {      // (the summing pass stores dW / db as 16-byte vectors)
     // the 512 x 512 layers: persistent feature-sliced kernel (train_wgrad512.hip), bias gradient = row sums of its dy operand
     // with the scratch: partial tiles + one summing pass that OVERWRITES dW / db (no zeroing, no atomics)
     if (!wgpart) {
@@ -1229,7 +1230,8 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
   }
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
                  bool accum, const float* resid = nullptr, int slot = -1, const float* resid2 = nullptr) {
-    if (slot >= 0 && N == 512 && K == 512 && lin512_ok(x, ldx, y, N, resid, nullptr)) {
+    if (slot >= 0 && N == 512 && K == 512 && lin512_ok(x, ldx, y, N, resid, nullptr) && (reinterpret_cast<size_t>(b) & 15) == 0 &&
+        (reinterpret_cast<size_t>(resid2) & 15) == 0) {      // (the epilogue reads bias / residuals as 16-byte vectors)
       void* wp = wpack_slot(ws, w, slot, false);
       Lin512Args a{x, wp, y, b, resid, nullptr, M, ldx, N, (relu ? kL512ReluIn : 0) | (accum ? kL512Accum : 0)};
       a.resid2 = resid2;

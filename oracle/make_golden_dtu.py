@@ -35,7 +35,7 @@ def write_png16(path, a):
 
 
 def build_tree():
-    from diner_amd.imageio import write_png
+    from diner_amd.png import write_png
     from diner_amd.synthetic import look_at_extrinsics
     g = np.random.default_rng(13)
     os.makedirs(os.path.join(TREE, "Cameras", "train"), exist_ok=True)

@@ -25,7 +25,7 @@ SPLITS = os.path.join(TREE, "splits")          # publishable_list_v1.txt lives h
 
 
 def build_tree():
-    from diner_amd.imageio import write_png
+    from diner_amd.png import write_png
     from diner_amd.synthetic import look_at_extrinsics
     from oracle.make_golden_dtu import write_png16
     g = np.random.default_rng(14)

@@ -31,7 +31,7 @@ def cam_centre(az, el, r=1000.0):
 
 
 def build_tree():
-    from diner_amd.imageio import write_png
+    from diner_amd.png import write_png
     from diner_amd.synthetic import look_at_extrinsics
     from oracle.make_golden_dtu import write_png16
     g = np.random.default_rng(15)

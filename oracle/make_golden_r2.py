@@ -60,7 +60,7 @@ def setup(ns, W, H, seed, **scene_kw):
     return sc, nerf, scene, w, rays
 
 
-def render_fixture(ns, name, W, H, seed, K, G, white, noise_seed, scene_kw, n_lattice=64):
+def render_fixture(ns, name, W, H, seed, K, G, white, noise_seed, scene_kw, n_lattice=64, tie_likelihood_max=1e-4):
     n_cand = 1000
     sc, nerf, scene, w, rays = setup(ns, W, H, seed, **scene_kw)
     idx = lattice(W, H, n_lattice)
@@ -97,7 +97,10 @@ def render_fixture(ns, name, W, H, seed, K, G, white, noise_seed, scene_kw, n_la
         # ulp of erf near 1), so a few coincide.  Which of two tied candidates the reference keeps is decided by torch's
         # unstable argsort on this host; the fixture lists those rays, tests do not require the same pick on them.
         print(f"    tie rays {tie_rays.tolist()} at likelihoods {[float(Ls[r, K - G]) for r in tie_rays]}")
-    assert ties <= 8           # (G9 / G10: all below 1e-4; G16 has one exact tie at 1.8e-3: two candidates mirrored about the surface)
+    assert ties <= 8
+    # exact ties at the cut-off only among small likelihoods: below 1e-4 for G9 / G10; G16 has one exact tie at 1.8e-3 (two candidates
+    # mirrored about the surface) and says so in its call
+    assert all(float(Ls[r, K - G]) < tie_likelihood_max for r in tie_rays), [float(Ls[r, K - G]) for r in tie_rays]
     np.savez_compressed(os.path.join(OUT, name + ".npz"), W=W, H=H, seed=seed, K=K, G=G, n_cand=n_cand,
                         white_bkgd=int(white), noise_seed=noise_seed, znear=sc["znear"], zfar=sc["zfar"],
                         ray_idx=idx.numpy(), rays=rs.numpy(), tie_rays=tie_rays.numpy(), in_sha=sha(ncz[:64], ngz[:64], nfz[:64]),
@@ -156,7 +159,7 @@ def main():
                            dict(scale=1.75, znear=1.0, zfar=2.5, std_law="facescape"))
         if "g16" in which:
             print("G16 renderer.forward K=192/G=72, DTU sigma law and range, 2304 rays of the 400x300 bench scene")
-            render_fixture(ns, "g16_render_K192_dtu", 400, 300, 0, 192, 72, False, 116, {}, n_lattice=48)
+            render_fixture(ns, "g16_render_K192_dtu", 400, 300, 0, 192, 72, False, 116, {}, n_lattice=48, tie_likelihood_max=2e-3)
     print("done")
 
 

@@ -445,6 +445,17 @@ def test_fp16_overflow_falls_back_to_exact_kernels(ops):
         for mode in ("f16x3", "f16"):
             assert torch.equal(ops.field_from_points(hs, hh, pts, dirs, precision=mode), exact), (key, mode)
         assert hh.fallback_launches() == 2, key
+    # ragged launches (P % 64 != 0: the last post tile holds column groups without points; P % 16 != 0: a ragged 16-point group) with the
+    # overflow in the LAST point only -- the flag must come up whichever wave sees it
+    n_all = pts.shape[0]
+    for P1 in (n_all - (n_all % 64) - 23, 16 * 5 + 3, 7):
+        hot = {k: v.clone() for k, v in msd.items()}
+        hot["blocks.3.fc_0.bias"] = hot["blocks.3.fc_0.bias"] + 1.0e5 * (torch.arange(512) % 7 == 0)
+        hr = hip_mlp(ops, hot)
+        exact = ops.field_from_points(hs, hr, pts[:P1], dirs[:P1], precision="fp32")
+        for mode in ("f16x3", "f16"):
+            assert torch.equal(ops.field_from_points(hs, hr, pts[:P1], dirs[:P1], precision=mode), exact), (P1, mode)
+        assert hr.fallback_launches() == 2, P1
 
 
 def test_scene_prepared_with_another_handle_is_refused(ops):
