@@ -257,7 +257,7 @@ def main():
             def step(seed, precision, max_rays=None):
                 ops.set_precision(precision)
                 try:
-                    nerf.hip_scene(0).prepare(nerf.hip_mlp(), force=True)   # the hoist belongs to the frame (see below)
+                    nerf.hip_scene(0).prepare(nerf.hip_mlp(), force=True, f16=precision == ops.PRECISION_F16)   # the hoist belongs to the frame (see below)
                     if max_rays is not None:                                # warm-up on the first rays only
                         with torch.no_grad():
                             rr = ops.gen_rays(tE, tK, W, H, sc["znear"], sc["zfar"], dev, ray0=0, n_rays=min(NRF, max_rays))
@@ -291,7 +291,7 @@ def main():
         def step(seed, precision, max_rays=None):
             # per-scene preparation (projection of the latent through lin_z[0..2]) is redone every
             # frame inside the timed region, so that no cached per-scene output is excluded from the measurement
-            scene.prepare(mlp, force=True)
+            scene.prepare(mlp, force=True, f16=precision == ops.PRECISION_F16)      # (the fp16 copy of the maps belongs to the f16 mode's frame)
             n = hi - lo if max_rays is None else min(hi - lo, max_rays)
             render_range(lo, lo + n, seed, precision, out)
             if multi and not args.weak:
@@ -402,14 +402,14 @@ def main():
         else:
             n_em = 8                                    # one rank: the 8 ray ranges of an 8-way shard rendered in turn
             sharded = torch.empty(NRF, 4, device=dev)
-            scene.prepare(mlp, force=True)
+            scene.prepare(mlp, force=True, f16=head == ops.PRECISION_F16)
             for r in range(n_em):
                 a, b = shard_range(NRF, r, n_em)
                 rr(a, b, CHECK_SEED, head, sharded[a:b])
             how = f"{n_em} ray ranges rendered in turn by one rank (emulation)"
         if rank == 0:
             single = torch.empty(NRF, 4, device=dev)
-            scene.prepare(mlp, force=True)
+            scene.prepare(mlp, force=True, f16=head == ops.PRECISION_F16)
             rr(0, NRF, CHECK_SEED, head, single)
             torch.cuda.synchronize()
             sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16]

@@ -12,7 +12,7 @@ class DinerScene(C.Structure):
                 ("std_pad_scale", C.c_void_p),
                 ("img_w", C.c_float), ("img_h", C.c_float), ("feature_padding", C.c_float),
                 ("nv", C.c_int32), ("C", C.c_int32), ("Hf", C.c_int32), ("Wf", C.c_int32),
-                ("Hs", C.c_int32), ("Ws", C.c_int32), ("proj_stamp", C.c_uint64)]
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("proj_stamp", C.c_uint64), ("latent_proj_f16", C.c_void_p)]
 
 
 class DinerMlpParams(C.Structure):
@@ -42,6 +42,8 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p]),
     "diner_scene_proj_bytes": (C.c_size_t, [C.POINTER(DinerScene)]),
     "diner_scene_prepare_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_scene_proj_f16_bytes": (C.c_size_t, [C.POINTER(DinerScene)]),
+    "diner_scene_prepare_f16": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p]),
     "diner_field_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "diner_field_from_rays_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -92,7 +94,7 @@ SIGNATURES = {
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),
 }
 
-ABI_VERSION = 3          # DINER_ABI_VERSION of include/diner_hip.h
+ABI_VERSION = 4          # DINER_ABI_VERSION of include/diner_hip.h
 _lib = None
 
 

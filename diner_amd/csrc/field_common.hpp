@@ -208,6 +208,7 @@ struct FieldArgs {
   const float* direct_feat;     // (NV*P, 64)   explicit MLP inputs (ResnetFC.forward on a matrix); tz rows = (3, NV*P, 512)
   const float* tz;              // hoisted projections: (3, NV, Hf, Wf, 512) of the scene, or (3, NV*P, 512) rows
   size_t tz_stride;             // floats between lin_z[b] and lin_z[b+1] maps
+  const void* tz16;             // the same maps in fp16, channels in the plain-fp16 kernel's order (DinerScene.latent_proj_f16), or null
   long long P;
   int K;
   float freq_factor;            // PositionalEncoding.freq_factor of the MLP handle (6.28 in every shipped config)

@@ -572,6 +572,26 @@ __global__ void k_absmax(const float* __restrict__ x, long long n, float* __rest
   }
 }
 
+// fp32 projected maps -> fp16 in the plain-fp16 kernel's channel order (mlp_h3n.hip, GatherSideH): position 128 w + 32 mp + 8 q + 4 t + i
+// of a texel's 512 halves holds channel 128 w + 16 (2 mp + t) + 4 q + i.  One thread per 8 output halves (two f32x4 reads 64 B apart).
+__global__ __launch_bounds__(256) void k_proj_to_f16(const float* __restrict__ src, long long rows, _Float16* __restrict__ dst) {
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  const long long n = rows * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i >> 6;
+    const int o = (int)(i & 63), w = o >> 4, mp = (o >> 2) & 3, q = o & 3;
+    const float* s = src + row * kLatent + 128 * w + 32 * mp + 4 * q;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 16);
+    h8v h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = (_Float16)a[j];
+      h[4 + j] = (_Float16)b[j];
+    }
+    reinterpret_cast<h8v*>(dst)[i] = h;
+  }
+}
+
 // ---- per-device launch state: function attributes (dynamic LDS above 64 KB) are per device, and so is the CU count ----
 constexpr int kMaxDevices = 64;
 struct DeviceState {
@@ -636,6 +656,11 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
     return DINER_E_UNSUPPORTED;
   }
   const bool split = precision != DINER_PRECISION_F16;
+  if (use_hn && !split && !fa.tz16) {
+    set_error("field: DINER_PRECISION_F16 gathers from the fp16 copy of the projected maps -- call diner_scene_prepare_f16 and set "
+              "scene->latent_proj_f16 (or use DINER_PRECISION_F16X3 / _FP32)");
+    return DINER_E_INVALID;
+  }
   fa.w_pre = m->w_pre;
   fa.b_pre = m->b_pre;
   fa.xpre = (float*)workspace;
@@ -899,6 +924,7 @@ extern "C" int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp
   fa.K = K;
   fa.P = (long long)NR * K;
   fa.tz = scene->latent_proj;
+  fa.tz16 = scene->latent_proj_f16;
   fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
   return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, precision, (hipStream_t)stream);
 }
@@ -918,6 +944,7 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
   fa.K = 1;
   fa.P = P;
   fa.tz = scene->latent_proj;
+  fa.tz16 = scene->latent_proj_f16;
   fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
   return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, precision, (hipStream_t)stream);
 }
@@ -958,6 +985,19 @@ extern "C" int diner_scene_prepare_f32(const DinerScene* scene, const DinerMlp* 
                   "scene_prepare: channels-last latent (NV,Hf,Wf,%d) missing", kLatent);
   return launch_hoist(&mlp->impl, scene->latent_cl, (long long)scene->nv * scene->Hf * scene->Wf, latent_proj_out,
                       (hipStream_t)stream);
+}
+
+extern "C" size_t diner_scene_proj_f16_bytes(const DinerScene* scene) { return diner_scene_proj_bytes(scene) / 2; }
+
+extern "C" int diner_scene_prepare_f16(const DinerScene* scene, void* latent_proj_f16_out, void* stream) {
+  DINER_CHECK_ARG(scene && latent_proj_f16_out, "scene_prepare_f16: null pointer argument");
+  DINER_CHECK_ARG(scene->latent_proj && scene->C == kLatent && scene->Hf > 0 && scene->Wf > 0 && scene->nv > 0,
+                  "scene_prepare_f16: scene->latent_proj (diner_scene_prepare_f32) missing");
+  DINER_CHECK_ARG((reinterpret_cast<size_t>(latent_proj_f16_out) & 15) == 0, "scene_prepare_f16: output must be 16-byte aligned");
+  const long long rows = 3ll * scene->nv * scene->Hf * scene->Wf;
+  hipLaunchKernelGGL(k_proj_to_f16, dim3(4096), dim3(256), 0, (hipStream_t)stream, scene->latent_proj, rows, (_Float16*)latent_proj_f16_out);
+  DINER_LAUNCH_OK();
+  return 0;
 }
 
 extern "C" int diner_render_f32(const DinerScene* scene, const DinerMlp* mlp, const float* rays, const float* z, int NR,

@@ -666,6 +666,12 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[kSlice][kGroups], const fl
 #ifndef DINER_HN_GDEPTH_F16
 #define DINER_HN_GDEPTH_F16 3
 #endif
+#ifndef DINER_HN_GDEPTH_H        // GatherSideH (fp16 maps): units between request and blend as a GEMM side task / stand-alone
+#define DINER_HN_GDEPTH_H 2
+#endif
+#ifndef DINER_HN_G0DEPTH_H
+#define DINER_HN_G0DEPTH_H 4
+#endif
 
 // xs[mo][g] += 16 * interp(lin_z[b](latent)) for this wave's feature slice and all four column groups: 32 units
 // (g, mo) of 4 taps each.  As a GEMM side task (SIDE) one unit's taps are requested per half-step, one per quarter-step, and
@@ -784,6 +790,104 @@ struct GatherSide {
   }
 };
 
+// The same side task for the plain-fp16 instances (round 4): the taps come from the FP16 copy of the projected maps
+// (DinerScene.latent_proj_f16, written by k_proj_to_f16 in mlp.hip), whose 512 channels are stored in the order this kernel consumes
+// them -- position 128 w + 32 mp + 8 q + 4 (mo & 1) + i holds channel 128 w + 16 mo + 4 q + i (mp = mo / 2) -- so that ONE 16-byte load
+// per lane and tap carries the lane's four rows of TWO row tiles: half the load instructions, half the bytes through the vector-memory
+// path (which, not the matrix pipe, bounds these instances: at one MFMA per product the weight stream alone needs the path's 64 B/clk,
+// profiles/r04_cfg5_f16_*).  16 units (g, mp) of 4 taps; unit U is requested during half-step 2 U (tap G in quarter-step G) and
+// blended D units later, row tile 2 mp during the even half-step, 2 mp + 1 during the odd one: the blend is v_fma_mix_f32 (fp16 tap x
+// fp32 weight + fp32 sum: full rate, one per value as before).
+template <int D, bool SIDE = true>
+struct GatherSideH {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const char* __restrict__ tz;             // fp16 map of this block: (NV, Hf, Wf, 512) halves, 1 KB per texel
+  const TapRec* __restrict__ taps_lds;     // [g 4][col 16]
+  int wave, q, pt;
+  f32x4 (&xs)[kSlice][kGroups];
+  u32x4 r[D + 1][4];
+  u32x4 off4[kGroups];
+  f32x4 w4[kGroups];
+  f32x4 bw, bv;
+
+  __device__ __forceinline__ GatherSideH(const void* tz_, const TapRec* taps_lds_, int wave_, int q_, int pt_, f32x4 (&xs_)[kSlice][kGroups])
+      : tz(reinterpret_cast<const char*>(tz_)), taps_lds(taps_lds_), wave(wave_), q(q_), pt(pt_), xs(xs_) {
+    prefetch<0>();
+  }
+  template <int g>
+  __device__ __forceinline__ void prefetch() {
+    off4[g] = *reinterpret_cast<const u32x4*>(taps_lds[g * 16 + pt].off);
+    w4[g] = *reinterpret_cast<const f32x4*>(taps_lds[g * 16 + pt].w) * kScale;
+  }
+  template <int U, int KTAP>
+  __device__ __forceinline__ void issue_tap() {
+    constexpr int g = U >> 2, mp = U & 3;
+    const unsigned lane_off = (unsigned)(wave * 256 + q * 16);
+    r[U % (D + 1)][KTAP] = *reinterpret_cast<const u32x4*>(tz + (off4[g][KTAP] * 1024u + lane_off) + mp * 64);
+  }
+  static __device__ __forceinline__ float mix_lo(unsigned h, float w, float c) {      // float(low half of h) * w + c
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "v"(c));
+    return d;
+  }
+  static __device__ __forceinline__ float mix_hi(unsigned h, float w, float c) {      // float(high half of h) * w + c
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "v"(c));
+    return d;
+  }
+  // tap K of unit U into row tile 2 mp + HF: the blend is summed on its own and added to the accumulator in ONE step behind tap 3 (the
+  // GEMM this rides on accumulates into the same registers between the quarter-steps)
+  template <int U, int HF, int K>
+  __device__ __forceinline__ void blend_step() {
+    constexpr int g = U >> 2, mo = 2 * (U & 3) + HF;
+    const u32x4& t = r[U % (D + 1)][K];
+    if constexpr (K == 0) {
+      bw = w4[g];
+      asm volatile("" : "+v"(bw));           // (see GatherSide::blend_step)
+      bv = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    bv[0] = mix_lo(t[2 * HF], bw[K], bv[0]);
+    bv[1] = mix_hi(t[2 * HF], bw[K], bv[1]);
+    bv[2] = mix_lo(t[2 * HF + 1], bw[K], bv[2]);
+    bv[3] = mix_hi(t[2 * HF + 1], bw[K], bv[3]);
+    if constexpr (K == 3) {
+      asm volatile("" : "+a"(xs[mo][g]));      // keep the accumulator file assignment: read, add, write back
+      f32x4 acc = xs[mo][g];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = add1(acc[i], bv[i]);
+      xs[mo][g] = acc;
+      asm volatile("" : "+a"(xs[mo][g]));
+    }
+  }
+  template <int H, int G>
+  __device__ __forceinline__ void run() {
+    constexpr int U = H >> 1, V = U - D;
+    if constexpr (V >= 0 && V < 16) blend_step<(V >= 0 && V < 16 ? V : 0), (H & 1), G>();
+    if constexpr ((H & 1) == 0 && U < 16) issue_tap<(U < 16 ? U : 0), G>();
+    if constexpr (G == 1 && (H & 7) == 7 && H < 31) prefetch<(H < 31 ? (H + 1) >> 3 : 0)>();
+  }
+  __device__ __forceinline__ void finish() {
+    static_for<D>([&](auto I) {
+      constexpr int V = 16 - D + decltype(I)::value;
+      static_for<2>([&](auto HF) {
+        blend_step<V, decltype(HF)::value, 0>();
+        blend_step<V, decltype(HF)::value, 1>();
+        blend_step<V, decltype(HF)::value, 2>();
+        blend_step<V, decltype(HF)::value, 3>();
+      });
+    });
+  }
+  __device__ __forceinline__ void all() {
+    static_for<32>([&](auto H) {
+      run<decltype(H)::value, 0>();
+      run<decltype(H)::value, 1>();
+      run<decltype(H)::value, 2>();
+      run<decltype(H)::value, 3>();
+    });
+    finish();
+  }
+};
+
 template <bool LO>
 __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   constexpr int kRing = LO ? DINER_HN_RING : DINER_HN_RING_F16, kRing0 = LO ? DINER_HN_RING0 : DINER_HN_RING0_F16;
@@ -861,8 +965,13 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       NoSide none;
       gemm<2, 2, LO>(w_in, Bl, wave, lane, xs, none);
       pf.mark(4);
-      GatherSide<DINER_HN_G0DEPTH, false> g0(fa.tz, taps_lds, wave, q, pt, xs);   // lin_z[0]: nothing long enough to hide under yet
-      g0.all();
+      if constexpr (LO) {
+        GatherSide<DINER_HN_G0DEPTH, false> g0(fa.tz, taps_lds, wave, q, pt, xs);   // lin_z[0]: nothing long enough to hide under yet
+        g0.all();
+      } else {
+        GatherSideH<DINER_HN_G0DEPTH_H, false> g0(fa.tz16, taps_lds, wave, q, pt, xs);
+        g0.all();
+      }
       pf.mark(5);
     }
 #pragma nounroll
@@ -877,8 +986,11 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
       // (folded into the projected map's bias when the weights are packed, mlp.hip)
       const _Float16* w1 = w_blk + (size_t)(2 * b + 1) * kLayerHalfs;
 #if DINER_HN_OWNG
-      {
+      if constexpr (LO) {
         GatherSide<kGDepth> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
+        publish_gemm<kRing, LO, DINER_HN_EARLY1 != 0, true>(w1, Bl, wave, lane, ns, xs, gs, [&] { pin_acc(xs); }, pf, 10);
+      } else {
+        GatherSideH<DINER_HN_GDEPTH_H> gs(reinterpret_cast<const _Float16*>(fa.tz16) + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
         publish_gemm<kRing, LO, DINER_HN_EARLY1 != 0, true>(w1, Bl, wave, lane, ns, xs, gs, [&] { pin_acc(xs); }, pf, 10);
       }
 #else

@@ -119,26 +119,39 @@ class HipScene:
         s.img_w, s.img_h, s.feature_padding = self.img_w, self.img_h, self.feature_padding
         s.nv, s.C, s.Hf, s.Wf, s.Hs, s.Ws = self.nv, self.C, self.Hf, self.Wf, self.Hs, self.Ws
         s.latent_proj = None
+        s.latent_proj_f16 = None
         s.proj_stamp = 0
         self.struct = s
         self.latent_proj = None
+        self.latent_proj_f16 = None
         self._prepared_for = None
+        self._f16_current = False
 
-    def prepare(self, mlp, force=False):
+    def prepare(self, mlp, force=False, f16=False):
         """Hoist lin_z[0..2] out of the sample loop: project the channels-last latent once (k_hoist_linz).
-        Re-run when the MLP handle changes (the handle itself is rebuilt whenever a parameter changes)."""
+        Re-run when the MLP handle changes (the handle itself is rebuilt whenever a parameter changes).
+        f16: also (re)build the fp16 copy of the projected maps that PRECISION_F16 gathers from (+50 % memory, made only when that mode
+        is used; one conversion pass per preparation)."""
         if self.latent_cl is None:
             raise RuntimeError("diner_amd: scene has no latent map")
-        if not force and self._prepared_for is mlp and self.latent_proj is not None:
-            return
-        with torch.cuda.device(self.device):
-            if self.latent_proj is None:
-                nbytes = lib.diner_scene_proj_bytes(self.ref)
-                self.latent_proj = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-            _lib.check(lib.diner_scene_prepare_f32(self.ref, mlp.handle, _ptr(self.latent_proj), _stream()))
-        self.struct.latent_proj = self.latent_proj.data_ptr()
-        self.struct.proj_stamp = lib.diner_mlp_stamp(mlp.handle)      # the library refuses these maps with any other handle
-        self._prepared_for = mlp
+        fresh = force or self._prepared_for is not mlp or self.latent_proj is None
+        if fresh:
+            with torch.cuda.device(self.device):
+                if self.latent_proj is None:
+                    nbytes = lib.diner_scene_proj_bytes(self.ref)
+                    self.latent_proj = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+                _lib.check(lib.diner_scene_prepare_f32(self.ref, mlp.handle, _ptr(self.latent_proj), _stream()))
+            self.struct.latent_proj = self.latent_proj.data_ptr()
+            self.struct.proj_stamp = lib.diner_mlp_stamp(mlp.handle)      # the library refuses these maps with any other handle
+            self._prepared_for = mlp
+            self._f16_current = False
+        if f16 and not self._f16_current:
+            with torch.cuda.device(self.device):
+                if self.latent_proj_f16 is None:
+                    self.latent_proj_f16 = torch.empty(lib.diner_scene_proj_f16_bytes(self.ref) // 2, dtype=torch.float16, device=self.device)
+                _lib.check(lib.diner_scene_prepare_f16(self.ref, _ptr(self.latent_proj_f16), _stream()))
+            self.struct.latent_proj_f16 = self.latent_proj_f16.data_ptr()
+            self._f16_current = True
 
     @property
     def ref(self):
@@ -261,8 +274,8 @@ def field_from_rays(scene: HipScene, mlp: HipMlp, rays, z, precision=None):
     _require_hip(rays, z)
     rays, z = _f32c(rays), _f32c(z)
     NR, K = z.shape
-    scene.prepare(mlp)
     prec = _precision_for(scene, precision)
+    scene.prepare(mlp, f16=prec == PRECISION_F16)
     out = torch.empty(NR, K, 4, device=rays.device, dtype=torch.float32)
     if NR == 0:
         return out
@@ -281,8 +294,8 @@ def field_from_points(scene: HipScene, mlp: HipMlp, xyz, viewdirs, precision=Non
     _require_hip(xyz, viewdirs)
     xyz, viewdirs = _f32c(xyz), _f32c(viewdirs)
     P = xyz.shape[0]
-    scene.prepare(mlp)
     prec = _precision_for(scene, precision)
+    scene.prepare(mlp, f16=prec == PRECISION_F16)
     out = torch.empty(P, 4, device=xyz.device, dtype=torch.float32)
     if P == 0:
         return out

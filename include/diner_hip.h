@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DINER_ABI_VERSION 3
+#define DINER_ABI_VERSION 4
 
 #define DINER_E_INVALID     (-1)  /* bad argument (null pointer, size, unsupported configuration) */
 #define DINER_E_UNSUPPORTED (-2)  /* configuration outside what the kernels are built for        */
@@ -60,6 +60,9 @@ typedef struct DinerScene {
                                diner_scene_prepare_f32).  The field entry points return DINER_E_INVALID when it is not the
                                stamp of the handle they are called with: maps prepared with another (or an older) handle carry
                                that handle's biases */
+  const void* latent_proj_f16; /* ABI v4: the same three maps as fp16 (3, NV, Hf, Wf, C), channels in the order the plain-fp16 field
+                               kernel consumes them, written by diner_scene_prepare_f16 from latent_proj (same proj_stamp).  Only
+                               DINER_PRECISION_F16 reads it (half the gather bytes of that mode); NULL for the other modes */
 } DinerScene;
 
 /* ResnetFC parameters as the reference stores them (nn.Linear: weight (out,in), bias (out));
@@ -130,6 +133,12 @@ int diner_fill_uniform_f32(const float* z_in, const float* rays, int NR, int K, 
  * the lin_z parameters change, before any diner_field_* / diner_render_f32 call on that scene. */
 size_t diner_scene_proj_bytes(const DinerScene* scene);
 int diner_scene_prepare_f32(const DinerScene* scene, const DinerMlp* mlp, float* latent_proj_out, void* stream);
+/* ABI v4, DINER_PRECISION_F16 only ("fp16 MLP on MFMA", create_prediction_folder.py:44-47 with configs/evaluate_diner_on_facescape.yaml):
+ * fp16 copy of scene->latent_proj (which must be set and current) into latent_proj_f16_out, diner_scene_proj_f16_bytes(scene) bytes;
+ * the caller then stores the pointer in scene->latent_proj_f16.  Values beyond the fp16 range become inf and end up in the launch's
+ * overflow flag (the gated exact-fp32 pass recomputes it from latent_proj). */
+size_t diner_scene_proj_f16_bytes(const DinerScene* scene);
+int diner_scene_prepare_f16(const DinerScene* scene, void* latent_proj_f16_out, void* stream);
 
 /* ---- arithmetic of the MLP GEMMs: a PER-CALL argument of the field entry points (no process-wide state) ---------
  * DINER_PRECISION_FP32  exact fp32 MFMA (v_mfma_f32_16x16x4_f32), an fmaf chain per output (mlp.hip).
