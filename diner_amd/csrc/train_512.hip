@@ -12,7 +12,8 @@
 namespace diner {
 namespace train {
 
-enum : int { kShape64 = 0, kShape32 = 1, kShape32Shared = 2 };      // 64-row tiles; 32-row tiles; 32-row tiles shared by two workgroups
+enum : int { kShape64 = 0, kShape32 = 1, kShape32Shared = 2, kShape128 = 3 };      // 64-row tiles; 32-row tiles; 32-row tiles shared by two workgroups;
+                                                                                   // 128-row tiles (f16x3 only, round 4: a weight fragment feeds four MFMAs)
 struct Run512 {
   Lin512Args part[2];
   int n[2];              // workgroups of the two parts (0: absent)
@@ -28,7 +29,8 @@ __device__ __forceinline__ void lin512_part(const Lin512Args& a, int shape, int 
 
 // The forward products in the f16x3 arithmetic (lin512_body<.., AR = 1>: half the MFMAs of bf16x6): the same parts, no weight gradient
 __device__ __forceinline__ void lin512_part_f16(const Lin512Args& a, int shape, int bid, int nblk) {
-  if (shape == kShape64) lin512_body<DINER_L512_RING, 2, 1, 1>(a, bid, nblk);
+  if (shape == kShape128) lin512_body<DINER_L512_RING, 4, 1, 1>(a, bid, nblk);
+  else if (shape == kShape64) lin512_body<DINER_L512_RING, 2, 1, 1>(a, bid, nblk);
   else if (shape == kShape32) lin512_body<DINER_L512_RING, 1, 1, 1>(a, bid, nblk);
   else lin512_body<DINER_L512_RING, 1, 2, 1>(a, bid, nblk);
 }
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
 
 namespace {
 constexpr size_t kLdsBytesRun = kLdsBytesWgrad > kLdsBytes512 ? kLdsBytesWgrad : kLdsBytes512;
+static_assert(kLdsBytesRun >= kLdsBytes512F16, "the f16x3 128-row shape needs 128 KB");
 int device_cus(int* cus) {                                   // per device: dynamic LDS size of the kernel, CU count
   static std::atomic<int> attr_set[64];
   static std::atomic<int> cu_count[64];
@@ -64,7 +67,7 @@ int device_cus(int* cus) {                                   // per device: dyna
   dev &= 63;
   if (!attr_set[dev].load()) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
-    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512F16));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
@@ -80,7 +83,7 @@ int device_cus(int* cus) {                                   // per device: dyna
 // (half the features each).  Costs in units of one round of 32-row tiles, measured on the reference training batch (20480 rows = 2.5
 // rounds of 32-row tiles: three rounds as 32-row tiles, 1.85 + 0.55 as one 64-row round + one round of shared tiles).
 // DINER_L512_CT = 1 | 2 forces one shape for everything, DINER_L512_HALF = 0 keeps the shared tiles out (measurement aids).
-void plan_lin512(const Lin512Args& a, int cus, Run512* r) {
+void plan_lin512(const Lin512Args& a, int cus, Run512* r, bool f16 = false) {
   auto part = [&](long long row0, long long rows) {
     Lin512Args b = a;
     b.X += (size_t)row0 * a.ldx;
@@ -94,7 +97,7 @@ void plan_lin512(const Lin512Args& a, int cus, Run512* r) {
   auto set = [&](int i, long long row0, long long rows, int shape) {
     r->part[i] = part(row0, rows);
     r->shape[i] = shape;
-    const long long units = shape == kShape64 ? (rows + 63) / 64 : (rows + 31) / 32 * (shape == kShape32Shared ? 2 : 1);
+    const long long units = shape == kShape128 ? (rows + 127) / 128 : shape == kShape64 ? (rows + 63) / 64 : (rows + 31) / 32 * (shape == kShape32Shared ? 2 : 1);
     r->n[i] = (int)(units < cus ? units : cus);
   };
   r->n[0] = r->n[1] = 0;
@@ -103,6 +106,22 @@ void plan_lin512(const Lin512Args& a, int cus, Run512* r) {
   static const int forced = [] { const char* e = getenv("DINER_L512_CT"); return e ? atoi(e) : 0; }();
   static const bool halves = [] { const char* e = getenv("DINER_L512_HALF"); return !(e && *e == '0'); }();
   if (forced == 1 || forced == 2) return set(0, 0, a.M, forced == 2 ? kShape64 : kShape32);
+  // f16x3 at 64-row tiles is bound by the weight stream through the vector-memory path (1 MB per tile for 24.7 k clocks of MFMAs: the
+  // path's 64 B/clk; MfmaUtil 0.38, profiles/r04_train_1x4096_pmc_summary.md): whole rounds of 128-row tiles first (DINER_L512_T128=0: off)
+  static const bool t128 = [] { const char* e = getenv("DINER_L512_T128"); return !(e && *e == '0'); }();
+  if (f16 && t128 && a.M >= 128ll * cus) {
+    const long long round128 = 128ll * cus, main128 = a.M / round128 * round128;
+    set(0, 0, main128, kShape128);
+    if (a.M > main128) {
+      const long long rest = a.M - main128;
+      int shape_rest = kShape32;
+      const double c32r = 1.0, c64r = 1.85;
+      auto rounds2 = [&](long long units) { return (double)((units + cus - 1) / cus); };
+      const double r64 = rounds2((rest + 63) / 64) * c64r, r32 = rounds2((rest + 31) / 32) * c32r;
+      set(1, main128, rest, r64 <= r32 ? kShape64 : shape_rest);
+    }
+    return;
+  }
   const double c32 = 1.0, c64 = 1.85, chalf = 0.55;
   auto rounds = [&](long long units) { return (double)((units + cus - 1) / cus); };
   auto rest_cost = [&](long long rows, int* shape) {         // cheapest 32-row shape for `rows` rows
@@ -146,9 +165,9 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream, int arith) {
   int rc = device_cus(&cus);
   if (rc) return rc;
   Run512 r;
-  plan_lin512(a, cus, &r);
+  plan_lin512(a, cus, &r, arith == 1);
   memset(&r.wg, 0, sizeof(r.wg));
-  if (arith == 1) hipLaunchKernelGGL(k_fwd512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytes512, stream, r);
+  if (arith == 1) hipLaunchKernelGGL(k_fwd512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytes512F16, stream, r);
   else hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
   DINER_LAUNCH_OK();
   return 0;
@@ -166,7 +185,7 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
   if (rc) return rc;
   Run512 r;
   r.n[0] = r.n[1] = 0;
-  if (dgrad) plan_lin512(*dgrad, cus, &r);
+  if (dgrad) plan_lin512(*dgrad, cus, &r, ar && ar->arith == 1);
   else {
     memset(r.part, 0, sizeof(r.part));
     r.shape[0] = r.shape[1] = kShape32;

@@ -34,6 +34,7 @@ constexpr float kF16Scale = 16.0f, kF16InvScale = 1.0f / 16.0f;      // f16x3 ar
 constexpr int kStepsPerSlab = 8;                // k16 steps per staged slab (128 contraction indices)
 constexpr int kSlabs = 512 / (16 * kStepsPerSlab);
 constexpr size_t kLdsBytes512 = (size_t)2 * kStepsPerSlab * 2 * 3 * 1024;  // two slab buffers of [step 8][row half CT][plane 3] 1 KB fragments: 96 KB at CT = 2
+constexpr size_t kLdsBytes512F16 = (size_t)2 * kStepsPerSlab * 4 * 2 * 1024;  // f16x3 (two planes) at CT = 4 (128-row tiles): 128 KB
 
 // fp32 -> three bf16 planes (round to nearest each time; the residuals are exact in fp32), 8 values at once
 __device__ __forceinline__ void split3x8(const float (&v)[8], bf8& p0, bf8& p1, bf8& p2) {
@@ -287,12 +288,18 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
       (void)last;
       lds_ptr rb = lbase + buf * (kSlabFrags * 1024);
       asm volatile("" : "+v"(rb));
-      bf8 bb[2][CT][NP];                                     // B fragments [parity][row half][plane]
+      // B fragments [parity][row part][plane]; CT = 4: ONE buffer, each row part re-read for the next step right after its last use in this
+      // one (groups run row part by row part: part c is free from group 3 (c + 1) on; the last part at the top of the next step) -- 32
+      // registers less, which the 128-row shape needs
+      constexpr bool kRollB = CT == 4;
+      bf8 bb[kRollB ? 1 : 2][CT][NP];
+      auto load_b1 = [&](int par, int s, int h) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * CT + h) * NP + pl) * 1024);
+      };
       auto load_b = [&](int par, int s) {
 #pragma unroll
-        for (int h = 0; h < CT; ++h)
-#pragma unroll
-          for (int pl = 0; pl < NP; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * CT + h) * NP + pl) * 1024);
+        for (int h = 0; h < CT; ++h) load_b1(par, s, h);
       };
       load_b(0, 0);
       sfor<kStepsPerSlab>([&](auto S) {
@@ -309,10 +316,16 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
           constexpr int ib = AR == 1 ? (t == 1 ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0);
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (LW * g < NF) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, LW * g, (LW * g + LW <= NF ? LW : NF - LW * g));
-          if constexpr (g == (NG >= 12 ? 7 : NG >= 6 ? 3 : 1) && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
+          if constexpr (kRollB) {
+            if constexpr (t == 0 && ct > 0 && s + 1 < kStepsPerSlab) load_b1(0, s + 1, ct - 1);
+            if constexpr (g == 0 && s > 0) load_b1(0, s, CT - 1);
+          } else {
+            if constexpr (g == (NG >= 12 ? 7 : NG >= 6 ? 3 : 1) && s + 1 < kStepsPerSlab) load_b((s + 1) & 1, s + 1);
+          }
           // staging side task: one of the slab's NQ requests per step (steps 0 .. NQ-1), in three groups
           // // (which steps makes no measurable difference)
           constexpr int g0 = AR == 1 ? NG - 3 : (CT == 2 ? 8 : 2);
+          constexpr int g1 = 3;                                // CT = 4 (16 requests per slab): a second request per step, s + 8, in groups 3..5
 #ifndef DINER_L512_ABL_X
           if constexpr (s < NQ && g == g0) stash_half(s, 0);
           if constexpr (s < NQ && g == g0 + 1) stash_half(s, 1);
@@ -320,14 +333,20 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
             stash_write(buf ^ 1, s);
             request_one(s, t2, s2);
           }
+          if constexpr (s + 8 < NQ && g == g1) stash_half(s + 8, 0);
+          if constexpr (s + 8 < NQ && g == g1 + 1) stash_half(s + 8, 1);
+          if constexpr (s + 8 < NQ && g == g1 + 2) {
+            stash_write(buf ^ 1, s + 8);
+            request_one(s + 8, t2, s2);
+          }
 #endif
-          const bf8 b = bb[s & 1][ct][ib];
+          const bf8 b = bb[kRollB ? 0 : (s & 1)][ct][ib];
 #pragma unroll
           for (int rt = 0; rt < NRT; ++rt) {
             if constexpr (AR == 1) DINER_F16_MFMA(acc[rt][ct], wc[NP * rt + ia], b);
             else DINER_BF16_MFMA(acc[rt][ct], wc[NP * rt + ia], b);
           }
-          if constexpr (s < NQ && (g == g0 || g == g0 + 1)) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
+          if constexpr ((s < NQ && (g == g0 || g == g0 + 1)) || (s + 8 < NQ && (g == g1 || g == g1 + 1))) {      // the conversion between the MFMAs, not in front of them: <= 6 vector-ALU slots per MFMA
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
               __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
