@@ -348,19 +348,36 @@ def main():
             return "k_field_pre_h3n<false>", 1, PEAK_F16_MFMA_TFLOPS, "f16 operands, fp32 accumulate (reduced precision: ~1e-3, outside the parity bar)"
         return "k_field_pre", 1, PEAK_FP32_MFMA_TFLOPS, "f32"
 
-    def roof(m, prof, wall_s):
+    def traffic_for(kname, dims, prof):
+        """HBM bytes per launch of kernel `kname` on workload dims = (W, H, K): PMC bytes/point of tools/profile_round.sh (FETCH_SIZE x2 +
+        WRITE_SIZE) x points per launch.  Counters cannot be read inside this process; the committed figure is only quoted when it was
+        taken with the kernel sources of this build (digest match) on this workload, otherwise null."""
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                pmc = json.load(f)
+            wl_key = "%dx%dx%d" % dims
+            ent = pmc.get(f"{kname} @ {wl_key}") or pmc.get(kname)
+            if ent and ent.get("source_digest") == kernel_source_digest() and ent.get("workload") == wl_key:
+                return (round(ent["hbm_bytes_per_point"] * prof["points"] / max(prof["launches"], 1)),
+                        f"HBM bytes per launch: PMC bytes/point of {ent['source']} x points per launch")
+        except Exception:
+            pass
+        return None, "no PMC figure for this build and workload (profiles/pmc_latest.json missing or stale)"
+
+    def roof(m, prof, wall_s, dims=None):
         """Roofline figures of one measured run: the per-view kernel from its HIP-event time, the whole path from the wall time."""
         kname, mult, peak, label = mode_facts(m)
+        tr = traffic_for(kname, dims, prof)[0] if dims else None
         pre_s = prof["pre_ms"] * 1e-3
         ach = prof["points"] * ops.FLOP_PRE_PER_POINT * mult / pre_s / 1e12 if pre_s > 0 else 0.0
         path = prof["points"] * (ops.FLOP_PRE_PER_POINT + ops.FLOP_POST_PER_POINT) * mult / wall_s / 1e12
         return {"bound": "mfma", "kernel": kname, "mfma_dtype": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "launches": prof["launches"],
                 "avg_launch_ms": round(prof["pre_ms"] / max(prof["launches"], 1), 3),
-                "points_per_launch": round(prof["points"] / max(prof["launches"], 1)),
+                "points_per_launch": round(prof["points"] / max(prof["launches"], 1)), "traffic": tr,
                 "whole_path_achieved": round(path, 2), "whole_path_frac": round(path / peak, 4)}
 
-    def measure(stepf, m, rays, n):
+    def measure(stepf, m, rays, n, dims=None):
         """median-of-n timed frames of `stepf` in mode m (each frame bracketed by barrier + synchronize) + roofline figures."""
         sync()
         ops.profile_enable(True)
@@ -373,7 +390,7 @@ def main():
         ops.profile_enable(False)
         med = sorted(ts)[len(ts) // 2]
         return {"rays_per_s": round(rays / med, 1), "ms_per_step": round(med * 1e3, 2), "steps": n,
-                "ms_all": [round(t * 1e3, 2) for t in ts], "mode": names[m], "roofline": roof(m, prof, sum(ts))}
+                "ms_all": [round(t * 1e3, 2) for t in ts], "mode": names[m], "roofline": roof(m, prof, sum(ts), dims)}
 
     for i in range(args.warmup):
         step(i, head)
@@ -442,7 +459,7 @@ def main():
             if m == head:
                 continue
             step(0, m)                              # warm-up (first launch of that kernel family)
-            e = measure(step, m, rays_per_step, max(1, args.extra_steps))
+            e = measure(step, m, rays_per_step, max(1, args.extra_steps), (W, H, K))
             e["parity"] = ("outside the 1e-4 bar (~1e-3), BASELINE configs[4] only" if m == ops.PRECISION_F16
                            else "1e-4 bar (same tests as the headline mode)")
             modes[names[m]] = e
@@ -455,19 +472,7 @@ def main():
     pre_s = prof["pre_ms"] * 1e-3
     fp32_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT / pre_s / 1e12 if pre_s > 0 else 0.0
     ref_equiv = prof["points"] * ops.FLOP_PRE_PER_POINT_REFERENCE / pre_s / 1e12 if pre_s > 0 else 0.0
-    # HBM traffic per launch: bytes/point from the rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE x2 +
-    # WRITE_SIZE).  Counters cannot be read inside this process; the committed figure is only quoted when it was taken
-    # with the kernel sources of this build (digest match), otherwise null.
-    traffic, traffic_note = None, "no PMC figure for this build (profiles/pmc_latest.json missing or stale)"
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            pmc = json.load(f)
-        ent = pmc.get(f"{pre_kernel} @ {W}x{H}x{K}") or pmc.get(pre_kernel)
-        if ent and ent.get("source_digest") == kernel_source_digest() and ent.get("workload") == f"{W}x{H}x{K}":
-            traffic = round(ent["hbm_bytes_per_point"] * prof["points"] / max(prof["launches"], 1))
-            traffic_note = f"HBM bytes per launch: PMC bytes/point of {ent['source']} x points per launch"
-    except Exception:
-        pass
+    traffic, traffic_note = traffic_for(pre_kernel, (W, H, K), prof)
     roofline = {"bound": "mfma", "kernel": pre_kernel, "mfma_dtype": rf["mfma_dtype"],
                 "achieved": rf["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": rf["frac"],
                 "traffic": traffic, "traffic_unit": traffic_note,
@@ -546,7 +551,7 @@ def main():
             wl = workload(cw, ch, ck, cfs, cfs, via_modules=via)
             for m in cmodes:
                 wl["step"](0, m, max_rays=2 * args.ray_batch)          # warm-up on the first two ray batches
-                e = measure(wl["step"], m, cw * ch, nx)
+                e = measure(wl["step"], m, cw * ch, nx, (cw, ch, ck))
                 if wl["out"] is not None:
                     assert torch.isfinite(wl["out"]).all()
                 else:

@@ -5,12 +5,19 @@ touches `fine.rgb` only, gradients flow through the compositor (nerf_renderer.py
 (pixelnerf.py:139-143), ResnetFC (resnetfc.py:129-159) and the bilinear latent lookup (image_encoder.py:97-146) into the
 MLP parameters and the encoder's feature maps; sample positions carry no gradient (`sample_depthguided` is `@no_grad`).
 
-Here that is two `torch.autograd.Function`s whose forward AND backward are calls into libdiner_hip.so (csrc/train.hip: one
-fp32 MFMA GEMM with the needed epilogues + small kernels, sequenced on the C side); torch only owns the buffers.  The
-building blocks are also exported one by one (`gemm`, `_linear`, `_linear_backward` below drive them from Python; the
-tests use them).  The forward
-is the un-fused one that keeps every pre-activation, which is what a backward pass needs; inference keeps using the fused
-kernels.  Sizes: 128 rays x 40 samples x 4 views = 20 k columns per object and step (configs/train_dtu.yaml).
+Here that is two `torch.autograd.Function`s whose forward AND backward are ONE call into libdiner_hip.so each
+(diner_field_train_forward_f32 / _backward_f32, csrc/train.hip, sequence the kernels on the C side; torch only owns the buffers):
+  * the 13 layer products with a 512 x 512 weight matrix -- forward, data gradient, weight gradient -- on persistent
+    one-wave-per-SIMD kernels (csrc/train_lin512.hip, train_wgrad512.hip, entry points in train_512.hip) in the f16x3 arithmetic of the
+    inference kernels (two fp16 planes per operand, three MFMA terms, fp32 accumulation); loss gradients are staged times a power of
+    two taken from their maximum, operands outside the fp16 split fall to bf16x6 twins (three bf16 planes, six terms) without a host
+    synchronisation (DESIGN.md section 6.3);
+  * lin_in, lin_out, the view mean, the latent gather / scatter and the output activations on small dedicated kernels; a general
+    split-bf16 GEMM (`gemm`, `_linear`, `_linear_backward` below drive it from Python; the tests use them) for everything ragged.
+The forward is the un-fused one that keeps every pre-activation, which is what a backward pass needs; inference keeps using the
+fused kernels.  Sizes: the shipped configs train SB = 4 objects x 4096 rays (a 64 x 64 patch: w_vgg != 0, diner.py:57) x 40 samples x
+4 views = 655 k columns per object and step (configs/train_dtu.yaml:16,52-63); the workspace of saved activations is 94 KB per sample
+point = 14.7 GiB per object at that size (diner_field_train_workspace_bytes), four of them alive between forward and backward.
 """
 import torch
 

@@ -268,6 +268,16 @@ def test_bench_line_contract():
     if "configs" in line:      # round 3: the other single-GPU BASELINE configs ride in the same line
         assert any("400x300" in k for k in line["configs"]) and sum("1024x1024" in k for k in line["configs"]) == 2
         assert "whole_path" in line["roofline"]
+    if "frame_check" in line:      # round 4: the line says who took part and whether the sharded frame was checked; every modes / configs entry is a
+        assert line["n_gpus"] == 1 and line["dist"] is None and line["backend"] is None      # median of >= 3 frames with its own roofline figures,
+        assert "no collective" in line["config"]["parallelism"]                               # and the frame through the drop-in modules rides along
+        for e in list(line["modes"].values()) + list(line["configs"].values()):
+            assert e["steps"] >= 3 and len(e["ms_all"]) == e["steps"]
+            rr = e["roofline"]
+            assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3 and 0 < rr["whole_path_frac"] < 1
+        via = [v for k, v in line["configs"].items() if "through src.models" in k]
+        assert len(via) == 1 and "4096 rays" in [k for k in line["configs"] if "through src.models" in k][0]
+        assert abs(via[0]["vs_ops_level_headline"] - 1.0) < 0.03          # the module-level API costs < 3 % against the ops level
     r = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
