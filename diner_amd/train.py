@@ -197,6 +197,30 @@ class CompositeFunction(torch.autograd.Function):
         return d_field, None, None, None
 
 
+class _ObjectSlabs(torch.autograd.Function):
+    """latent (SB, NV, C, Hf, Wf) -> its SB per-object slabs as separate autograd inputs of the per-object field nodes.  Plain indexing
+    (`latent[sb]`) makes autograd build each object's gradient as a zero-filled tensor of the WHOLE latent with one slab copied in and then
+    add SB of those (at SB = 4 and 400 x 300 images: four 1.85 GB zero-fills + three 1.85 GB additions per step, ~5 ms of HBM traffic);
+    here the backward stacks the SB slab gradients once."""
+
+    @staticmethod
+    def forward(ctx, latent):
+        ctx.sb = latent.shape[0]
+        return tuple(latent[sb] for sb in range(latent.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        return torch.stack([g if g is not None else torch.zeros_like(ref) for g in grads])
+
+
+def object_slabs(latent):
+    """Per-object views of encoder.latent for the training path (see _ObjectSlabs); without grad: plain views."""
+    if torch.is_grad_enabled() and latent.requires_grad:
+        return _ObjectSlabs.apply(latent)
+    return tuple(latent[sb] for sb in range(latent.shape[0]))
+
+
 def field_train(scene: HipScene, xyz, viewdirs, latent, params, freq_factor=6.28):
     return FieldFunction.apply(scene, xyz, viewdirs, latent, float(freq_factor), *params)
 

@@ -43,7 +43,7 @@ class NeRFRendererDGS(torch.nn.Module):
         if not (hasattr(model, "hip_scene") and hasattr(model, "hip_mlp")):
             raise TypeError("diner_amd: `model` must be src.models.pixelnerf.PixelNeRF of this package")
 
-    def _render_train(self, model, sb, rays, z, want_weights):
+    def _render_train(self, model, sb, rays, z, want_weights, latent_sb=None):
         """Differentiable composite for one object (training): sample points as in
         nerf_renderer.py:304, the radiance field and the compositor through diner_amd/train.py (HIP forward + backward).
         Gradients reach the MLP parameters and encoder.latent; z and rays carry none (the sampler is @no_grad)."""
@@ -52,7 +52,7 @@ class NeRFRendererDGS(torch.nn.Module):
         r = rays.detach()
         xyz = (r[:, None, :3] + z[..., None] * r[:, None, 3:6]).reshape(-1, 3)
         dirs = r[:, None, 3:6].expand(-1, K, -1).reshape(-1, 3)
-        field = train.field_train(model.hip_scene(sb), xyz, dirs, model.encoder.latent[sb],
+        field = train.field_train(model.hip_scene(sb), xyz, dirs, model.encoder.latent[sb] if latent_sb is None else latent_sb,
                                   train.mlp_params(model.mlp_fine), model.poscode.freq_factor).view(NR, K, 4)
         rgb, depth = train.composite_train(field, z, r, self.white_bkgd)
         w = ops.composite(field.detach(), z, r, self.white_bkgd, want_weights=True)[0] if want_weights else None
@@ -106,7 +106,9 @@ class NeRFRendererDGS(torch.nn.Module):
         model._check_poscode()
         SB = rays.shape[0]
         if model.needs_grad():
-            res = [self._render_train(model, sb, rays[sb], z_samp[sb].detach(), True) for sb in range(SB)]
+            from diner_amd import train
+            slabs = train.object_slabs(model.encoder.latent)      # one autograd node for the SB objects' latent gradients
+            res = [self._render_train(model, sb, rays[sb], z_samp[sb].detach(), True, slabs[sb]) for sb in range(SB)]
         else:
             mlp = model.hip_mlp()
             res = [ops.render(model.hip_scene(sb), mlp, rays[sb], z_samp[sb], self.white_bkgd, want_weights=True)
@@ -122,6 +124,9 @@ class NeRFRendererDGS(torch.nn.Module):
         SB = rays.shape[0]
         training = model.needs_grad()
         mlp = None if training else model.hip_mlp()
+        if training:
+            from diner_amd import train
+            slabs = train.object_slabs(model.encoder.latent)      # one autograd node for the SB objects' latent gradients
         inj = _noise.current()
         rgbs, depths, wts = [], [], []
         for sb in range(SB):
@@ -131,7 +136,7 @@ class NeRFRendererDGS(torch.nn.Module):
             z = ops.sample_depthguided(scene, rays[sb], self.n_samples, self.n_depth_candidates, self.n_gaussian,
                                        0.05, noise=nz, seed=seed, ray_index0=r0)
             if training:
-                w, rgb, depth = self._render_train(model, sb, rays[sb], z, want_weights)
+                w, rgb, depth = self._render_train(model, sb, rays[sb], z, want_weights, slabs[sb])
             else:
                 w, rgb, depth = ops.render(scene, mlp, rays[sb], z, self.white_bkgd, want_weights=want_weights)
             rgbs.append(rgb)

@@ -104,7 +104,8 @@ class PixelNeRF(torch.nn.Module):
             # (diner_amd/train.py); gradients reach the MLP parameters and, through encoder.latent, the image encoder
             from diner_amd import train
             params = train.mlp_params(self.mlp_fine)
-            return torch.stack([train.field_train(self.hip_scene(sb), xyz[sb], viewdirs[sb], self.encoder.latent[sb], params,
+            slabs = train.object_slabs(self.encoder.latent)
+            return torch.stack([train.field_train(self.hip_scene(sb), xyz[sb], viewdirs[sb], slabs[sb], params,
                                                   self.poscode.freq_factor) for sb in range(SB)])
         self._check_poscode()
         mlp = self.hip_mlp()
