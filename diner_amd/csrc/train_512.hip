@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256, 1) void k_run512_f16x3(Run512 r) {
   if (b < r.n[0]) return lin512_part_f16(r.part[0], r.shape[0], b, r.n[0]);
   b -= r.n[0];
   if (b < r.n[1]) return lin512_part_f16(r.part[1], r.shape[1], b, r.n[1]);
-  wgrad512_body<1>(r.wg, b - r.n[1]);
+  if (r.wg.wide) wgrad512_body_wide(r.wg, b - r.n[1]);
+  else wgrad512_body<1>(r.wg, b - r.n[1]);
 }
 
 __global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
@@ -149,14 +150,14 @@ void plan_lin512(const Lin512Args& a, int cus, Run512* r, bool f16 = false) {
 // The weight-gradient part: row chunks -- 32 (8 tiles x 32 = 256 workgroups) unless a chunk would be shorter than 4 slabs; returns its
 // workgroups and the chunks that have rows (the ones the summing pass reads)
 int plan_wgrad512(const float* dY, int ldy, const float* X, int ldx, bool relu_x, float* dW, float* db, long long M, float* part,
-                  Wgrad512Args* a, int* used) {
-  long long n_chunks = kWgMaxChunks;
+                  Wgrad512Args* a, int* used, int max_chunks = kWgPlanChunks, bool wide = false) {
+  long long n_chunks = max_chunks;
   while (n_chunks > 1 && (M + n_chunks - 1) / n_chunks < 128) n_chunks >>= 1;
   long long rows = (M + n_chunks - 1) / n_chunks;
   rows = (rows + 31) / 32 * 32;
-  *a = Wgrad512Args{dY, X, dW, db, part, M, ldy, ldx, relu_x ? 1 : 0, (int)n_chunks, rows, nullptr, nullptr, nullptr};
+  *a = Wgrad512Args{dY, X, dW, db, part, M, ldy, ldx, relu_x ? 1 : 0, (int)n_chunks, rows, nullptr, nullptr, nullptr, wide ? 1 : 0};
   *used = (int)((M + rows - 1) / rows);
-  return 8 * (int)(n_chunks <= 8 ? 8 : n_chunks);             // the block -> (tile, chunk) map needs whole groups of 8 chunks
+  return (wide ? 4 : 8) * (int)(n_chunks <= 8 ? 8 : n_chunks);   // the block -> (tile, chunk) map needs whole groups of 8 chunks
 }
 }  // namespace
 
@@ -191,7 +192,12 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
     r.shape[0] = r.shape[1] = kShape32;
   }
   int used = 0;
-  const int n_wg = plan_wgrad512(dY, ldy, X, ldx, relu_x, dW, db, M, part, &r.wg, &used);
+  // f16x3: 256 x 256 tiles over up to 64 row chunks (DINER_WGRAD_WIDE=0: the 128 x 256-tile body); the bf16x6 twin of such a launch keeps the
+  // same chunks (its partial tiles go where the summing pass of the pair expects them), as 8 tiles x 64 chunks
+  static const bool wide_on = [] { const char* e = getenv("DINER_WGRAD_WIDE"); return !(e && *e == '0'); }();
+  const bool pair = ar && part && (ar->wg_skip || ar->wg_gate) && wide_on;
+  const bool wide = pair && ar->arith == 1;
+  const int n_wg = plan_wgrad512(dY, ldy, X, ldx, relu_x, dW, db, M, part, &r.wg, &used, pair ? kWgPlanChunksWide : kWgPlanChunks, wide);
   if (ar) {
     r.wg.amax_dy = ar->amax_dy;
     r.wg.skip = ar->wg_skip;

@@ -29,8 +29,10 @@ typedef float f32x2w __attribute__((ext_vector_type(2)));
 
 constexpr int kWgFragsPerStep = (4 + 8) * 3;                     // [A: 4 f tiles | B: 8 k tiles][plane 3] fragments of 1 KB per k16 step
 constexpr int kWgSlabBytes = 2 * kWgFragsPerStep * 1024;         // two steps (32 rows) per slab: 72 KB
-constexpr size_t kLdsBytesWgrad = (size_t)2 * kWgSlabBytes;      // two slab buffers (f16x3: two planes, 96 KB)
-constexpr int kWgMaxChunks = 32;                                 // row chunks (the scratch holds one partial dW + db per chunk)
+constexpr size_t kLdsBytesWgrad = (size_t)2 * kWgSlabBytes;      // two slab buffers (f16x3: two planes, 96 KB; its 256 x 256-tile body: 128 KB)
+constexpr int kWgMaxChunks = 64;                                 // row chunks the scratch holds (one partial dW + db per chunk)
+constexpr int kWgPlanChunks = 32;                                // chunks of the 128 x 256-tile plan (8 tiles x 32 chunks = 256 workgroups)
+constexpr int kWgPlanChunksWide = 64;                            // chunks of the 256 x 256-tile plan (4 tiles x 64 chunks = 256 workgroups)
 
 struct Wgrad512Args {
   const float* dY;       // (M, ldy)
@@ -48,6 +50,7 @@ struct Wgrad512Args {
   const unsigned* amax_dy;
   const int* skip;
   const int* gate;
+  int wide;              // f16x3 launch: 256 x 256 tiles (wgrad512_body_wide: grid = 4 * n_chunks)
 };
 
 template <class F, int... I>
@@ -279,6 +282,182 @@ __device__ __forceinline__ void wgrad512_body(const Wgrad512Args& a, const int b
     } else {
       atomicAdd(a.db + f, rs0);
       atomicAdd(a.db + f + 1, rs1);
+    }
+  }
+}
+
+// ---- round 4: the f16x3 weight gradient on 256 (f) x 256 (k) tiles.  At three MFMAs per product the 128 x 256-tile body above is bound by its
+// STAGING (48 values per thread and 32-row slab to convert, for 96 MFMAs per wave: the conversion no longer fits in the MFMAs' shadow); a
+// 256 x 256 tile converts 64 values for 192 MFMAs -- a third less conversion per MFMA.  4 tiles x up to 64 row chunks = 256 workgroups (the 4
+// tiles of a chunk read the same rows and sit on one XCD); waves 2 x 2 over the tile: 128 f x 128 k each = 4 x 4 accumulator tiles = 256
+// registers; dy is staged like x (4 columns per lane); slabs of 64 KB ([A: 8 f tiles | B: 8 k tiles][hi, lo] per k16 step), two buffers.
+__device__ __forceinline__ void wgrad512_body_wide(const Wgrad512Args& a, const int bid) {
+  constexpr int NP = 2, kFrags = 16 * NP, kSlab = 2 * kFrags * 1024;
+  if (a.gate && *a.gate == 0) return;
+  if (a.skip && *a.skip != 0) return;
+  float sy = 1.0f, inv_sy = 1.0f;
+  if (a.amax_dy) {
+    const unsigned e = (*a.amax_dy >> 23) & 0xffu;
+    if (e >= 32u && e < 255u) {
+      sy = __uint_as_float((268u - e) << 23);
+      inv_sy = __uint_as_float((e - 14u) << 23);
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  typedef __attribute__((address_space(3))) bf8w* lds_bf8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  // workgroup b: tile (b / 8) % 4, chunk b % 8 + 8 (b / 32)
+  const int tile = (bid >> 3) & 3, chunk = (bid & 7) + 8 * (bid >> 5);
+  const int ft = tile >> 1, kt2 = tile & 1;                  // f range [256 ft, +256), k range [256 kt2, +256)
+  const long long m_begin = (long long)chunk * a.rows_per_chunk;
+  long long m_end = m_begin + a.rows_per_chunk;
+  if (m_end > a.M) m_end = a.M;
+  if (m_begin >= a.M) return;
+  const int n_slabs = (int)((m_end - m_begin + 31) / 32);
+  // staging: wave w owns columns [64 w, +64) of the tile's x range AND of its dy range, all 32 rows of a slab; request j (0..7): lanes
+  // 16 g .. 16 g + 15 read row 8 g + j, 4 columns each -- after the 8 requests a lane holds rows 8 g .. 8 g + 7 of its 4 + 4 columns
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 xr[8], yr[8];
+  const unsigned x_bytes = (unsigned)((m_end - m_begin) * (long long)a.ldx * 4), y_bytes = (unsigned)((m_end - m_begin) * (long long)a.ldy * 4);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X + (size_t)m_begin * a.ldx), 0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dY + (size_t)m_begin * a.ldy), 0, (int)y_bytes, 0x00020000);
+  const unsigned xvoff = (unsigned)(8 * g) * (unsigned)a.ldx * 4u + (unsigned)(256 * kt2 + 64 * wave + 4 * li) * 4u;
+  const unsigned yvoff = (unsigned)(8 * g) * (unsigned)a.ldy * 4u + (unsigned)(256 * ft + 64 * wave + 4 * li) * 4u;
+  typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+  auto request = [&](int j, long long m0) {
+    const unsigned row = (unsigned)(m0 - m_begin) + (unsigned)j;
+    xr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, row * (unsigned)a.ldx * 4u, 0));
+    yr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, yvoff, row * (unsigned)a.ldy * 4u, 0));
+  };
+  // LDS slots: step s = g >> 1, lane' = column & 31 + 32 (g & 1); columns 64 w + 4 li + c -> tile 2 w + (li >> 3), lane' += 4 (li & 7) + c
+  lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kFrags * 1024) + (32 * (g & 1)) * 16;
+  const int yslot = ((2 * wave + (li >> 3)) * NP) * 1024 + (4 * (li & 7)) * 16;
+  const int xslot = ((8 + 2 * wave + (li >> 3)) * NP) * 1024 + (4 * (li & 7)) * 16;
+  const int relu_floor = a.relu_x ? 0 : (int)0x80000000;
+  float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};                   // row sums of this lane's four dy columns (bias gradient)
+  u32x4w sp0, sp1;                                           // the lane-fragment being converted (two halves of 4 rows): hi / lo words
+  // unit i (0..7): columns 0..3 of the lane's x block, then 0..3 of its dy block; half 0 / 1 = rows 0..3 / 4..7 (+ the store)
+  auto stash_half = [&](int buf, int i, int half) {
+    float v[4];
+    if (i < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = __int_as_float(max(__float_as_int(xr[4 * half + j][i]), relu_floor));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = yr[4 * half + j][i - 4];
+      rs[i - 4] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= sy;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned h = cvt_pk_f16_w(v[2 * j], v[2 * j + 1]);
+      sp0[2 * half + j] = h;
+      sp1[2 * half + j] = cvt_pk_f16_w(resid_lo_w(h, v[2 * j]), resid_hi_w(h, v[2 * j + 1]));
+    }
+    if (half == 1) {
+      lds_ptr d = sbase + buf * kSlab + (i < 4 ? xslot + i * 16 : yslot + (i - 4) * 16);
+      *(lds_bf8)(d) = __builtin_bit_cast(bf8w, sp0);
+      *(lds_bf8)(d + 1024) = __builtin_bit_cast(bf8w, sp1);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j) request(j, m_begin);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    stash_half(0, i, 0);
+    stash_half(0, i, 1);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) request(j, m_begin + 32);      // (past the chunk: zeros)
+  __syncthreads();
+
+  const int wf = wave >> 1, wk = wave & 1;                    // this wave's 128 f x 128 k quarter of the tile
+  f32x16w acc[4][4];
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[fi][kt][e] = 0.0f;
+  lds_ptr lbase = (lds_ptr)smem + lane * 16;
+#pragma nounroll
+  for (int slab = 0; slab < n_slabs; ++slab) {
+    const int buf = slab & 1;
+    const long long m_next2 = m_begin + 32ll * (slab + 2);
+    lds_ptr rb = lbase + buf * kSlab;
+    asm volatile("" : "+v"(rb));
+    wfor<2>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      bf8w af[4][NP], bfr[2][NP];
+#pragma unroll
+      for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) af[fi][pl] = *(lds_bf8)(rb + (s * kFrags + (4 * wf + fi) * NP + pl) * 1024);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) bfr[0][pl] = *(lds_bf8)(rb + (s * kFrags + (8 + 4 * wk) * NP + pl) * 1024);
+      wfor<16>([&](auto G) {
+        constexpr int gi = decltype(G)::value, kt = gi >> 2, fi = gi & 3;
+        constexpr int u = s * 16 + gi;                       // 32 groups of 3 MFMAs per slab
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (fi == 0 && kt + 1 < 4) {
+#pragma unroll
+          for (int pl = 0; pl < NP; ++pl) bfr[(kt + 1) & 1][pl] = *(lds_bf8)(rb + (s * kFrags + (8 + 4 * wk + kt + 1) * NP + pl) * 1024);
+        }
+        // staging side task: the next slab's eight lane-fragment columns, each in two halves, groups 1..16; requests re-armed in group 17
+        if constexpr (u >= 1 && u <= 16) stash_half(buf ^ 1, (u - 1) >> 1, (u - 1) & 1);
+        if constexpr (u == 17) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) request(j, m_next2);
+        }
+        const bf8w b0 = bfr[kt & 1][0], b1 = bfr[kt & 1][1];
+        DINER_WG_MFMA_F16(acc[fi][kt], af[fi][1], b0);       // smallest terms first
+        DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], b1);
+        DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], b0);
+        if constexpr (u >= 1 && u <= 16) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        }
+        asm volatile("" : "+a"(acc[fi][kt]));
+      });
+    });
+    __syncthreads();
+  }
+  // epilogue: D layout of a 32 x 32 tile: lane holds column (k) = lane & 31, rows (f) = 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = 256 * kt2 + 32 * (4 * wk + kt) + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int f = 256 * ft + 32 * (4 * wf + fi) + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        const float val = acc[fi][kt][e] * inv_sy;
+        if (a.part) a.part[((size_t)chunk * 512 + f) * 512 + k] = val;
+        else atomicAdd(a.dW + (size_t)f * 512 + k, val);
+      }
+    }
+  if (a.db && kt2 == 0) {
+    const int f = 256 * ft + 64 * wave + 4 * li;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      rs[c] += __shfl_xor(rs[c], 16);
+      rs[c] += __shfl_xor(rs[c], 32);
+    }
+    if (lane < 16) {
+      if (a.part) {
+        float* pdb = a.part + (size_t)kWgMaxChunks * 512 * 512 + (size_t)chunk * 512;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pdb[f + c] = rs[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(a.db + f + c, rs[c]);
+      }
     }
   }
 }
