@@ -478,6 +478,16 @@ def test_scene_prepared_with_another_handle_is_refused(ops):
     assert call(hm_a.handle, ops.PRECISION_F16X3) == 0
     assert call(hm_b.handle, ops.PRECISION_F16X3) == -1 and b"another packed-weights handle" in ops.lib.diner_last_error()
     assert call(hm_a.handle, 2) == -1 and b"retired" in ops.lib.diner_last_error()
+    # ABI v4: the plain-fp16 mode gathers from the fp16 copy of the projected maps; without it the call is refused (nothing was prepared
+    # for that mode yet: this scene has only been used with f16x3), and the copy is stale as soon as the maps are prepared again
+    assert hs.struct.latent_proj_f16 is None
+    assert call(hm_a.handle, ops.PRECISION_F16) == -1 and b"diner_scene_prepare_f16" in ops.lib.diner_last_error()
+    hs.prepare(hm_a, f16=True)
+    assert hs.struct.latent_proj_f16 and call(hm_a.handle, ops.PRECISION_F16) == 0
+    first = out.clone()
+    hs.prepare(hm_a, force=True)                     # new fp32 maps: the host marks the fp16 copy stale and rebuilds it on the next f16 call
+    assert not hs._f16_current
+    assert torch.equal(ops.field_from_points(hs, hm_a, pts, dirs, precision="f16"), first) and hs._f16_current
     with pytest.raises(ValueError):
         ops.set_precision(2)
     assert max_norm_rel(ops.field_from_points(hs, hm_b, pts, dirs).cpu(), g["out"]) < TOL_STAGE      # the host re-prepares
