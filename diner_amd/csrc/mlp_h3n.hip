@@ -788,6 +788,26 @@ struct GatherSide {
     });
     finish();
   }
+  // the same in two parts (experiment DINER_HN_G0EARLY, round 4): head() = the first GD - 1 units' requests only (no blend reads xs yet),
+  // issued in front of the lin_in GEMM; tail() = the rest behind it
+  __device__ __forceinline__ void head() {
+    static_for<GD - 1>([&](auto H) {
+      run<decltype(H)::value, 0>();
+      run<decltype(H)::value, 1>();
+      run<decltype(H)::value, 2>();
+      run<decltype(H)::value, 3>();
+    });
+  }
+  __device__ __forceinline__ void tail() {
+    static_for<32 - (GD - 1)>([&](auto I) {
+      constexpr int H = GD - 1 + decltype(I)::value;
+      run<H, 0>();
+      run<H, 1>();
+      run<H, 2>();
+      run<H, 3>();
+    });
+    finish();
+  }
 };
 
 // The same side task for the plain-fp16 instances (round 4): the taps come from the FP16 copy of the projected maps
@@ -961,6 +981,17 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
     pf.mark(3);
     f32x4 xs[kSlice][kGroups], ns[kSlice][kGroups];
     set_bias(xs, a.b, wave, q);
+#if defined(DINER_HN_G0EARLY)
+    if constexpr (LO) {      // experiment: block 0's first tap requests in front of the lin_in GEMM (measured, not kept: profiles/r04_ab_runs.txt)
+      NoSide none;
+      GatherSide<DINER_HN_G0DEPTH, false> g0(fa.tz, taps_lds, wave, q, pt, xs);
+      g0.head();
+      gemm<2, 2, LO>(w_in, Bl, wave, lane, xs, none);
+      pf.mark(4);
+      g0.tail();
+      pf.mark(5);
+    } else
+#endif
     {
       NoSide none;
       gemm<2, 2, LO>(w_in, Bl, wave, lane, xs, none);
