@@ -792,3 +792,31 @@ def test_full_frame_properties_800x600(ops):
     assert torch.equal(white[:, 3], black[:, 3])
     print(f"800x600 frame: {int((~inside).sum())} rays with a sample beyond far; on the others sum(w) in [{float(wsum[inside].min()):.2e}, "
           f"{float(wsum[inside].max()):.6f}]; {int(hit.sum())} of {NR} rays have sum(w) > 0.5")
+
+
+def test_tile_queues_hand_out_every_tile_once(ops):
+    """Round 4: the per-view kernel's tiles are dealt to the 8 XCD queues by depth segment for ANY samples-per-ray count that is a multiple of
+    16 (QueueMap, mlp_h3n.hip: ray groups of 8 / gcd(S, 8), runs of S R / 8 slots per queue, entries past the launch skipped, the workgroups'
+    first tiles on the same map, stealing from the other queues).  A tile that is skipped leaves its 16 points unwritten, one that is handed out
+    twice is harmless -- so every (rays, samples) shape below is rendered by the f16x3 kernels (dynamic queues) and by the exact-fp32 kernels
+    (static round-robin over tiles) from a NaN-filled output: all finite and equal to the fp32 mode within the arithmetic's 2e-5.  Shapes: fewer
+    tiles than workgroups, ragged last ray group, S odd / even / a multiple of 8 / not a multiple of 16 (the default map), K up to the limit."""
+    sc, scene, w, msd, rays = oracle_setup(48, 40, 5)
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    g = torch.Generator().manual_seed(9)
+    for NR, K in ((1, 16), (3, 48), (7, 80), (333, 192), (1000, 16), (257, 112), (96, 256), (41, 40), (130, 128), (64, 208)):
+        r = rays[torch.randint(0, rays.shape[0], (NR,), generator=g)].cuda()
+        z = (r[:, 6:7].cpu() + (r[:, 7:8] - r[:, 6:7]).cpu() * torch.rand(NR, K, generator=g).sort(-1).values).cuda()
+        exact = ops.field_from_rays(hs, hm, r, z, precision="fp32")
+        ws_bytes = int(ops.lib.diner_field_workspace_bytes(NR * K))
+        for mode in ("f16x3", "f16"):
+            # poison what the call is about to allocate (the caching allocator hands the freed blocks of exactly these sizes back): the
+            # output and the hand-over workspace of the previous call would otherwise still hold a correct result
+            junk = [torch.full((NR, K, 4), float("nan"), device="cuda"), torch.full((ws_bytes,), 0xFF, dtype=torch.uint8, device="cuda")]
+            torch.cuda.synchronize()
+            del junk
+            got = ops.field_from_rays(hs, hm, r, z, precision=mode)
+            assert torch.isfinite(got).all(), (NR, K, mode)
+            tol = 2e-5 if mode == "f16x3" else 2e-2
+            assert max_norm_rel(got.cpu(), exact.cpu()) < tol, (NR, K, mode)
+    assert hm.fallback_launches() == 0
