@@ -175,6 +175,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get(CHILD_ENV):
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     import torch
+    launched_by = "bench.py self-launch" if os.environ.get(CHILD_ENV) else ("external launcher (torch.distributed.run)" if "WORLD_SIZE" in os.environ
+                                                                              else "none (one process, --force-dist)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -450,7 +452,7 @@ def main():
             rccl = None
         dist_info = {"world_size": dist.get_world_size(), "backend": str(dist.get_backend()), "rccl_version": rccl,
                      "devices_visible_per_rank": n_dev, "distinct_devices": len({(i["device"], i["pci_bus_id"]) for i in infos}),
-                     "ranks": infos, "launcher": "bench.py self-launch" if os.environ.get(CHILD_ENV) else "external (torch.distributed.run)"}
+                     "ranks": infos, "launcher": launched_by}
 
     # ---- the other arithmetic modes ------------------------------------------------------------------------------------------
     modes = {}
