@@ -1228,17 +1228,29 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     if (f16_packs) DINER_HIP_OK(hipMemsetAsync(ws + w.flags, 0, 16 * sizeof(int), st));
     if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st, f16_packs ? 4 : 2, reinterpret_cast<int*>(ws + w.flags) + kFlagWBad))) return rc;
   }
+  // seg2_slot >= 0: a second contraction segment in the same product (Lin512Args.X2: + x2 W[seg2_slot]^T + bias2, no relu on x2)
   auto lin = [&](const float* x, int ldx, const float* W, const float* b, float* y, long long M, int N, int K, bool relu,
-                 bool accum, const float* resid = nullptr, int slot = -1, const float* resid2 = nullptr) {
+                 bool accum, const float* resid = nullptr, int slot = -1, const float* resid2 = nullptr, const float* x2 = nullptr,
+                 int seg2_slot = -1, const float* bias2 = nullptr) {
     if (slot >= 0 && N == 512 && K == 512 && lin512_ok(x, ldx, y, N, resid, nullptr) && (reinterpret_cast<size_t>(b) & 15) == 0 &&
         (reinterpret_cast<size_t>(resid2) & 15) == 0) {      // (the epilogue reads bias / residuals as 16-byte vectors)
       void* wp = wpack_slot(ws, w, slot, false);
       Lin512Args a{x, wp, y, b, resid, nullptr, M, ldx, N, (relu ? kL512ReluIn : 0) | (accum ? kL512Accum : 0)};
       a.resid2 = resid2;
+      if (x2) {
+        a.X2 = x2;
+        a.Wp2 = wpack_slot(ws, w, seg2_slot, false);
+        a.bias2 = bias2;
+        a.relu2 = 0;
+      }
       if (use_fwd_f16() && !accum) {             // (an accumulating product cannot be run twice: lin_z stays on bf16x6)
         int* flag = reinterpret_cast<int*>(ws + w.flags) + slot;
         Lin512Args h = a;
         h.Wp = wpack_slot(ws, w, slot, false, true);
+        if (x2) {
+          h.Wp2 = wpack_slot(ws, w, seg2_slot, false, true);
+          h.ovf2 = reinterpret_cast<int*>(ws + w.flags) + seg2_slot;      // (the weight gradient of the fused layer looks at its own slot)
+        }
         h.ovf = flag;
         h.skip = reinterpret_cast<int*>(ws + w.flags) + kFlagWBad;      // weights beyond the fp16 split: raises the flag and returns
         int hrc = lin512_launch(h, st, 1);
@@ -1247,7 +1259,7 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
       }
       return lin512_launch(a, st);
     }
-    DINER_CHECK_ARG(!resid2, "field_train_forward: second residual off the 512-kernel path");
+    DINER_CHECK_ARG(!resid2 && !x2, "field_train_forward: second residual / second segment off the 512-kernel path");
     return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid);
   };
   // The lin_z term of block b, Z_b = lat Wz_b^T + bz_b, is a product of its own into a scratch buffer (d_lat is free in the forward) and
@@ -1270,9 +1282,17 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
     // next residual stream: X + fc_1(relu(H)); the view mean comes after block 2
     float* nx = b == 4 ? ws + w.x_last : (b == 2 ? ws + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
     const bool z_next = z_sep && b + 1 < 3;
-    if (z_next && (rc = lin_z(b + 1, Z))) return rc;
+    // round 4: the lin_z term of block b + 1 as a SECOND CONTRACTION SEGMENT of this block's fc_1 product (K = 512 + 512: relu(H) W1^T +
+    // lat Wz^T + both biases + X in one pass over the rows) -- no Z tensor written and read back (2 of this block's ~8 tensor passes).
+    // DINER_TRAIN_FUSE_Z=0: Z_{b+1} as a product of its own into the scratch buffer, entering through the second residual (round 3)
+    static const bool fuse_z = [] { const char* e = getenv("DINER_TRAIN_FUSE_Z"); return !(e && *e == '0'); }();
+    const bool fused = z_next && fuse_z && use_fwd_f16() && (reinterpret_cast<size_t>(p->lin_z_b[b + 1]) & 15) == 0;
+    if (z_next && !fused && (rc = lin_z(b + 1, Z))) return rc;
     // (the residual enters through the product's epilogue: no copy of X)
-    if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b, z_next ? Z : nullptr))) return rc;
+    if (fused) {
+      if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b, nullptr,
+                    ws + w.lat, kSlotLinZ + b + 1, p->lin_z_b[b + 1]))) return rc;
+    } else if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b, z_next ? Z : nullptr))) return rc;
     if (b == 2)
       hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3]);
   }

@@ -145,7 +145,10 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   constexpr int NRT = 4 / FH, NF = NP * NRT;                 // MFMA row (= feature) tiles per wave, weight fragments per k16 step
   if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
   if (a.skip && *a.skip != 0) {                              // f16x3 launch of a step whose weights do not fit: the bf16x6 twin works
-    if (a.ovf && threadIdx.x == 0) *a.ovf = 1;               // (the forward's twin is gated on this product's flag)
+    if (a.ovf && threadIdx.x == 0) {                         // (the forward's twin is gated on this product's flag)
+      *a.ovf = 1;
+      if (a.ovf2) *a.ovf2 = 1;
+    }
     return;
   }
   // AR = 1 with amax_in: the staged operand times sx = 2^(14 - E), E the exponent of the operand's maximum; the epilogue takes it out
@@ -166,7 +169,9 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const long long n_tiles = (a.M + kRows - 1) / kRows;
-  const int relu_floor = (a.flags & kL512ReluIn) ? 0 : (int)0x80000000;
+  const int relu_floor1 = (a.flags & kL512ReluIn) ? 0 : (int)0x80000000, relu_floor2 = a.relu2 ? 0 : (int)0x80000000;
+  int relu_floor = relu_floor1;                              // of the slab being converted (two contraction segments: set per slab)
+  const int n_slabs = a.X2 ? 2 * kSlabs : kSlabs;            // slabs kSlabs .. 2 kSlabs - 1: the second segment (X2, Wp2)
   lds_ptr lbase = (lds_ptr)smem + lane * 16;                 // lane's 16 B slot in fragment 0 of slab buffer 0
   // ---- staging share of this wave: rows [8 CT w, 8 CT (w + 1)) of the tile, all 128 contraction indices of the slab.  Request i (0..NQ-1)
   // reads rows 8 CT w + 2 i and + 1 whole: lanes 0..31 one row (512 contiguous bytes), lanes 32..63 the next -- 8 cache lines per
@@ -180,9 +185,10 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
     const long long row0 = tile * kRows;
     long long left = a.M - row0;
     left = left < 0 ? 0 : (left > kRows ? kRows : left);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X + (size_t)row0 * a.ldx), 0,
+    const float* src = slab >= kSlabs ? a.X2 : a.X;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)row0 * a.ldx), 0,
                                                                         (int)(left * a.ldx * 4), 0x00020000);
-    xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvoff, ((unsigned)(2 * i) * (unsigned)a.ldx + 128u * slab) * 4u, 0));
+    xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvoff, ((unsigned)(2 * i) * (unsigned)a.ldx + 128u * (slab & (kSlabs - 1))) * 4u, 0));
   };
   auto request_slab = [&](long long tile, int slab) {
 #pragma unroll
@@ -242,13 +248,15 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   const int wslice = FH == 2 ? 2 * half + (wave >> 1) : wave;                // 128-feature slice of the packed weights
   const int rt0 = FH == 2 ? 2 * (wave & 1) : 0;                              // first of this wave's row tiles inside the slice
   const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + ((size_t)wslice * 32 * (4 * NP) + NP * rt0) * 1024;
+  const gptr wbase2 = (gptr)(reinterpret_cast<const char*>(a.Wp2 ? a.Wp2 : a.Wp)) + ((size_t)wslice * 32 * (4 * NP) + NP * rt0) * 1024;
+  const int step_mask = 8 * n_slabs - 1;                     // k16 steps of a tile - 1 (the weight stream repeats per tile)
   const unsigned woff = lane * 16;
   bf8 wr[R][NF];
   auto load_w = [&](bf8 (&dst)[NF], int step, int first, int count) {        // fragments [first, first + count) of step (0..31)
 #ifdef DINER_L512_ABL_W       // ablation (wrong results): a 24 KB weight working set per wave, i.e. no L2 latency on the weight stream
     step &= 1;
 #endif
-    gptr p = wbase + (size_t)step * (4 * NP) * 1024;
+    gptr p = (step >= 32 ? wbase2 : wbase) + (size_t)(step & 31) * (4 * NP) * 1024;
     asm volatile("" : "+s"(p));                  // scalar base + per-lane 32-bit offset + immediate: no address registers per load
 #pragma unroll
     for (int i = first; i < first + count; ++i) dst[i] = *(const __attribute__((address_space(1))) bf8*)(p + woff + i * 1024);
@@ -276,14 +284,15 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
 #pragma nounroll
-    for (int slab = 0; slab < kSlabs; ++slab, ++unit) {
+    for (int slab = 0; slab < n_slabs; ++slab, ++unit) {
+      relu_floor = (slab + 1 >= kSlabs && slab + 1 < n_slabs) ? relu_floor2 : relu_floor1;      // the slab converted during this one
       const int buf = unit & 1;
       // Staging, branch-free so that the conversion can be scheduled between the MFMAs: during this slab the NEXT slab (requested one
       // slab ago, in xst) is converted and written to the other buffer, one request per k16 step, and each request register is
       // re-armed at once with the slab after that.  Past the workgroup's last slab the requests repeat valid addresses (harmless).
-      const bool last = slab == kSlabs - 1;
-      long long t2 = slab >= kSlabs - 2 ? tile + tile_stride : tile;          // tile / slab two slabs ahead
-      const int s2 = (slab + 2) & (kSlabs - 1);
+      const bool last = slab == n_slabs - 1;
+      long long t2 = slab >= n_slabs - 2 ? tile + tile_stride : tile;          // tile / slab two slabs ahead
+      const int s2 = (slab + 2) & (n_slabs - 1);
       if (t2 >= n_tiles) t2 = tile;
       (void)last;
       lds_ptr rb = lbase + buf * (kSlabFrags * 1024);
@@ -315,7 +324,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
           constexpr int ia = AR == 1 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0);
           constexpr int ib = AR == 1 ? (t == 1 ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0);
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (LW * g < NF) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & 31, LW * g, (LW * g + LW <= NF ? LW : NF - LW * g));
+          if constexpr (LW * g < NF) load_w(wr[(s + R - 1) % R], (gstep + R - 1) & step_mask, LW * g, (LW * g + LW <= NF ? LW : NF - LW * g));
           if constexpr (kRollB) {
             if constexpr (t == 0 && ct > 0 && s + 1 < kStepsPerSlab) load_b1(0, s + 1, ct - 1);
             if constexpr (g == 0 && s > 0) load_b1(0, s, CT - 1);
@@ -382,6 +391,11 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
 #pragma unroll
         for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(bp + 32 * (n >> 2) + 8 * (n & 3));
       }
+      if (a.bias2) {
+        const float* bp = a.bias2 + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(bp + 32 * (n >> 2) + 8 * (n & 3));
+      }
       if (a.resid) {
 #pragma unroll
         for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.resid + at0 + 32 * (n >> 2) + 8 * (n & 3));
@@ -418,7 +432,10 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
     if (lane == 0 && y_max) atomicMax(a.amax_out, y_max);
   }
   if constexpr (AR == 1) {                                   // an operand beyond the fp16 range (or not finite): the caller's bf16x6 launch recomputes
-    if (a.ovf && ((x_max & 0xffffu) >= 0x7c00u || (x_max >> 16) >= 0x7c00u)) *a.ovf = 1;      // a hi half was inf or NaN
+    if (a.ovf && ((x_max & 0xffffu) >= 0x7c00u || (x_max >> 16) >= 0x7c00u)) {      // a hi half was inf or NaN
+      *a.ovf = 1;
+      if (a.ovf2) *a.ovf2 = 1;
+    }
   }
 }
 

@@ -26,6 +26,13 @@ struct Lin512Args {
                              // maximum lose their low part (far below fp32 round-off of any sum the maximum takes part in); null: no scaling
   unsigned* amax_out;        // null, or: atomic maximum of the bit patterns of |Y| as stored (zeroed by the caller): the next product's amax_in
   const int* skip;           // null, or: the launch does nothing when *skip != 0 (an f16x3 product whose weights do not fit 16 w in fp16)
+  // round 4 -- a second contraction segment: Y = act(X) Wp^T + act2(X2) Wp2^T + ... (K = 512 + 512 in one pass over the rows; the forward
+  // uses it for fc_1 of block b together with lin_z of block b + 1, whose sum is the next residual stream: no Z tensor written and read back)
+  const float* X2;           // (M, ldx) or null; same row stride as X
+  const void* Wp2;           // packed weights of the second segment (same pack mode as Wp)
+  const float* bias2;        // 512 or null
+  int relu2;                 // relu on the second segment's operand
+  int* ovf2;                 // f16x3: a second flag raised together with ovf (the weight gradient of the fused layer looks at its own slot)
 };
 
 // W (512, 512) row-major fp32 -> packed planes; transpose = 0: y = x W^T (W as nn.Linear stores it), 1: y = x W
