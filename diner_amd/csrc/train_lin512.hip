@@ -33,8 +33,12 @@ constexpr float kF16Scale = 16.0f, kF16InvScale = 1.0f / 16.0f;      // f16x3 ar
 
 constexpr int kStepsPerSlab = 8;                // k16 steps per staged slab (128 contraction indices)
 constexpr int kSlabs = 512 / (16 * kStepsPerSlab);
-constexpr size_t kLdsBytes512 = (size_t)2 * kStepsPerSlab * 2 * 3 * 1024;  // two slab buffers of [step 8][row half CT][plane 3] 1 KB fragments: 96 KB at CT = 2
-constexpr size_t kLdsBytes512F16 = (size_t)2 * kStepsPerSlab * 4 * 2 * 1024;  // f16x3 (two planes) at CT = 4 (128-row tiles): 128 KB
+#ifndef DINER_L512_STEP_PAD       // bytes between the k16 steps of a slab buffer beyond their fragments, see lin512_body (staging writes)
+#define DINER_L512_STEP_PAD 32
+#endif
+constexpr int kStepPad = DINER_L512_STEP_PAD;
+constexpr size_t kLdsBytes512 = (size_t)2 * kStepsPerSlab * (2 * 3 * 1024 + kStepPad);  // two slab buffers of [step 8][row half CT][plane 3] 1 KB fragments: 96 KB at CT = 2
+constexpr size_t kLdsBytes512F16 = (size_t)2 * kStepsPerSlab * (4 * 2 * 1024 + kStepPad);  // f16x3 (two planes) at CT = 4 (128-row tiles): 128 KB
 
 // fp32 -> three bf16 planes (round to nearest each time; the residuals are exact in fp32), 8 values at once
 __device__ __forceinline__ void split3x8(const float (&v)[8], bf8& p0, bf8& p1, bf8& p2) {
@@ -142,6 +146,11 @@ template <int R, int CT, int FH, int AR = 0>
 __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, const int nblk) {
   constexpr int NP = AR == 1 ? 2 : 3, NT = AR == 1 ? 3 : 6;  // planes per operand, product terms
   constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * NP, NQ = 4 * CT;      // NQ: staging requests per wave and slab
+  // A staging write puts 8 bytes per lane into the fragments of EIGHT k16 steps at once (a lane holds 4 consecutive k of one row); with the
+  // steps a multiple of 1 KB apart those are 8 lanes per LDS bank (PMC, round 4: 70 % of the kernel's LDS-active cycles were bank-conflict
+  // cycles).  kStepPad = 32 bytes between the steps spreads them over the banks (2 lanes per bank are left: the two 8-row halves of a
+  // fragment are 512 bytes apart by the MFMA layout); the fragment reads stay 1 KB contiguous per instruction.
+  constexpr int kStepBytes = CT * NP * 1024 + kStepPad, kSlabBytes = kStepsPerSlab * kStepBytes;
   constexpr int NRT = 4 / FH, NF = NP * NRT;                 // MFMA row (= feature) tiles per wave, weight fragments per k16 step
   if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
   if (a.skip && *a.skip != 0) {                              // f16x3 launch of a step whose weights do not fit: the bf16x6 twin works
@@ -198,7 +207,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   typedef __attribute__((address_space(3))) bf4* lds_bf4;
   // where this lane's 4 values go inside a slab buffer: step s = k / 16, lane' = (row & 31) + 32 ((k / 8) & 1), element k & 7
   const int k4 = 4 * (lane & 31);
-  const int st_off = ((k4 >> 4) * CT * NP) * 1024 + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
+  const int st_off = (k4 >> 4) * kStepBytes + (32 * ((k4 >> 3) & 1)) * 16 + (k4 & 7) * 2;
   bf4 sp0, sp1, sp2;                                         // the request being converted (two halves, see the slab loop)
   unsigned x_max = 0;                                        // AR = 1: packed running maximum of the |hi| halves this lane has produced
   auto stash_half = [&](int i, int half) {
@@ -232,7 +241,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   };
   auto stash_write = [&](int buf, int i) {
     const int r = 8 * CT * wave + 2 * i + (lane >> 5);       // row within the tile
-    lds_ptr d = (lds_ptr)smem + buf * (kSlabFrags * 1024) + st_off + ((r >> 5) * NP) * 1024 + (r & 31) * 16;
+    lds_ptr d = (lds_ptr)smem + buf * kSlabBytes + st_off + ((r >> 5) * NP) * 1024 + (r & 31) * 16;
     *(lds_bf4)(d) = sp0;
     *(lds_bf4)(d + 1024) = sp1;
     if constexpr (NP == 3) *(lds_bf4)(d + 2048) = sp2;
@@ -295,7 +304,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
       const int s2 = (slab + 2) & (n_slabs - 1);
       if (t2 >= n_tiles) t2 = tile;
       (void)last;
-      lds_ptr rb = lbase + buf * (kSlabFrags * 1024);
+      lds_ptr rb = lbase + buf * kSlabBytes;
       asm volatile("" : "+v"(rb));
       // B fragments [parity][row part][plane]; CT = 4: ONE buffer, each row part re-read for the next step right after its last use in this
       // one (groups run row part by row part: part c is free from group 3 (c + 1) on; the last part at the top of the next step) -- 32
@@ -304,7 +313,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
       bf8 bb[kRollB ? 1 : 2][CT][NP];
       auto load_b1 = [&](int par, int s, int h) {
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + ((s * CT + h) * NP + pl) * 1024);
+        for (int pl = 0; pl < NP; ++pl) bb[par][h][pl] = *(lds_bf8)(rb + s * kStepBytes + (h * NP + pl) * 1024);
       };
       auto load_b = [&](int par, int s) {
 #pragma unroll
