@@ -29,6 +29,11 @@ CASES = {   # name: (W, H, scene seed, K, G, white, noise seed of the fixture, s
     "g16": ("g16_render_K192_dtu", 400, 300, 0, 192, 72, False, 116, {}, 48),
 }
 EXTRA_SEEDS = (1000, 2000)       # added to the fixture's noise seed
+# `python oracle/make_golden_seeds.py ensemble [g9] [g10] [g16]`: six MORE seeds per fixture -> tests/golden/g18_seed_ensemble.npz.  With the two
+# above that is an 8-member ensemble of the reference's own renders whose mean is the "ground truth" of a PSNR-vs-ground-truth comparison: the
+# stand-in for north_star's "PSNR within 0.05 dB of reference on DTU val" (the GPU test compares PSNR(HIP image, ensemble mean) with
+# PSNR(reference's fixture image, ensemble mean)).
+ENSEMBLE_SEEDS = (3000, 4000, 5000, 6000, 7000, 8000)
 
 
 def psnr(a, b):
@@ -36,9 +41,13 @@ def psnr(a, b):
 
 
 def main():
-    which = [a.lower() for a in sys.argv[1:]] or list(CASES)
+    args = [a.lower() for a in sys.argv[1:]]
+    ensemble = "ensemble" in args
+    which = [a for a in args if a != "ensemble"] or list(CASES)
     torch.set_num_threads(os.cpu_count())
     ns = import_reference()
+    if ensemble:
+        return make_ensemble(ns, which)
     path = os.path.join(OUT, "g17_seed_to_seed.npz")
     store = dict(np.load(path)) if os.path.exists(path) else {}
     with torch.no_grad():
@@ -69,6 +78,32 @@ def main():
             store[f"{key}_psnr_s2_vs_fixture"] = np.float64(psnr(imgs[1][0], ref_rgb))
             store[f"{key}_psnr_s1_vs_s2"] = np.float64(psnr(imgs[0][0], imgs[1][0]))
             store[f"{key}_noise_seeds"] = np.array([noise_seed + s for s in EXTRA_SEEDS])
+            np.savez_compressed(path, **store)
+    print("done", path)
+
+
+def make_ensemble(ns, which):
+    path = os.path.join(OUT, "g18_seed_ensemble.npz")
+    store = dict(np.load(path)) if os.path.exists(path) else {}
+    with torch.no_grad():
+        for key in which:
+            name, W, H, seed, K, G, white, noise_seed, scene_kw, n_lat = CASES[key]
+            fix = np.load(os.path.join(OUT, name + ".npz"))
+            sc, nerf, scene, w, rays = setup(ns, W, H, seed, **scene_kw)
+            rs = rays[lattice(W, H, n_lat)].contiguous()
+            assert np.array_equal(rs.numpy(), fix["rays"]), "ray lattice differs from the fixture's"
+            NR, n_cand = rs.shape[0], 1000
+            ren = ns.nerf_renderer.NeRFRendererDGS(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=white)
+            imgs = []
+            for s in ENSEMBLE_SEEDS:
+                g = torch.Generator().manual_seed(noise_seed + s)
+                nz = (torch.rand(NR, n_cand, generator=g), torch.randn(NR, G, generator=g), torch.rand(NR, K, generator=g))
+                with inject_noise(*nz):
+                    out = ren.forward(nerf, rs[None])
+                imgs.append(out.fine.rgb[0].clone())
+                print(f"{name} ensemble seed +{s}: PSNR against the fixture's image {psnr(imgs[-1], torch.from_numpy(fix['rgb'])):.2f} dB", flush=True)
+            store[f"{key}_rgb"] = torch.stack(imgs).numpy().astype(np.float32)          # (6, NR, 3)
+            store[f"{key}_noise_seeds"] = np.array([noise_seed + s for s in ENSEMBLE_SEEDS])
             np.savez_compressed(path, **store)
     print("done", path)
 

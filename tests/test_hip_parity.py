@@ -218,6 +218,9 @@ def test_render_cfg1_end_to_end(ops, precision):
     assert psnr > 55.0 and psnr_same > 90.0
 
 
+# margin of |PSNR(HIP, ground truth) - PSNR(reference's image, ground truth)| per fixture, see statement (5) of the render test: north_star's 0.05 dB
+PSNR_VS_GT_MARGIN_DB = {"g9": 0.05, "g10": 0.05, "g16": 0.05}
+
 RENDER_FIXTURES = {
     # name: (scene kwargs of diner_amd.synthetic.make_scene,
     #        max number of class-A rays, max number of class-B rays (erf round-off classes, see the test), each pinned a few per cent
@@ -387,6 +390,21 @@ def test_render_at_metric_sample_counts(ops, precision, name):
         assert abs(bias) <= 3.0 * se + 1e-6
         assert worst_ray_hip <= worst_ray_seed * 1.05 + 1e-6
     print(msg)
+    # (5) PSNR against "ground truth" (G18): the mean of EIGHT other-seed renders of the reference itself (the two of G17 + six more) is the
+    # expected image of this scene -- what a ground-truth photo is to the metric of north_star ("PSNR within 0.05 dB of reference on DTU val").
+    # PSNR(HIP image, ground truth) must equal PSNR(the reference's fixture image, ground truth) within that margin: the HIP image IS the
+    # fixture's image except on the rays whose sample set differs, and those are other draws from the same distribution.
+    ens = load("g18_seed_ensemble.npz")
+    members = [T(m) for m in ens[f"{key}_rgb"]] + seeds
+    gt = torch.stack(members).mean(0)
+    p_hip, p_fix = psnr_of(hr, gt), psnr_of(ref_rgb, gt)
+    loo = []
+    for i in range(len(members)):                 # the reference's own spread: each member against the mean of the others
+        rest = torch.stack([m for j, m in enumerate(members) if j != i]).mean(0)
+        loo.append(psnr_of(members[i], rest))
+    print(f"{name} [{precision}] PSNR against the 8-seed ensemble mean of the reference: HIP {p_hip:.3f} dB, reference's fixture image {p_fix:.3f} dB "
+          f"(difference {p_hip - p_fix:+.3f} dB; the reference's members against the mean of the others: {min(loo):.2f} .. {max(loo):.2f} dB)")
+    assert abs(p_hip - p_fix) <= PSNR_VS_GT_MARGIN_DB[key], (p_hip, p_fix)
 
 
 def test_cfg5_fp16_mlp_psnr(ops):
