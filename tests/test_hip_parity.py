@@ -426,6 +426,17 @@ def test_cfg5_fp16_mlp_psnr(ops):
               f"{out[mode][1]:.2e}, depth {out[mode][2]:.2e}")
     assert out["f16"][0] >= 50.0 and out["f16"][1] < 1e-2
     assert out["f16x3"][0] >= 90.0 and out["f16x3"][1] < TOL
+    # the metric itself (G18, see test_render_at_metric_sample_counts statement 5): PSNR of the fp16-mode image against the mean of the
+    # reference's 8-seed ensemble is the reference image's own to far less than north_star's 0.05 dB -- an image 84 dB from the reference's
+    # cannot move a 37 dB PSNR
+    ens, s2s = load("g18_seed_ensemble.npz"), load("g17_seed_to_seed.npz")
+    gt = torch.stack([T(m) for m in ens["g10_rgb"]] + [T(s2s[f"g10_rgb_s{i}"]) for i in (1, 2)]).mean(0)
+    psnr_of = lambda a, b: float(-10.0 * torch.log10((a - b).square().mean()))
+    _, rgb16, _ = ops.render(hs, hm, rc, T(g["z"]).cuda(), white, precision="f16")
+    d = psnr_of(rgb16.cpu(), gt) - psnr_of(ref_rgb, gt)
+    print(f"cfg5 K=192 white [f16]: PSNR against the reference's 8-seed ensemble mean {psnr_of(rgb16.cpu(), gt):.4f} dB, the reference image's own "
+          f"{psnr_of(ref_rgb, gt):.4f} dB (difference {d:+.5f} dB)")
+    assert abs(d) < 0.005
 
 
 def test_fp16_overflow_falls_back_to_exact_kernels(ops):
