@@ -558,3 +558,50 @@ def test_training_step_two_objects_patch_of_rays(ops):
             assert r_par < 3e-3 and r_lat < 3e-3
     # the per-object slabs of the latent gradient are different (each object's own rays and maps)
     assert not torch.equal(nerf.encoder.latent.grad[0], nerf.encoder.latent.grad[1])
+
+
+def test_shipped_ray_batch_equals_the_sum_of_reference_sized_batches(ops):
+    """The ray batch the shipped configs train on (4096 rays per object = a 64 x 64 patch, diner.py:57 with configs/train_dtu.yaml:63; 163,840
+    sample points, 655,360 per-view rows) takes launch plans no oracle comparison reaches -- 128-row tiles of the forward / data-gradient
+    products, 256 x 256 weight-gradient tiles over 64 row chunks, the two-segment fc_1 + lin_z product -- and a CPU autograd of that size needs
+    40 GB.  Size-independent property instead: rays are independent and the loss is a sum over rays, so the gradients of the 4096-ray step
+    are the SUM of the gradients of its 32 sub-batches of 128 rays -- the size whose gradients are pinned against the oracle's autograd at 1e-4
+    (test_field_forward_and_backward_against_oracle_autograd[5120]).  Per row the arithmetic is the same whatever the tile shape, so the relu
+    decisions are the same and only the summation order of the weight gradients differs: 1e-4 max-norm per tensor, rgb bit for bit."""
+    from tests.test_boundary_gpu import setup_model
+    from diner_amd import noise
+    sc, nerf, R, rays = setup_model(64, 64, 8)
+    nerf.train()
+    NR, K, G, n_cand, CH = 4096, 40, 15, 1000, 128
+    r = rays.cuda()[None]                                                   # all 64 x 64 rays of the target view
+    assert r.shape[1] == NR
+    gen = torch.Generator().manual_seed(5)
+    inj = (torch.rand(1, NR, n_cand, generator=gen).cuda(), torch.randn(1, NR, G, generator=gen).cuda(), torch.rand(1, NR, K, generator=gen).cuda())
+    Gm = torch.randn(1, NR, 3, generator=gen).cuda()
+    ren = R(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=True)
+    nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+    params = dict(nerf.mlp_fine.named_parameters())
+
+    def step(lo, hi):
+        for p in params.values():
+            p.grad = None
+        nerf.encoder.latent.grad = None
+        with noise.inject(*(t[:, lo:hi] for t in inj)):
+            out = ren.forward(nerf, r[:, lo:hi])
+        (out.fine.rgb * Gm[:, lo:hi]).sum().backward()
+        return out.fine.rgb.detach(), {k: p.grad.clone() for k, p in params.items()}, nerf.encoder.latent.grad.clone()
+
+    rgb_full, g_full, l_full = step(0, NR)
+    assert torch.isfinite(rgb_full).all() and all(torch.isfinite(v).all() for v in g_full.values())
+    g_sum = {k: torch.zeros_like(v) for k, v in g_full.items()}
+    l_sum = torch.zeros_like(l_full)
+    for lo in range(0, NR, CH):
+        rgb_c, g_c, l_c = step(lo, lo + CH)
+        assert torch.equal(rgb_c, rgb_full[:, lo:lo + CH]), f"rays {lo}..{lo + CH}: the forward depends on the batch the ray is rendered in"
+        for k in g_sum:
+            g_sum[k] += g_c[k]
+        l_sum += l_c
+    worst = max(((k, max_norm_rel(g_full[k].cpu(), g_sum[k].cpu())) for k in g_sum), key=lambda t: t[1])
+    e_lat = max_norm_rel(l_full.cpu(), l_sum.cpu())
+    print(f"4096-ray step against the sum of its 32 sub-batches of 128 rays: worst parameter gradient {worst[0]} {worst[1]:.2e}, d latent {e_lat:.2e}; rgb bit-equal")
+    assert worst[1] < TOL_GRAD and e_lat < TOL_GRAD
