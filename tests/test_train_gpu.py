@@ -605,3 +605,54 @@ def test_shipped_ray_batch_equals_the_sum_of_reference_sized_batches(ops):
     e_lat = max_norm_rel(l_full.cpu(), l_sum.cpu())
     print(f"4096-ray step against the sum of its 32 sub-batches of 128 rays: worst parameter gradient {worst[0]} {worst[1]:.2e}, d latent {e_lat:.2e}; rgb bit-equal")
     assert worst[1] < TOL_GRAD and e_lat < TOL_GRAD
+
+
+def test_shipped_step_four_objects_equals_the_sum_of_its_objects(ops):
+    """The whole step the shipped configs run (configs/train_dtu.yaml:16,63: SB = 4 objects x 4096 rays x 40 samples; DINER.calc_losses,
+    diner.py:217-290: ONE renderer.forward on (4, 4096, 8) rays): 60 GB of saved activations alive between forward and backward, the SB
+    per-object field nodes, one autograd node for the objects' latent slabs (diner_amd.train._ObjectSlabs), autograd's sum of the four
+    gradient sets of the shared MLP parameters.  Property: objects are independent, so the step's parameter gradients are the sum of the four
+    single-object steps' and its latent gradient is their stack (the single-object 4096-ray step is tied to the oracle by
+    test_shipped_ray_batch_equals_the_sum_of_reference_sized_batches)."""
+    from diner_amd import noise
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict, build_modules
+    W = H = 64
+    SB, NR, K, G, n_cand = 4, 4096, 40, 15, 1000
+    scs = [make_scene(W, H, seed=21 + s) for s in range(SB)]
+    msd = make_mlp_state_dict()
+    dev = torch.device("cuda", 0)
+    E = torch.stack([s["target_extrinsics"] for s in scs])
+    Km = torch.stack([s["target_intrinsics"] for s in scs])
+    rays = ops.gen_rays(E, Km, W, H, scs[0]["znear"], scs[0]["zfar"], dev)                  # (SB, 4096, 8)
+    gen = torch.Generator().manual_seed(13)
+    inj = (torch.rand(SB, NR, n_cand, generator=gen).cuda(), torch.randn(SB, NR, G, generator=gen).cuda(), torch.rand(SB, NR, K, generator=gen).cuda())
+    Gm = torch.randn(SB, NR, 3, generator=gen).cuda()
+
+    def run(objs):
+        nerf, R = build_modules([scs[i] for i in objs], msd, dev)
+        nerf.train()
+        nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+        ren = R(n_samples=K, n_depth_candidates=n_cand, n_gaussian=G, white_bkgd=True)
+        idx = torch.tensor(objs, device=dev)
+        with noise.inject(*(t[idx] for t in inj)):
+            out = ren.forward(nerf, rays[idx])
+        (out.fine.rgb * Gm[idx]).sum().backward()
+        g = {k: p.grad.clone() for k, p in nerf.mlp_fine.named_parameters()}
+        return out.fine.rgb.detach().clone(), g, nerf.encoder.latent.grad.clone()
+
+    torch.cuda.reset_peak_memory_stats()
+    rgb_all, g_all, l_all = run(list(range(SB)))
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert rgb_all.shape == (SB, NR, 3) and l_all.shape[0] == SB and torch.isfinite(rgb_all).all()
+    g_sum = {k: torch.zeros_like(v) for k, v in g_all.items()}
+    for sb in range(SB):
+        rgb1, g1, l1 = run([sb])
+        assert torch.equal(rgb1[0], rgb_all[sb])
+        # (the latent gradient is scattered with float atomics: the order of the additions is not reproducible, the values are to round-off)
+        assert max_norm_rel(l_all[sb].cpu(), l1[0].cpu()) < 1e-5, f"object {sb}: latent gradient slab differs from the single-object step's"
+        for k in g_sum:
+            g_sum[k] += g1[k]
+    worst = max(((k, max_norm_rel(g_all[k].cpu(), g_sum[k].cpu())) for k in g_sum), key=lambda t: t[1])
+    print(f"SB = 4 x 4096 rays x 40 samples: peak device memory {peak:.1f} GiB; parameter gradients against the sum of the four single-object steps: "
+          f"worst {worst[0]} {worst[1]:.2e}; latent gradient slabs within 1e-5, rgb bit-equal per object")
+    assert worst[1] < 1e-5
