@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU baseline sample (0 disables)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-modes", action="store_true", help="skip the extra passes in the other arithmetic modes")
+    ap.add_argument("--modes-multi", action="store_true",
+                    help="with N > 1 the extra passes in the other arithmetic modes are OFF by default (a scaling run needs the headline only); "
+                         "this switches them on")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the extra passes of the other single-GPU BASELINE configs (400x300; 1024x1024 K=192 f16 / f16x3; "
                          "800x600 through the drop-in modules)")
@@ -290,14 +293,33 @@ def main():
                 dst[r0:r0 + args.ray_batch, :3] = rgb
                 dst[r0:r0 + args.ray_batch, 3] = depth
 
+        phases = []             # per timed frame of this rank: (event start, after the hoist, after the shard, after the gather, host s of a staged gather)
+        res["phases"] = phases
+
         def step(seed, precision, max_rays=None):
             # per-scene preparation (projection of the latent through lin_z[0..2]) is redone every
             # frame inside the timed region, so that no cached per-scene output is excluded from the measurement
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if res.get("record_phases") else None
+            if ev:
+                ev[0].record()
             scene.prepare(mlp, force=True, f16=precision == ops.PRECISION_F16)      # (the fp16 copy of the maps belongs to the f16 mode's frame)
+            if ev:
+                ev[1].record()
             n = hi - lo if max_rays is None else min(hi - lo, max_rays)
             render_range(lo, lo + n, seed, precision, out)
+            if ev:
+                ev[2].record()
             if multi and not args.weak:
+                host_s = None
+                if ev and backend != "nccl":       # the staged gather begins with a stream synchronisation anyway: take it first, then the
+                    torch.cuda.current_stream().synchronize()      # host clock brackets the gather alone (pinned copy + gloo + upload on rank 0)
+                    t_g = time.perf_counter()
                 frame[0] = gather_tiles(out, NRF, rank, world, force=args.force_dist)   # one RCCL gather of the rendered tiles per frame
+                if ev:
+                    if backend != "nccl":
+                        host_s = time.perf_counter() - t_g
+                    ev[3].record()                 # (RCCL: the current stream waits for the collective, the event closes behind it)
+                    phases.append((ev, host_s))
             elif multi:
                 src = out if backend == "nccl" else out.cpu()
                 gat = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
@@ -396,7 +418,9 @@ def main():
 
     for i in range(args.warmup):
         step(i, head)
+    wl_head["record_phases"] = bool(multi and not args.weak and not args.via_modules)
     elapsed, prof = timed(args.steps, head, args.warmup, profile=True)
+    wl_head["record_phases"] = False
     if not os.environ.get("DINER_AMD_LIB"):        # (timing experiments with ablated libraries produce garbage)
         if out is not None:
             assert torch.isfinite(out).all(), "non-finite render output"
@@ -444,6 +468,14 @@ def main():
         pr = torch.cuda.get_device_properties(dev)
         me = {"rank": rank, "local_rank": local_rank, "device": dev.index, "name": pr.name,
               "pci_bus_id": getattr(pr, "pci_bus_id", None), "uuid": str(getattr(pr, "uuid", "")) or None, "pid": os.getpid()}
+        ph = wl_head.get("phases") or []
+        if ph:                                  # the timed frames of THIS rank: hoist / shard / gather, HIP events on the launch stream
+            torch.cuda.synchronize()
+            stat = lambda v: {"min": round(min(v), 3), "median": round(sorted(v)[len(v) // 2], 3), "max": round(max(v), 3)}
+            hoist = [e[0].elapsed_time(e[1]) for e, _ in ph]
+            shard = [e[1].elapsed_time(e[2]) for e, _ in ph]
+            gath = [(e[2].elapsed_time(e[3]) if hs is None else hs * 1e3) for e, hs in ph]
+            me.update({"rays": hi - lo, "frames": len(ph), "hoist_ms": stat(hoist), "shard_ms": stat(shard), "gather_ms": stat(gath)})
         infos = [None] * world
         dist.all_gather_object(infos, me)
         try:
@@ -453,10 +485,27 @@ def main():
         dist_info = {"world_size": dist.get_world_size(), "backend": str(dist.get_backend()), "rccl_version": rccl,
                      "devices_visible_per_rank": n_dev, "distinct_devices": len({(i["device"], i["pci_bus_id"]) for i in infos}),
                      "ranks": infos, "launcher": launched_by}
+        if all("shard_ms" in i for i in infos):
+            # what a sub-linear SCALE line is made of: the slowest rank's replicated hoist + its shard against the measured frame time
+            # (the rest = the gather, the barrier and launch gaps); shard raggedness = slowest / fastest shard
+            busy = [i["hoist_ms"]["median"] + i["shard_ms"]["median"] for i in infos]
+            frame_ms = elapsed / args.steps * 1e3
+            dist_info["breakdown"] = {
+                "frame_ms": round(frame_ms, 3), "slowest_rank_hoist_plus_shard_ms": round(max(busy), 3),
+                "fastest_rank_hoist_plus_shard_ms": round(min(busy), 3),
+                "hoist_ms_max": max(i["hoist_ms"]["median"] for i in infos), "shard_ms_max": max(i["shard_ms"]["median"] for i in infos),
+                "shard_ms_min": min(i["shard_ms"]["median"] for i in infos), "gather_ms_rank0": infos[0]["gather_ms"]["median"],
+                "gather_ms_max": max(i["gather_ms"]["median"] for i in infos),
+                "scaling_efficiency_vs_emulated": round(max(busy) / frame_ms, 4),
+                "note": "per rank and timed frame, HIP events on the launch stream: hoist = per-frame scene preparation (replicated), shard = "
+                        "ray generation + sampler + field + compositor of the rank's ray range, gather = the tile gather (RCCL: event "
+                        "behind the collective; gloo: host clock around the staged gather, behind a stream synchronisation); "
+                        "scaling_efficiency_vs_emulated = slowest rank's (hoist + shard) / measured frame time: 1.0 = the frame costs what "
+                        "its slowest shard costs, the remainder is gather + barrier + launch gaps"}
 
     # ---- the other arithmetic modes ------------------------------------------------------------------------------------------
     modes = {}
-    if not args.no_modes:
+    if not args.no_modes and (world == 1 or args.modes_multi):
         for m in (ops.PRECISION_FP32, ops.PRECISION_F16X3, ops.PRECISION_F16):
             if m == head:
                 continue

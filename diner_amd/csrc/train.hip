@@ -664,6 +664,16 @@ __global__ void k_view_mean(const float* __restrict__ x, int nv, long long PC, f
     y[i] = s / (float)nv;
   }
 }
+// atomic maximum of the bit patterns of |x[0 .. n)| into *out: the scale slot of a dy tensor whose producer was not one of the kernels that
+// keep the maximum themselves (the general GEMM behind a product with fewer than 256 rows or odd alignment; ADVICE r4: those slots used
+// to stay 0 and the f16x3 consumers staged small gradients unscaled)
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 // amax_in / amax_out (or null): the maximum of |dx| is that of |dy| / nv (thread 0 writes it)
 __global__ void k_view_bcast(const float* __restrict__ dy, int nv, long long PC, float* __restrict__ dx, const unsigned* __restrict__ amax_in,
                              unsigned* __restrict__ amax_out) {
@@ -1126,6 +1136,10 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   static const long long cap = [] { const char* e = getenv("DINER_TRAIN_WGRAD_CAP"); return e ? atoll(e) : 64LL; }();
   long long split = M / rows_per_chunk;
   split = split < 1 ? 1 : (split > cap ? cap : split);
+  // a dx produced by the general GEMM keeps no maximum of its own: one pass over it fills the slot the f16x3 consumers scale by
+  auto dx_amax = [&]() {
+    if (f16 && f16->amax_dx && dx) hipLaunchKernelGGL(k_absmax, dim3(grid1d(M * (long long)K)), dim3(256), 0, st, dx, M * (long long)K, f16->amax_dx);
+  };
   if (N == 512 && K == 512 && M >= 256 && use_wgrad512() && (ldy & 1) == 0 && (ldx & 3) == 0 &&
       (reinterpret_cast<size_t>(dy) & 7) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 &&
       (reinterpret_cast<size_t>(dW) & 15) == 0 && (reinterpret_cast<size_t>(db) & 15) == 0) {      // (the summing pass stores dW / db as 16-byte vectors)
@@ -1160,7 +1174,11 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
                               dgrad512 && one_launch ? &da : nullptr);
     if (rcw) return rcw;
     if (dgrad512) return one_launch ? 0 : lin512_launch(da, st);
-    if (dx) return gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
+    if (dx) {
+      int rcd = gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
+      if (rcd) return rcd;
+      dx_amax();
+    }
     return 0;
   }
   DINER_HIP_OK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
@@ -1181,9 +1199,13 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   if (dx && Wt_packed && N == 512 && K == 512 && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask)) {
     // dx = dy W on the feature-sliced kernel (train_lin512.hip): D[k][row] = sum_f W[f][k] dy[row][f], W packed transposed
     Lin512Args a{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+    if (f16) a.amax_out = f16->amax_dx;            // (fewer than 256 rows or an odd alignment: bf16x6 here, the consumers may still run f16x3)
     return lin512_launch(a, st);
   }
-  if (dx) rc = gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
+  if (dx) {
+    rc = gemm_launch(dy, W, dx, M, K, N, ldy, K, K, dx_accum ? kAccum : 0, nullptr, dx_mask, 1, st);
+    if (!rc) dx_amax();
+  }
   return rc;
 }
 }  // namespace
@@ -1354,10 +1376,11 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
     hipLaunchKernelGGL(k_lin_out_bwd, dim3(grid1d(P, 4, 256)), dim3(256), 0, st, ws + w.x_last, ws + w.raw, d_out, p->lin_out_w, P, dx,
                        (float*)grads->lin_out_w, (float*)grads->lin_out_b, bwd16 ? amax + 0 : nullptr);
   } else {
-    DINER_CHECK_ARG(!bwd16, "field_train_backward: lin_out off its skinny kernel with the f16x3 backward (set DINER_TRAIN_BWD_F16X3=0)");
     hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, ws + w.d_raw);
     if ((rc = linear_bwd(ws + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
                          (float*)grads->lin_out_b, P, 4, kHidden, dx, ws + w.x_last, false, st))) return rc;
+    // (lin_out off its skinny kernel -- a weight or d_out that is not 16-byte aligned: the general path keeps no maximum of dx)
+    if (bwd16) hipLaunchKernelGGL(k_absmax, dim3(grid1d(P * (long long)kHidden)), dim3(256), 0, st, dx, P * (long long)kHidden, amax + 0);
   }
   for (int b = 4; b >= 0; --b) {
     const long long M = b < 3 ? cols : P;

@@ -34,6 +34,16 @@ def test_bench_launches_its_own_ranks(n):
     assert d["world_size"] == n and len(d["ranks"]) == n and sorted(r["rank"] for r in d["ranks"]) == list(range(n))
     assert d["launcher"] == "bench.py self-launch"
     assert len({r["pid"] for r in d["ranks"]}) == n                       # N processes
+    # round 5: the line explains itself -- per rank the replicated hoist, the shard and the gather of the timed frames (min / median / max)
+    for r in d["ranks"]:
+        assert r["frames"] == 2 and r["rays"] == 800 * 600 // n
+        for key in ("hoist_ms", "shard_ms", "gather_ms"):
+            assert 0 < r[key]["min"] <= r[key]["median"] <= r[key]["max"]
+    b = d["breakdown"]
+    assert b["frame_ms"] == pytest.approx(line["ms_per_step"], rel=1e-3)
+    assert 0 < b["scaling_efficiency_vs_emulated"] <= 1.25 and b["shard_ms_min"] <= b["shard_ms_max"]
+    assert b["slowest_rank_hoist_plus_shard_ms"] <= b["frame_ms"] * 1.25       # (medians of 2 frames of ranks that time-slice one GPU)
+    assert line["modes"] == {}                                            # off by default for N > 1 (a scaling run needs the headline only)
     fc = line["frame_check"]
     assert fc["bit_equal"] is True and fc["sha256_sharded"] == fc["sha256_single_rank"] and fc["max_abs_diff"] == 0.0
     import torch

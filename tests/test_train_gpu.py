@@ -143,6 +143,37 @@ def test_field_forward_and_backward_against_oracle_autograd(ops, P):
         assert max_norm_rel(b.cpu(), 2 * a.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("scale", [1e-6, 1e-9])
+def test_small_batch_backward_with_small_upstream_gradients(ops, scale):
+    """with P < 256 the post-mean layers (M = P rows) leave the 512 x 512 kernels, and until round 5 the general-GEMM
+    fall-back wrote no maximum of its dx, so blocks 2..0 (M = P nv >= 256, f16x3) staged their dy operand UNSCALED -- harmless for the O(1)
+    upstream gradients of the test above, but loss gradients of 1e-6 .. 1e-9 lost most of their bits in two fp16 planes.  The backward is
+    linear in the upstream gradient: the gradients for G x scale must be scale x the gradients for G (pinned against the oracle's autograd
+    by test_field_forward_and_backward_against_oracle_autograd[200]) to fp32 round-off."""
+    from diner_amd import train
+    from tests.tests_train_util import module_param_list
+    P = 200
+    g = load("g6_pixelnerf.npz")
+    sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
+    xyz, dirs = T(g["pts"])[:P], T(g["dirs"])[:P]
+    G = torch.randn(P, 4, generator=torch.Generator().manual_seed(3))
+    hs = ops.HipScene(sc["latent"].detach().cuda(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(),
+                      sc["src_extrinsics"], sc["src_intrinsics"][:, [0, 1], [0, 1]], sc["src_intrinsics"][:, :2, -1],
+                      sc["image_shape"], sc["feature_padding"])
+    grads = {}
+    for s in (1.0, scale):
+        latent = sc["latent"].detach().cuda().requires_grad_(True)
+        params, names = module_param_list(msd)
+        out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
+        (out * (G * s).cuda()).sum().backward()
+        grads[s] = [p.grad.cpu() for p in params] + [latent.grad.cpu()]
+    out_o, dlat_o, gr_o = _oracle_grads(scene, w, xyz, dirs, G * scale)
+    worst = max(max_norm_rel(b / scale, a) for a, b in zip(grads[1.0], grads[scale]))
+    worst_o = max([max_norm_rel(b, gr_o[(k, i)]) for b, (k, i) in zip(grads[scale], names)] + [max_norm_rel(grads[scale][-1], dlat_o)])
+    print(f"upstream gradients x {scale:g}: HIP gradients against {scale:g} x the O(1) run {worst:.2e}, against the oracle's autograd {worst_o:.2e}")
+    assert worst < 2e-5 and worst_o < TOL_GRAD
+
+
 def test_composite_backward_against_oracle_autograd(ops):
     from diner_amd import train
     g = torch.Generator().manual_seed(11)
