@@ -176,6 +176,7 @@ struct QueueMap {
 struct Args {
   FieldArgs fa;
   const _Float16* w;       // n-split packed weights: lin_in, then per block b<3: fc_0, fc_1
+  const _Float16* w8;      // the same seven layers in the 8-wave kernel's order (k_field_pre_h8; hi plane only), or null
   const float* b;          // biases x16: lin_in, then per block: fc_0, fc_1  (7 x 512)
   unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
   unsigned* tile_counter;     // 8 counters (one per XCD queue), zeroed per launch: see TileQueue
@@ -1055,6 +1056,429 @@ __global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) {
   pf.end(a.prof, lane);
 }
 
+// =====================================================================================================================================
+// Round 5: the plain-fp16 per-view kernel with EIGHT waves per workgroup (two per SIMD): k_field_pre_h8.
+//
+// What the GEMM-chain micro-benchmark showed (tools/ubench/chain_f16.hip, profiles/r05_chain_f16_ubench.txt): with ONE wave per SIMD a clean
+// 512-wide GEMM of the 64-column body takes 10.0-10.2 k clocks for 8.2 k clocks of MFMAs, and a 128-column body (half the weight bytes per
+// column) takes 2 x 10.6-10.8 k -- the weight stream is NOT what bounds a plain-fp16 GEMM; one wave cannot issue v_mfma_f32_16x16x32_f16
+// back to back (18-20 clocks apiece, tools/ubench/mfma_dep.hip).  The same 64 columns on eight waves of 64 features each -- two waves per
+// SIMD whose MFMAs interleave -- run the GEMM in 8.35 k clocks (0.98 of the matrix pipe), and everything one wave does between MFMAs
+// (operand conversion, tap blends, waiting for a load) is covered by the other wave's MFMAs instead of by hand-placed side tasks.
+//   * wave w (0..7) owns features [64 w, 64 w + 64) of all 64 columns (4 views x 16 points): 4 row tiles x 4 column groups = 16 accumulators
+//     (64 registers) for the residual stream, 16 for the hidden activation; 256 registers per wave
+//   * weights [wave 8][k32 block][row tile 4][lane 64][8 halfs] (hi plane only), global -> VGPR through a register ring as before;
+//     a fragment feeds 4 MFMAs (one per column group) -- the weight bytes per column are those of the 4-wave kernel
+//   * B operands: one 64 KB LDS buffer [k32 16][g 4][lane 64] x 8 halfs; barrier, publish, barrier per layer (the own-chunk scheme of the
+//     4-wave kernel is not needed to hide the conversion: the SIMD's other wave is multiplying)
+//   * front end: wave w serves view w & 3 and computes the 8 inputs of k32 block w >> 2 per lane
+//   * taps: the fp16 copy of the projected maps in the same channel order (a wave pair = one wave of the 4-wave kernel), 8 units (g, mp) per wave
+//   * the hand-over to the post kernel is unchanged (row tile 4 w + mo)
+namespace w8 {
+constexpr int kS8 = 4;                                    // row tiles per wave
+constexpr int kB8Bytes = 16 * kGroups * 1024;             // 64 KB
+constexpr size_t kFeatSrcBytes8 = 512 * kSrcStride * 4;
+constexpr size_t kLdsBytes8 = (size_t)2 * kB8Bytes + kTapsBytes + kFeatTabBytes + kFeatSrcBytes8;      // two B buffers (see the kernel)
+static_assert(kLdsBytes8 <= 160 * 1024, "LDS of one CU");
+constexpr size_t kLinInHalfs8 = (size_t)8 * 2 * 4 * 512, kLayerHalfs8 = (size_t)8 * 16 * 4 * 512;
+#ifndef DINER_H8_RING
+#define DINER_H8_RING 3
+#endif
+#ifndef DINER_H8_RING0            // ... of the GEMMs without a side task (no tap buffers live)
+#define DINER_H8_RING0 4
+#endif
+#ifndef DINER_H8_GDEPTH          // units between a tap request and its blend: as a GEMM side task / stand-alone (block 0)
+#define DINER_H8_GDEPTH 1
+#endif
+#ifndef DINER_H8_G0DEPTH
+#define DINER_H8_G0DEPTH 4
+#endif
+#ifndef DINER_H8_TAPS_A          // 1: the tap buffers of the side task in AGPRs
+#define DINER_H8_TAPS_A 0
+#endif
+
+__device__ __forceinline__ lds_h8 bfrag8(lds_ptr base, int t, int g) { return (lds_h8)(base + (t * kGroups + g) * 1024); }
+
+// The weight ring of one GEMM: BUFFER loads -- a descriptor over the wave's slice of the layer (scalars), the lane's 16 bytes as the one
+// vector offset of the whole GEMM, the fragment as a constant scalar offset: no vector-ALU instruction per load (the flat form the compiler
+// makes of `scalar base + lane offset + immediate` costs a v_lshl_add_u64 per fragment -- with two waves per SIMD the vector ALU's slots
+// between the MFMAs are what the side tasks live on)
+template <int KT, int R>
+struct ARing8 {
+  h8 a[R][4];
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned avoff;
+  template <int H>
+  __device__ __forceinline__ void load1(h8 (&dst)[4], int i) {      // fragment i of k32 block H
+    dst[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, (H * 4 + i) * 1024, 0));
+  }
+  __device__ __forceinline__ void start(const _Float16* __restrict__ layer, int wave, int lane) {
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(layer) + (size_t)wave * KT * 4096), 0, KT * 4096, 0x00020000);
+    avoff = lane * 16;
+    static_for<(R - 1 < KT ? R - 1 : KT)>([&](auto H) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load1<decltype(H)::value>(a[decltype(H)::value], i);
+    });
+  }
+};
+
+struct NoSide8 {
+  template <int T, int G>
+  __device__ __forceinline__ void run() {}
+  __device__ __forceinline__ void finish() {}
+};
+
+// acc[mo][g] += W[64 w + 16 mo ..][k] . B[k][16 g ..]: 16 MFMAs per k32 block (one weight fragment per row tile, one B fragment per
+// column group); the fragments of block t + R - 1 are requested one per quarter-step, B fragment g of block t + 1 is re-read right
+// after its last use for block t
+// ACC_A: the accumulator block lives in the AGPR half of the file (the residual stream xs); false: in arch VGPRs (the hidden block ns, dead
+// while the gather-carrying GEMM runs -- with both blocks pinned to AGPRs the arch half is 128 registers and the ring + taps spill)
+template <int KT, int R, bool ACC_A, class Side>
+__device__ __forceinline__ void gemm8(const _Float16* __restrict__ layer, lds_ptr Bb, int wave, int lane, f32x4 (&acc)[kS8][kGroups], Side& side) {
+  ARing8<KT, R> ring;
+  ring.start(layer, wave, lane);
+  asm volatile("" : "+v"(Bb));
+  h8 bb[kGroups];
+#pragma unroll
+  for (int g = 0; g < kGroups; ++g) bb[g] = *bfrag8(Bb, 0, g);
+  static_for<KT * kGroups>([&](auto Q) {
+    constexpr int qi = decltype(Q)::value;
+    constexpr int t = qi >> 2, g = qi & 3;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (t + R - 1 < KT) ring.template load1<(t + R - 1 < KT ? t + R - 1 : 0)>(ring.a[(t + R - 1) % R], g);
+    if constexpr (g > 0 && t + 1 < KT) bb[g - 1] = *bfrag8(Bb, t + 1, g - 1);
+    if constexpr (g == 0 && t > 0) bb[kGroups - 1] = *bfrag8(Bb, t, kGroups - 1);
+    side.template run<t, g>();
+    h8 (&ac)[4] = ring.a[t % R];
+    const h8 b0 = bb[g];
+#pragma unroll
+    for (int m = 0; m < kS8; ++m) DINER_HN_MFMA(acc[m][g], ac[m], b0);
+#pragma unroll
+    for (int m = 0; m < kS8; ++m) {
+      if constexpr (ACC_A) asm volatile("" : "+a"(acc[m][g]));
+      else asm volatile("" : "+v"(acc[m][g]));
+    }
+  });
+  side.finish();
+}
+
+// two row tiles' values of one column group (rows 4q .. 4q+3 each) -> one B fragment: relu on the bit pattern, x 1/16, round to fp16
+template <bool ACC_A>
+__device__ __forceinline__ u32x4 cvt_frag8(const f32x4& x0, const f32x4& x1) {
+  u32x4 h;
+  if constexpr (ACC_A) {
+    u32x4 l;
+    cvt4<false, 0>(x0, kInvScale, h, l);
+    cvt4<false, 1>(x1, kInvScale, h, l);
+  } else {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = mul1s(__int_as_float(max(__float_as_int(x0[i]), 0)), kInvScale);
+      v[4 + i] = mul1s(__int_as_float(max(__float_as_int(x1[i]), 0)), kInvScale);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = cvt_pk_f16(v[2 * i], v[2 * i + 1]);
+  }
+  return h;
+}
+
+// relu(acc) / 16 -> fp16 B operands of this wave's two k32 blocks (2 w, 2 w + 1), all four column groups
+template <bool ACC_A>
+__device__ __forceinline__ void publish8(lds_ptr Bb, int wave, const f32x4 (&acc)[kS8][kGroups]) {
+  lds_ptr mine = Bb + wave * (2 * kGroups * 1024);
+  asm volatile("" : "+v"(mine));
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      *bfrag8(mine, tl, g) = __builtin_bit_cast(h8, cvt_frag8<ACC_A>(acc[2 * tl][g], acc[2 * tl + 1][g]));
+    }
+}
+
+__device__ __forceinline__ void set_bias8(f32x4 (&acc)[kS8][kGroups], const float* __restrict__ bias, int wave, int q) {
+#pragma unroll
+  for (int mo = 0; mo < kS8; ++mo) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 64 * wave + 16 * mo + 4 * q);
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) acc[mo][g] = bv;
+  }
+}
+__device__ __forceinline__ void pin_acc8(f32x4 (&acc)[kS8][kGroups]) {
+#pragma unroll
+  for (int mo = 0; mo < kS8; ++mo)
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) asm volatile("" : "+a"(acc[mo][g]));
+}
+
+// xs[mo][g] += 16 * interp(projected map) from the fp16 maps (see GatherSideH): 8 units U = (g, mp) of 4 taps; ONE 16-byte load per lane and
+// tap carries the lane's four rows of the wave's row tiles 2 mp and 2 mp + 1.  Steps T (the k32 blocks of the GEMM this rides on, or the
+// steps of the stand-alone loop) of four quarters G: unit U is requested during step 2 U (tap G in quarter G) and blended D units
+// later, row tile 2 mp during step 2 (U + D), row tile 2 mp + 1 during the next one.  A column's tap rows (`off4`, needed when group g's
+// units are requested: steps 4 g, 4 g + 2) and blend weights (`w4`, needed from step 4 g + 2 D on) are read from LDS one step ahead of
+// their first use into ONE slot each (the previous group's last use lies behind by then).
+template <int D>
+struct Gather8 {
+  static constexpr int kSteps = 2 * (8 + D);             // steps until the last unit is blended
+  const char* __restrict__ tz;
+  const TapRec* __restrict__ taps_lds;
+  int pt;
+  unsigned lane_off;
+  f32x4 (&xs)[kS8][kGroups];
+  u32x4 r[D + 1][4];
+  u32x4 off4;
+  f32x4 w4, bw, bv;
+  __device__ __forceinline__ Gather8(const void* tz_, const TapRec* taps_lds_, int wave, int q, int pt_, f32x4 (&xs_)[kS8][kGroups])
+      : tz(reinterpret_cast<const char*>(tz_)), taps_lds(taps_lds_), pt(pt_),
+        lane_off((unsigned)((wave >> 1) * 256 + (wave & 1) * 128 + q * 16)), xs(xs_) {
+    off4 = *reinterpret_cast<const u32x4*>(taps_lds[pt].off);
+  }
+  template <int U, int KTAP>
+  __device__ __forceinline__ void issue_tap() {
+    constexpr int mp = U & 1;
+#ifdef DINER_H8_G_NOLOAD        // ablation: the side task without its loads
+    asm volatile("" : "+v"(r[U % (D + 1)][KTAP]));
+#else
+#ifdef DINER_H8_TAPS_SAME       // ablation: every tap from texel row 0..3 (always cached): prices the taps' latency
+    r[U % (D + 1)][KTAP] = *reinterpret_cast<const u32x4*>(tz + ((off4[KTAP] & 3u) * 1024u + lane_off) + mp * 64);
+#else
+    r[U % (D + 1)][KTAP] = *reinterpret_cast<const u32x4*>(tz + (off4[KTAP] * 1024u + lane_off) + mp * 64);
+#endif
+#if DINER_H8_TAPS_A
+    // the tap lands in the AGPR half of the file (the hidden block's 64 registers are dead while this GEMM runs; the arch half holds the
+    // weight ring and the B fragments): read back one dword at a time where it is blended
+    asm volatile("" : "+a"(r[U % (D + 1)][KTAP]));
+#endif
+#endif
+  }
+  template <int U, int HF, int K>
+  __device__ __forceinline__ void blend_step() {
+    constexpr int g = U >> 1, mo = 2 * (U & 1) + HF;
+#if DINER_H8_TAPS_A
+    u32x4 t;
+    {
+      const u32x4& ta = r[U % (D + 1)][K];
+      int t0, t1;
+      asm("v_accvgpr_read_b32 %0, %1" : "=v"(t0) : "a"(ta[2 * HF]));
+      asm("v_accvgpr_read_b32 %0, %1" : "=v"(t1) : "a"(ta[2 * HF + 1]));
+      t[2 * HF] = (unsigned)t0;
+      t[2 * HF + 1] = (unsigned)t1;
+    }
+#else
+    const u32x4& t = r[U % (D + 1)][K];
+#endif
+#ifdef DINER_H8_NO_BLEND        // ablation: the loads without the arithmetic
+    asm volatile("" :: "v"(t[2 * HF]), "v"(t[2 * HF + 1]));
+    return;
+#endif
+    if constexpr (K == 0) {
+      bw = w4;
+      asm volatile("" : "+v"(bw));           // (see GatherSide::blend_step)
+      bv = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    bv[0] = GatherSideH<1>::mix_lo(t[2 * HF], bw[K], bv[0]);
+    bv[1] = GatherSideH<1>::mix_hi(t[2 * HF], bw[K], bv[1]);
+    bv[2] = GatherSideH<1>::mix_lo(t[2 * HF + 1], bw[K], bv[2]);
+    bv[3] = GatherSideH<1>::mix_hi(t[2 * HF + 1], bw[K], bv[3]);
+    if constexpr (K == 3) {
+#ifdef DINER_H8_NO_ACCUM        // ablation: the blend without the accumulator update
+      asm volatile("" :: "v"(bv));
+      return;
+#endif
+      asm volatile("" : "+a"(xs[mo][g]));      // keep the accumulator file assignment: read, add, write back
+      f32x4 acc = xs[mo][g];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = add1(acc[i], bv[i]);
+      xs[mo][g] = acc;
+      asm volatile("" : "+a"(xs[mo][g]));
+    }
+  }
+  template <int T, int G>
+  __device__ __forceinline__ void run() {
+    constexpr int U = T >> 1, V = U - D;
+    if constexpr (V >= 0 && V < 8) blend_step<(V >= 0 && V < 8 ? V : 0), (T & 1), G>();
+    if constexpr ((T & 1) == 0 && U < 8) issue_tap<(U < 8 ? U : 0), G>();
+    if constexpr (G == 1) {
+      // tap rows of group (T + 1) / 4, whose first unit is requested in step T + 1 (this step, 4 g' - 1, is odd: it requests nothing)
+      if constexpr ((T & 3) == 3 && (T + 1) / 4 < kGroups) off4 = *reinterpret_cast<const u32x4*>(taps_lds[((T + 1) / 4) * 16 + pt].off);
+      // blend weights of group gw, first used in step 4 gw + 2 D = T + 1 (the previous group's weights were copied in quarter 0 of this step)
+      if constexpr (T + 1 >= 2 * D && ((T + 1 - 2 * D) & 3) == 0 && (T + 1 - 2 * D) / 4 < kGroups)
+        w4 = *reinterpret_cast<const f32x4*>(taps_lds[((T + 1 - 2 * D) / 4) * 16 + pt].w) * kScale;
+    }
+  }
+  // behind a 16-block GEMM: the steps that are left
+  __device__ __forceinline__ void finish() {
+    static_for<(kSteps > 16 ? kSteps - 16 : 0)>([&](auto I) {
+      constexpr int T = 16 + decltype(I)::value;
+      run<T, 0>(); run<T, 1>(); run<T, 2>(); run<T, 3>();
+    });
+  }
+  __device__ __forceinline__ void all() {              // stand-alone (block 0: no GEMM long enough in front of it)
+    static_for<kSteps>([&](auto I) {
+      constexpr int T = decltype(I)::value;
+      run<T, 0>(); run<T, 1>(); run<T, 2>(); run<T, 3>();
+    });
+  }
+};
+
+__global__ __launch_bounds__(512, 1) void k_field_pre_h8(SceneDev sc, Args a) {
+  constexpr int R = DINER_H8_RING, R0 = DINER_H8_RING0;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  h8* B = reinterpret_cast<h8*>(smem);
+  TapRec* taps_lds = reinterpret_cast<TapRec*>(reinterpret_cast<char*>(smem) + (size_t)2 * kB8Bytes);
+  FeatRec* feat_tab = reinterpret_cast<FeatRec*>(reinterpret_cast<char*>(taps_lds) + kTapsBytes);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, pt = lane & 15;
+  const int view = wave & 3, tin = wave >> 2;          // front end: this wave's view and which k32 block of the 64 padded inputs it makes
+  float* feat_src = reinterpret_cast<float*>(reinterpret_cast<char*>(feat_tab) + kFeatTabBytes) + wave * 64 * kSrcStride;
+  const FieldArgs& fa = a.fa;
+  if (threadIdx.x < 64) {      // recipe of (q, slot) = (threadIdx.x / 16, threadIdx.x % 16)
+    const int sl = threadIdx.x & 15;
+    feat_tab[threadIdx.x] = feat_recipe(16 * (sl >> 2) + 4 * (threadIdx.x >> 4) + (sl & 3), fa.freq_factor);
+  }
+  const long long n_tiles = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
+  __shared__ unsigned s_tile;
+  TileQueue tq;
+  tq.begin();
+  tq.first(a.tile_counter, n_tiles, a.qmap, &s_tile);
+  __syncthreads();
+  // TWO B buffers: a layer reads one and publishes its result into the other, so a wave converts its slice as soon as its own GEMM is done
+  // -- while slower waves are still multiplying -- and ONE barrier per layer (everybody has published) is left.  A tile runs seven layers:
+  // its last GEMM reads the buffer its lin_in operands were written to, so the next tile starts in the other one.
+  lds_ptr Brd = (lds_ptr)(reinterpret_cast<char*>(B)) + lane * 16, Bwr = Brd + kB8Bytes;
+  const _Float16* w_in = a.w8;
+  const _Float16* w_blk = a.w8 + kLinInHalfs8;
+  const _Float16* tz16 = reinterpret_cast<const _Float16*>(fa.tz16);
+
+  Prof pf;
+  pf.begin();
+  for (long long tile = tq.initial(&s_tile); tile < n_tiles; tile = tq.next(tile, &s_tile)) {
+    tq.request(a.tile_counter, n_tiles, a.qmap);
+    long long p = tile * kPtsPerWave + pt;
+    if (p >= fa.P) p = fa.P - 1;
+    MapDims dims{sc.Wf, sc.Hf, sc.Ws, sc.Hs};
+    asm volatile("" : "+s"(dims.Wf), "+s"(dims.Hf), "+s"(dims.Ws), "+s"(dims.Hs));
+    h8 fin;                                       // this lane's 8 inputs of k32 block `tin`, as B operands
+    Taps taps;
+    {
+      float px, py, pz, dx, dy, dz;
+      load_point(fa, p, px, py, pz, dx, dy, dz);
+      float xc[3], vd[3];
+      world_to_cam(sc.R[view], sc.t[view], px, py, pz, xc[0], xc[1], xc[2]);           // pixelnerf.py:91-93
+      vd[0] = rot_row(sc.R[view] + 0, dx, dy, dz);                                      // :100
+      vd[1] = rot_row(sc.R[view] + 3, dx, dy, dz);
+      vd[2] = rot_row(sc.R[view] + 6, dx, dy, dz);
+      const float u = project_axis(xc[0], xc[2], sc.focal[view][0], sc.c[view][0], sc.img_w);   // :105-108
+      const float w = project_axis(xc[1], xc[2], sc.focal[view][1], sc.c[view][1], sc.img_h);
+      const int ix = nearest_border(u, dims.Ws), iy = nearest_border(w, dims.Hs);    // nearest depth tap (:114-116)
+      const float dd = __fsub_rn(sc.depth[(size_t)view * dims.Hs * dims.Ws + (size_t)iy * dims.Ws + ix], xc[2]);
+      float* mine = feat_src + lane * kSrcStride;        // read back by this lane only: program order, no barrier
+      mine[0] = xc[0]; mine[1] = xc[1]; mine[2] = xc[2];
+      mine[3] = vd[0]; mine[4] = vd[1]; mine[5] = vd[2];
+      mine[6] = dd;    mine[7] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const FeatRec r = feat_tab[q * 16 + 8 * tin + j];
+        const float x = mine[r.src];
+        const float e = sin_posenc(__fmaf_rn(x, r.freq, r.phase));               // addcmul is fused, positional_encoding.py:46
+        fin[j] = (_Float16)(r.sin ? e : x);
+      }
+      bilinear_taps(dims.Wf, dims.Hf, sc.feature_padding, view, u, w, taps);
+    }
+    pf.mark(0);
+    // (no barrier here: this buffer was last read two layers before the previous tile ended, the taps by its second gather-carrying
+    // GEMM -- every wave has passed at least two barriers since)
+    pf.mark(1);
+    *bfrag8(Brd, tin, view) = fin;
+    if (tin == 0 && q == 0) {
+      TapRec r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        r.off[k] = (unsigned)(taps.off[k] >> 9);          // float offset -> units of 512 floats (one texel row)
+        r.w[k] = taps.w[k];
+      }
+      taps_lds[view * 16 + pt] = r;
+    }
+    pf.mark(2);
+    __syncthreads();
+    pf.mark(3);
+    f32x4 xs[kS8][kGroups], ns[kS8][kGroups];
+    set_bias8(xs, a.b, wave, q);
+    pin_acc8(xs);
+    {
+      NoSide8 none;
+      gemm8<2, 2, true>(w_in, Brd, wave, lane, xs, none);
+      pf.mark(4);
+      Gather8<DINER_H8_G0DEPTH> g0(tz16, taps_lds, wave, q, pt, xs);      // lin_z[0]: nothing long enough to hide under yet
+      g0.all();
+      pf.mark(5);
+    }
+    // one residual block: x += fc_1(relu(fc_0(relu(x)))) (+ the next block's projected taps riding on the fc_1 GEMM).  The hidden block
+    // lives inside the lambda: dead behind its publish, its 64 registers are free while the gather-carrying GEMM runs
+    auto block = [&](int b, auto&& side) {
+      const float* bias = a.b + kHidden * (1 + 2 * b);
+      pf.mark(6);
+      publish8<true>(Bwr, wave, xs);                // (the other buffer: nobody reads it now)
+      pf.mark(7);
+      __syncthreads();                            // everybody has published
+      pf.mark(8);
+      {
+        f32x4 ns[kS8][kGroups];
+        set_bias8(ns, bias, wave, q);
+        NoSide8 none;
+        gemm8<16, R0, true>(w_blk + (size_t)(2 * b) * kLayerHalfs8, Bwr, wave, lane, ns, none);
+        pf.mark(9);
+        pf.mark(10);
+        publish8<true>(Brd, wave, ns);
+        pf.mark(11);
+      }
+      __syncthreads();
+      pf.mark(12);
+      pin_acc8(xs);
+      constexpr int R1 = std::is_same<std::decay_t<decltype(side)>, NoSide8>::value ? R0 : R;
+      gemm8<16, R1, true>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs8, Brd, wave, lane, xs, side);
+      pf.mark(13);
+    };
+#pragma nounroll
+    for (int b = 0; b < 2; ++b) {
+      // the next block's lin_z contribution rides on the fc_1 GEMM (additions into xs commute); this block's fc_1 bias comes with it
+      // (folded into the projected map's bias when the weights are packed, mlp.hip)
+#ifdef DINER_H8_NO_GATHER       // ablation
+      NoSide8 gs;
+#else
+      Gather8<DINER_H8_GDEPTH> gs(tz16 + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
+#endif
+      block(b, gs);
+    }
+    {   // block 2: no gather left (and its fc_1 bias is added by the post kernel)
+      NoSide8 none;
+      block(2, none);
+    }
+    // view mean = mean over the four column groups; hand-over at scale 1 in accumulator layout (row tile 4 w + mo)
+    f32x4* out = reinterpret_cast<f32x4*>(fa.xpre) + (size_t)tile * (kTiles * 64) + lane;
+#pragma unroll
+    for (int mo = 0; mo < kS8; ++mo)
+      out[(4 * wave + mo) * 64] = (((xs[mo][0] + xs[mo][1]) + xs[mo][2]) + xs[mo][3]) * (0.25f * kInvScale);
+    pf.mark(14);
+    { const lds_ptr t = Brd; Brd = Bwr; Bwr = t; }      // the last GEMM read Brd: the next tile's inputs go to the other buffer
+  }
+  pf.end(a.prof, lane);
+}
+
+// layer packing for k_field_pre_h8: [w 8][t KT][mo 4][lane 64][8] = W[64 w + 16 mo + (lane & 15)][32 t + 16 (j >> 2) + 4 (lane >> 4) + (j & 3)] * scale
+__global__ void k_pack_layer_h8(const float* __restrict__ W, int rows, int cols, int KT, float scale, _Float16* __restrict__ dst) {
+  const long long total = (long long)8 * KT * 2048;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63, mo = (i >> 9) & 3;
+    const int wt = (int)(i >> 11), t = wt % KT, w = wt / KT;
+    const int row = 64 * w + 16 * mo + (lane & 15);
+    const int col = 32 * t + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+    dst[i] = (_Float16)((row < rows && col < cols) ? W[(size_t)row * cols + col] * scale : 0.0f);
+  }
+}
+}  // namespace w8
+
 struct PostArgsN {
   PostArgs pa;
   const _Float16* w;        // n-split packed fc_0 / fc_1 of blocks 3, 4 (4 layers of 4 * 16 * 16 KB)
@@ -1351,7 +1775,8 @@ __global__ void k_scale_pad(const float* __restrict__ src, int n, int n_pad, flo
 // (x16) + the lin_out bias at scale 1 (padded to 16).  The caller frees whatever was allocated when this fails.
 int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float** w_lin_out, float** b_pre, float** b_post) {
   using namespace h3n;
-  const size_t halfs = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
+  const size_t halfs4 = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
+  const size_t halfs = halfs4 + w8::kLinInHalfs8 + 6 * w8::kLayerHalfs8;            // + the per-view layers in the 8-wave kernel's order (hi plane)
   DINER_HIP_OK(hipMalloc(w_out, halfs * sizeof(_Float16)));
   DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16) + kLinOutWBytes));      // MFMA fragments + the fp32 pack of the vector-ALU lin_out
   DINER_HIP_OK(hipMalloc(b_pre, 7 * kHidden * sizeof(float)));
@@ -1391,10 +1816,22 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
     hipLaunchKernelGGL(k_pack_layer_h3n, dim3(512), dim3(256), 0, stream, p->fc1_w[b], kHidden, kHidden, 16, kScale, wp);
     wp += (size_t)4 * 16 * 8192;
   }
+  {
+    _Float16* w8p = (_Float16*)*w_out + halfs4;
+    hipLaunchKernelGGL(w8::k_pack_layer_h8, dim3(64), dim3(256), 0, stream, p->lin_in_w, kHidden, kDIn, 2, kScale, w8p);
+    w8p += w8::kLinInHalfs8;
+    for (int b = 0; b < 3; ++b) {
+      hipLaunchKernelGGL(w8::k_pack_layer_h8, dim3(512), dim3(256), 0, stream, p->fc0_w[b], kHidden, kHidden, 16, kScale, w8p);
+      w8p += w8::kLayerHalfs8;
+      hipLaunchKernelGGL(w8::k_pack_layer_h8, dim3(512), dim3(256), 0, stream, p->fc1_w[b], kHidden, kHidden, 16, kScale, w8p);
+      w8p += w8::kLayerHalfs8;
+    }
+  }
   DINER_LAUNCH_OK();
   return 0;
 }
 int h3n_set_attributes() {
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::w8::k_field_pre_h8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h3n::w8::kLdsBytes8));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_pre_h3n<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h3n::kLdsBytes));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_post_h3n<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1408,7 +1845,10 @@ int h3n_set_attributes() {
 // split = true: f16x3 split products (hi and lo parts, three MFMAs per product); false: plain fp16 operands
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
                     unsigned* tile_counter, hipStream_t stream) {
-  h3n::Args a{fa, (const _Float16*)w, b, nullptr, tile_counter,
+  const _Float16* w8p = (const _Float16*)w + ((size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192);
+  // DINER_F16_W8=0: the plain-fp16 mode on the 4-wave kernel (A/B measurement aid)
+  static const bool use_w8 = [] { const char* e = getenv("DINER_F16_W8"); return !(e && *e == '0'); }();
+  h3n::Args a{fa, (const _Float16*)w, w8p, b, nullptr, tile_counter,
               h3n::QueueMap::make((fa.P + kPtsPerWave - 1) / kPtsPerWave, fa.K, fa.rays != nullptr && fa.xyz == nullptr && fa.direct_feat == nullptr)};
 #ifdef DINER_HN_PROF
   static unsigned long long* prof = nullptr;
@@ -1417,6 +1857,7 @@ void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, con
   a.prof = prof;
 #endif
   if (split) hipLaunchKernelGGL(h3n::k_field_pre_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
+  else if (use_w8) hipLaunchKernelGGL(h3n::w8::k_field_pre_h8, dim3(grid), dim3(512), h3n::w8::kLdsBytes8, stream, sc, a);
   else hipLaunchKernelGGL(h3n::k_field_pre_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
 #ifdef DINER_HN_PROF
   unsigned long long h[32];

@@ -68,8 +68,9 @@ constexpr int kLayers = 6, kK = 512, kKT = 16;      // k32 blocks per contractio
 // accumulator values become its B-operand slots, see publish)
 // B buffer in LDS: [t 16][g NG][lane 64] h8; lane (n = lane & 15, q = lane >> 4): column 16 g + n, k slots as above
 
-template <int NW, int RT, int NG, int XM, int R>
+template <int NW, int RT, int NG, int XM, int R, int SV = 0, int SA = 0>
 struct Cfg {
+  static constexpr int sv = SV, sa = SA;      // synthetic side task: SV v_fma_mix_f32 per quarter-step; SA: read-add-write of one accumulator every 4th quarter-step
   static constexpr int nw = NW, rt = RT, ng = NG, xm = XM, ring = R;
   static constexpr int tb = (RT * 16) / 32;                 // k32 blocks a wave publishes (its own features)
   static constexpr int chunk_bytes = 4 * NG * 1024;         // four k32 blocks
@@ -108,6 +109,11 @@ __device__ __forceinline__ void gemm(const _Float16* layer, lds_ptr lbase, int w
   ARing<C> ring;
   ring.start(layer, wave, lane);
   asm volatile("" : "+v"(lbase));
+  float sx[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sx[i] = 0.0f;
+  float sc = __int_as_float(lane), sd = 0.0f;
+  asm volatile("" : "+v"(sc), "+v"(sd));
   h8 bb[NG];
   lds_ptr cbp[4];
   cbp[0] = lbase;
@@ -132,6 +138,19 @@ __device__ __forceinline__ void gemm(const _Float16* layer, lds_ptr lbase, int w
     // B fragment of group g - 1 had its last use for block t in the previous quarter-step: re-read it for block t + 1
     if constexpr (half == HV - 1 && g > 0 && t + 1 < kKT) bb[g - 1] = *bfrag<C>(cbp[(t + 1) >> 2], (t + 1) & 3, g - 1);
     if constexpr (half == 0 && g == 0 && t > 0) bb[NG - 1] = *bfrag<C>(cbp[t >> 2], t & 3, NG - 1);
+    if constexpr (C::sv > 0) {
+#pragma unroll
+      for (int j = 0; j < C::sv; ++j)
+        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(sx[(qi * C::sv + j) & 7]) : "v"(sc), "v"(sd));
+    }
+    if constexpr (C::sa > 0 && (qi & 3) == 3) {
+      constexpr int am = (qi >> 2) % C::rt, ag = ((qi >> 2) / C::rt) % NG;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = acc_read(acc[am][ag], i) + sx[i];
+      acc[am][ag] = v;
+      asm volatile("" : "+a"(acc[am][ag]));
+    }
     h8 (&ac)[4] = ring.a[h % R];
     const h8 b0 = bb[g];
 #pragma unroll
@@ -139,6 +158,10 @@ __device__ __forceinline__ void gemm(const _Float16* layer, lds_ptr lbase, int w
 #pragma unroll
     for (int m = 0; m < 4; ++m) asm volatile("" : "+a"(acc[4 * half + m][g]));
   });
+  if constexpr (C::sv > 0 || C::sa > 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(sx[i]));
+  }
 }
 
 // relu(acc) -> fp16 B operands of this wave's own k32 blocks (tb blocks from t0 = tb wave)
@@ -450,6 +473,12 @@ int main(int argc, char** argv) {
   run<Cfg<4, 8, 8, 1, 3>>("B 4x128", tiles_per_wg, &first, 0);
   run<Cfg<4, 8, 8, 1, 4>>("B 4x128", tiles_per_wg, &first, 0);
   run<Cfg<8, 4, 4, 0, 3>>("C 8x64", 2 * tiles_per_wg, &first, 0);
+  // the same with a synthetic side task per quarter-step (timing only: the outputs of the SA variants differ)
+  { std::vector<float> dummy; run<Cfg<8, 4, 4, 0, 3, 2, 0>>("C +2mix", 2 * tiles_per_wg, &dummy, 0); }
+  { std::vector<float> dummy; run<Cfg<8, 4, 4, 0, 3, 4, 0>>("C +4mix", 2 * tiles_per_wg, &dummy, 0); }
+  { std::vector<float> dummy; run<Cfg<8, 4, 4, 0, 3, 4, 1>>("C +4mix+acc", 2 * tiles_per_wg, &dummy, 0); }
+  { std::vector<float> dummy; run<Cfg<8, 4, 4, 0, 3, 0, 1>>("C +acc", 2 * tiles_per_wg, &dummy, 0); }
+  { std::vector<float> dummy; run<Cfg<4, 8, 4, 0, 3, 4, 1>>("A +4mix+acc", 2 * tiles_per_wg, &dummy, 0); }
   run<Cfg<8, 4, 8, 1, 3>>("D 8x128", tiles_per_wg, &first, 0);
   run<Cfg<4, 8, 6, 2, 3>>("E 4x96", 2 * tiles_per_wg, &first, 0);
 #else

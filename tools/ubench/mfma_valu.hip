@@ -38,6 +38,13 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const float* in, int ite
         if (KIND == 10) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x[(r * NV + j) & 7]) : "v"(c), "v"(d));
         if (KIND == 11) asm volatile("v_pk_fma_f16 %0, %1, %2, %2" : "=v"(x[(r * NV + j) & 7]) : "v"(c), "v"(d));
         if (KIND == 12) asm volatile("v_fma_f64 %0, %1, %2, %2" : "=v"(y[(r * NV + j) & 3]) : "v"(yc), "v"(yd));
+        // round 5: what the fp16-tap blend of the plain-fp16 kernels is made of
+        if (KIND == 13) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(x[(r * NV + j) & 7]) : "v"(c), "v"(d));
+        if (KIND == 14) asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(x[(r * NV + j) & 7]) : "v"(c));
+        if (KIND == 15) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(x[(r * NV + j) & 7]) : "v"(c));
+        if (KIND == 16) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(x[(r * NV + j) & 7]) : "v"(c), "v"(d));
+        if (KIND == 17) asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(x[(r * NV + j) & 7]) : "v"(c));
+        if (KIND == 18) asm volatile("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(x[(r * NV + j) & 7]) : "v"(c), "v"(d));
       }
     }
   }
@@ -74,5 +81,10 @@ int main() {
   run<1, 7>("v_accvgpr_write"); run<2, 7>("v_accvgpr_write"); run<4, 7>("v_accvgpr_write");
   run<2, 8>("v_add_u32"); run<2, 9>("v_mul_f32"); run<2, 10>("v_cvt_pk_f16_f32"); run<2, 11>("v_pk_fma_f16");
   run<1, 12>("v_fma_f64");
+  run<1, 13>("v_fma_mix_f32"); run<2, 13>("v_fma_mix_f32"); run<4, 13>("v_fma_mix_f32");
+  run<1, 14>("v_cvt_f32_f16"); run<2, 14>("v_cvt_f32_f16"); run<4, 14>("v_cvt_f32_f16");
+  run<1, 15>("v_cvt_f32_f16_sdwa"); run<2, 15>("v_cvt_f32_f16_sdwa"); run<4, 15>("v_cvt_f32_f16_sdwa");
+  run<2, 16>("v_fmac_f32"); run<4, 16>("v_fmac_f32");
+  run<2, 17>("v_lshrrev_b32"); run<2, 18>("v_lshl_add_u32");
   return 0;
 }
