@@ -12,7 +12,8 @@ class DinerScene(C.Structure):
                 ("std_pad_scale", C.c_void_p),
                 ("img_w", C.c_float), ("img_h", C.c_float), ("feature_padding", C.c_float),
                 ("nv", C.c_int32), ("C", C.c_int32), ("Hf", C.c_int32), ("Wf", C.c_int32),
-                ("Hs", C.c_int32), ("Ws", C.c_int32), ("proj_stamp", C.c_uint64), ("latent_proj_f16", C.c_void_p)]
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("proj_stamp", C.c_uint64), ("latent_proj_f16", C.c_void_p),
+                ("proj_stamp_f16", C.c_uint64)]
 
 
 class DinerMlpParams(C.Structure):
@@ -86,6 +87,11 @@ SIGNATURES = {
     "diner_field_train_backward_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams),
                                                  C.POINTER(DinerMlpParams), C.c_longlong, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p]),
+    "diner_mlp_generic_workspace_bytes": (C.c_size_t, [C.POINTER(DinerMlpParams), C.c_int, C.c_longlong]),
+    "diner_mlp_generic_forward_f32": (C.c_int, [C.POINTER(DinerMlpParams), C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]),
+    "diner_field_inputs_generic_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "diner_quantize_rgb_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_minmax_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "diner_colormap_u8": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
@@ -94,7 +100,7 @@ SIGNATURES = {
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),
 }
 
-ABI_VERSION = 4          # DINER_ABI_VERSION of include/diner_hip.h
+ABI_VERSION = 5          # DINER_ABI_VERSION of include/diner_hip.h
 _lib = None
 
 

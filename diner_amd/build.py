@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libdiner_hip.so")
-SOURCES = ["api.cpp", "sampler.hip", "composite.hip", "stage_ops.hip", "prep.hip", "train.hip", "train_512.hip", "mlp.hip", "mlp_h3n.hip"]
+SOURCES = ["api.cpp", "sampler.hip", "composite.hip", "stage_ops.hip", "prep.hip", "train.hip", "train_512.hip", "mlp.hip", "mlp_h3n.hip", "generic.hip"]
 # -ffp-contract=off: every fp32 op of the geometry path rounds where the reference's torch ops round;
 # fused multiply-adds are written explicitly (fmaf / MFMA) where they are wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value",

@@ -891,7 +891,7 @@ extern "C" size_t diner_mlp_forward_workspace_bytes(long long B) {
   return xpre_bytes(B, kMaxViews) + kFlagBytes + (size_t)B * kMaxViews * (kLatent + kDInPad + 3 * kLatent) * sizeof(float);
 }
 
-static int check_field_scene(const DinerScene* scene, const DinerMlp* mlp, SceneDev* sd) {
+static int check_field_scene(const DinerScene* scene, const DinerMlp* mlp, SceneDev* sd, int precision) {
   int rc = make_scene_dev(scene, sd);
   if (rc) return rc;
   DINER_CHECK_ARG(scene->proj_stamp == mlp->impl.stamp,
@@ -899,6 +899,10 @@ static int check_field_scene(const DinerScene* scene, const DinerMlp* mlp, Scene
                   "the projected maps carry that handle's lin_z / fc_1 biases -- call diner_scene_prepare_f32 with this handle and "
                   "store diner_mlp_stamp() in scene->proj_stamp", (unsigned long long)scene->proj_stamp,
                   (unsigned long long)mlp->impl.stamp);
+  DINER_CHECK_ARG(precision != DINER_PRECISION_F16 || !scene->latent_proj_f16 || scene->proj_stamp_f16 == mlp->impl.stamp,
+                  "field: scene->latent_proj_f16 was made from maps of another packed-weights handle (proj_stamp_f16 %llu, this handle "
+                  "%llu) -- call diner_scene_prepare_f16 after diner_scene_prepare_f32 and store diner_mlp_stamp() in scene->proj_stamp_f16",
+                  (unsigned long long)scene->proj_stamp_f16, (unsigned long long)mlp->impl.stamp);
   DINER_CHECK_ARG(scene->nv == kMaxViews, "field: the fused kernel is built for NV=%d source views (got %d)", kMaxViews,
                   scene->nv);
   DINER_CHECK_ARG(scene->C == kLatent, "field: latent size %d != %d", scene->C, kLatent);
@@ -915,7 +919,7 @@ extern "C" int diner_field_from_rays_f32(const DinerScene* scene, const DinerMlp
   DINER_CHECK_ARG(scene && mlp && rays && z && field_out && workspace, "field_from_rays: null pointer argument");
   DINER_CHECK_ARG(NR > 0 && K > 0, "field_from_rays: bad sizes NR=%d K=%d", NR, K);
   SceneDev sd;
-  int rc = check_field_scene(scene, mlp, &sd);
+  int rc = check_field_scene(scene, mlp, &sd, precision);
   if (rc) return rc;
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -935,7 +939,7 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
   DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && field_out && workspace, "field_from_points: null pointer argument");
   DINER_CHECK_ARG(P > 0, "field_from_points: P must be positive");
   SceneDev sd;
-  int rc = check_field_scene(scene, mlp, &sd);
+  int rc = check_field_scene(scene, mlp, &sd, precision);
   if (rc) return rc;
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));

@@ -121,6 +121,7 @@ class HipScene:
         s.latent_proj = None
         s.latent_proj_f16 = None
         s.proj_stamp = 0
+        s.proj_stamp_f16 = 0
         self.struct = s
         self.latent_proj = None
         self.latent_proj_f16 = None
@@ -151,6 +152,7 @@ class HipScene:
                     self.latent_proj_f16 = torch.empty(lib.diner_scene_proj_f16_bytes(self.ref) // 2, dtype=torch.float16, device=self.device)
                 _lib.check(lib.diner_scene_prepare_f16(self.ref, _ptr(self.latent_proj_f16), _stream()))
             self.struct.latent_proj_f16 = self.latent_proj_f16.data_ptr()
+            self.struct.proj_stamp_f16 = self.struct.proj_stamp          # ABI v5: the fp16 copy belongs to the maps of this handle
             self._f16_current = True
 
     @property
@@ -219,6 +221,118 @@ class HipMlp:
                 self.handle = None
         except Exception:
             pass
+
+
+def fused_shape(d_in, d_latent, d_hidden, d_out, n_blocks, combine_layer, nv=4, num_freqs=6, include_input=True, beta=0.0):
+    """True for the one ResnetFC / PixelNeRF configuration the fused field kernels are built for (every shipped DINER config,
+    configs/train_dtu.yaml:39-50); anything else takes the generic slow path (GenericMlp)."""
+    return (d_in, d_latent, d_hidden, d_out, n_blocks, combine_layer, nv, int(num_freqs), bool(include_input)) == \
+        (55, 512, 512, 4, 5, 3, 4, 6, True) and not beta > 0
+
+
+class GenericMlp:
+    """ResnetFC parameters for the generic slow path (csrc/generic.hip; ABI v5): ANY configuration the reference's constructor
+    accepts (resnetfc.py:72-127) -- d_hidden, n_blocks, combine_layer, d_in / d_latent / d_out, Softplus for beta > 0 -- chained by
+    the library on the general exact-fp32 MFMA GEMM, one launch per layer.  No packing: the struct points at the parameter tensors
+    (kept alive here)."""
+
+    def __init__(self, sd, prefix="", combine_layer=1000, beta=0.0, num_freqs=6, freq_factor=6.28, include_input=True):
+        g = lambda k: _f32c(sd[prefix + k])
+        n_blocks = len([k for k in sd if k.startswith(prefix + "blocks.") and k.endswith("fc_0.weight")])
+        n_z = len([k for k in sd if k.startswith(prefix + "lin_z.") and k.endswith(".weight")])
+        has_in = prefix + "lin_in.weight" in sd
+        self._keep = {"lin_out_w": g("lin_out.weight"), "lin_out_b": g("lin_out.bias")}
+        if has_in:
+            self._keep.update({"lin_in_w": g("lin_in.weight"), "lin_in_b": g("lin_in.bias")})
+        lists = {"fc0_w": [g(f"blocks.{i}.fc_0.weight") for i in range(n_blocks)],
+                 "fc0_b": [g(f"blocks.{i}.fc_0.bias") for i in range(n_blocks)],
+                 "fc1_w": [g(f"blocks.{i}.fc_1.weight") for i in range(n_blocks)],
+                 "fc1_b": [g(f"blocks.{i}.fc_1.bias") for i in range(n_blocks)],
+                 "lin_z_w": [g(f"lin_z.{i}.weight") for i in range(n_z)],
+                 "lin_z_b": [g(f"lin_z.{i}.bias") for i in range(n_z)]}
+        self._lists = lists
+        for t in list(self._keep.values()) + [t for l in lists.values() for t in l]:
+            _require_hip(t)
+        if any(k.startswith(prefix + "blocks.") and ".shortcut." in k for k in sd):
+            raise NotImplementedError("diner_amd: ResnetBlockFC shortcut layers (size_in != size_out) do not occur in ResnetFC (resnetfc.py:104)")
+        p = _lib.DinerMlpParams()
+        p.d_hidden, p.d_out = self._keep["lin_out_w"].shape[1], self._keep["lin_out_w"].shape[0]
+        p.d_in = self._keep["lin_in_w"].shape[1] if has_in else 0
+        p.d_latent = lists["lin_z_w"][0].shape[1] if n_z else 0
+        p.n_blocks, p.combine_layer = n_blocks, int(min(combine_layer, 2 ** 30))
+        p.num_freqs, p.include_input, p.freq_factor = int(num_freqs), int(bool(include_input)), float(freq_factor)
+        if has_in:
+            p.lin_in_w, p.lin_in_b = self._keep["lin_in_w"].data_ptr(), self._keep["lin_in_b"].data_ptr()
+        p.lin_out_w, p.lin_out_b = self._keep["lin_out_w"].data_ptr(), self._keep["lin_out_b"].data_ptr()
+        self._arrays = {}
+        for name, ts in lists.items():
+            arr = (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
+            self._arrays[name] = arr
+            setattr(p, name, C.cast(arr, C.POINTER(C.c_void_p)))
+        self.params = p
+        self.beta = float(beta)
+        self.device = self._keep["lin_out_w"].device
+        self.d_in, self.d_latent, self.d_out, self.d_hidden = p.d_in, p.d_latent, p.d_out, p.d_hidden
+        self.combines = 0 <= p.combine_layer < p.n_blocks        # views averaged inside the network
+        self.num_freqs, self.include_input, self.freq_factor = int(num_freqs), bool(include_input), float(freq_factor)
+
+    def forward(self, zx):
+        """zx (NV, B, d_latent + d_in) -> (B, d_out) when the views are combined inside the network, else (NV, B, d_out)."""
+        _require_hip(zx)
+        zx = _f32c(zx)
+        NV, B, D = zx.shape
+        if D != self.d_latent + self.d_in:
+            raise ValueError(f"diner_amd: ResnetFC input width {D} != d_latent + d_in = {self.d_latent + self.d_in}")
+        out = torch.empty((B, self.d_out) if self.combines else (NV, B, self.d_out), device=zx.device, dtype=torch.float32)
+        if B == 0:
+            return out
+        with torch.cuda.device(zx.device):
+            ws = _workspace(lib.diner_mlp_generic_workspace_bytes(C.byref(self.params), NV, B), zx.device)
+            _lib.check(lib.diner_mlp_generic_forward_f32(C.byref(self.params), self.beta, _ptr(zx), NV, B, _ptr(out), _ptr(ws), _stream()))
+        return out
+
+
+GENERIC_POINTS_PER_LAUNCH = 1 << 18      # bounds the (NV, P, d_latent + d_in) matrix of the generic path (2.4 GB at NV 4 x 567 floats)
+
+
+def field_generic(scene: HipScene, mlp: GenericMlp, rays=None, z=None, xyz=None, viewdirs=None):
+    """PixelNeRF.forward on the generic slow path: (rays (NR,8), z (NR,K)) or (xyz, viewdirs) (P,3) -> (P,4) [r, g, b, sigma]
+    (sigmoid / relu applied, pixelnerf.py:139-143).  The network must combine its views (combine_layer < n_blocks), as PixelNeRF's does."""
+    if not mlp.combines:
+        raise NotImplementedError("diner_amd: PixelNeRF needs an MLP that combines its views (combine_layer < n_blocks)")
+    per = 2 * mlp.num_freqs + (1 if mlp.include_input else 0)
+    if mlp.d_in != 4 * per + 3 or mlp.d_latent != scene.C or mlp.d_out != 4:
+        raise ValueError(f"diner_amd: MLP d_in {mlp.d_in} / d_latent {mlp.d_latent} / d_out {mlp.d_out} do not match the positional "
+                         f"encoding ({4 * per + 3} inputs), the scene's latent width ({scene.C}) and 4 outputs")
+    if rays is not None:
+        _require_hip(rays, z)
+        rays, z = _f32c(rays), _f32c(z)
+        NR, K = z.shape
+        P, dev = NR * K, rays.device
+    else:
+        _require_hip(xyz, viewdirs)
+        xyz, viewdirs = _f32c(xyz), _f32c(viewdirs)
+        P, K, dev = xyz.shape[0], 1, xyz.device
+    out = torch.empty(P, 4, device=dev, dtype=torch.float32)
+    if P == 0:
+        return out
+    D = mlp.d_latent + mlp.d_in
+    step = GENERIC_POINTS_PER_LAUNCH if rays is None else max(1, GENERIC_POINTS_PER_LAUNCH // K) * K
+    with torch.cuda.device(dev):
+        for p0 in range(0, P, step):
+            p1 = min(P, p0 + step)
+            n = p1 - p0
+            zx = torch.empty(scene.nv, n, D, device=dev, dtype=torch.float32)
+            if rays is not None:
+                r0, r1 = p0 // K, p1 // K
+                _lib.check(lib.diner_field_inputs_generic_f32(scene.ref, _ptr(rays[r0:r1]), _ptr(z[r0:r1]), K, None, None, n, mlp.num_freqs,
+                                                              int(mlp.include_input), mlp.freq_factor, _ptr(zx), _stream()))
+            else:
+                _lib.check(lib.diner_field_inputs_generic_f32(scene.ref, None, None, 0, _ptr(xyz[p0:p1]), _ptr(viewdirs[p0:p1]), n,
+                                                              mlp.num_freqs, int(mlp.include_input), mlp.freq_factor, _ptr(zx), _stream()))
+            raw = mlp.forward(zx)
+            _lib.check(lib.diner_field_act_f32(_ptr(raw), None, n, 4, _ptr(out[p0:p1]), _stream()))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -343,7 +457,11 @@ def composite(field, z, rays, white_bkgd, want_weights=True):
 
 def render(scene: HipScene, mlp: HipMlp, rays, z, white_bkgd, want_weights=False, precision=None):
     """field + composite (NeRFRendererDGS.composite): -> weights | None, rgb, depth."""
-    field = field_from_rays(scene, mlp, rays, z, precision=precision)
+    if isinstance(mlp, GenericMlp):        # a configuration outside the fused kernels: exact fp32, one GEMM launch per layer
+        NR, K = z.shape
+        field = field_generic(scene, mlp, rays=rays, z=z).view(NR, K, 4)
+    else:
+        field = field_from_rays(scene, mlp, rays, z, precision=precision)
     return composite(field, z, rays, white_bkgd, want_weights)
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DINER_ABI_VERSION 4
+#define DINER_ABI_VERSION 5
 
 #define DINER_E_INVALID     (-1)  /* bad argument (null pointer, size, unsupported configuration) */
 #define DINER_E_UNSUPPORTED (-2)  /* configuration outside what the kernels are built for        */
@@ -63,6 +63,10 @@ typedef struct DinerScene {
   const void* latent_proj_f16; /* ABI v4: the same three maps as fp16 (3, NV, Hf, Wf, C), channels in the order the plain-fp16 field
                                kernel consumes them, written by diner_scene_prepare_f16 from latent_proj (same proj_stamp).  Only
                                DINER_PRECISION_F16 reads it (half the gather bytes of that mode); NULL for the other modes */
+  uint64_t proj_stamp_f16;  /* ABI v5: diner_mlp_stamp() of the handle whose latent_proj the fp16 copy was made from (set by the caller after
+                               diner_scene_prepare_f16).  DINER_PRECISION_F16 returns DINER_E_INVALID when it is not the stamp of the handle
+                               it is called with: a caller that re-ran diner_scene_prepare_f32 with new weights but not _prepare_f16 would
+                               otherwise render from stale fp16 maps without an error */
 } DinerScene;
 
 /* ResnetFC parameters as the reference stores them (nn.Linear: weight (out,in), bias (out));
@@ -299,6 +303,26 @@ int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams
  * stream entering lin_out (P x 512), [11] lin_out's raw outputs (P x 4).  The signs of these values are the relu decisions of the
  * forward (resnetfc.py:61-69): tests evaluate the reference's backward conditioned on them.  n >= 12. */
 int diner_field_train_ws_layout(long long P, int nv, long long* float_offsets, int n);
+
+/* ---- ABI v5: generic-shape slow path -------------------------------------------------------------------------------------------
+ * ResnetFC.forward (resnetfc.py:129-159) for ANY configuration the reference's constructor accepts (resnetfc.py:72-127: d_hidden
+ * default 128, any n_blocks / combine_layer / d_in / d_latent / d_out, Softplus for beta > 0; combine_type "average" is the only one
+ * the reference implements, :9-14) and any number of views: the layers chained on the general exact-fp32 MFMA GEMM (diner_gemm_f32 with
+ * its exact flag), one launch per layer, the mean over the views at block `combine_layer`.  The fused field kernels remain the path of
+ * the shipped configuration; this one exists so that "same constructor kwargs" is "same behaviour" (forward only; training through it
+ * is not built).  `p` holds DEVICE pointers to the parameters as nn.Linear stores them; no packing, no handle.
+ *   zx   (nv, B, d_latent + d_in) row-major, the latent part first (resnetfc.py:140-142)
+ *   out  (B, d_out) when 0 <= combine_layer < n_blocks (views averaged inside the network), else (nv, B, d_out)
+ *   workspace: diner_mlp_generic_workspace_bytes(p, nv, B) bytes */
+size_t diner_mlp_generic_workspace_bytes(const DinerMlpParams* p, int nv, long long B);
+int diner_mlp_generic_forward_f32(const DinerMlpParams* p, float beta, const float* zx, int nv, long long B, float* out,
+                                  void* workspace, void* stream);
+/* The matrix PixelNeRF.forward hands to its MLP (pixelnerf.py:84-128) for any positional encoding / latent width / NV <= 4:
+ * zx (nv, P, C + d_in) with d_in = 4 (2 num_freqs + include_input) + 3, rows [latent (bilinear / border) ; poscode(x_c) ; R d ;
+ * poscode(depth_nearest - z_c)].  Point source: (rays (NR,8), z (NR,K), K) with P = NR K, or (xyz, viewdirs) (P,3) with rays == NULL. */
+int diner_field_inputs_generic_f32(const DinerScene* scene, const float* rays, const float* z, int K, const float* xyz,
+                                   const float* viewdirs, long long P, int num_freqs, int include_input, float freq_factor,
+                                   float* zx, void* stream);
 
 /* ---- measurement aid (bench.py): per-kernel durations of the two field kernels ------------------
  * With profiling enabled every field call brackets k_field_pre / k_field_post with HIP events on the

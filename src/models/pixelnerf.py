@@ -76,10 +76,21 @@ class PixelNeRF(torch.nn.Module):
         return hit[1]
 
     def hip_mlp(self):
-        """Packed ResnetFC weights; the handle also carries the positional encoding that feeds the MLP (the field kernels
-        evaluate it in registers)."""
+        """Packed ResnetFC weights (fused kernels) or the generic-path parameter block; either carries the positional encoding that
+        feeds the MLP (the fused field kernels evaluate it in registers)."""
         pc = self.poscode
-        return self.mlp_fine.hip_mlp(num_freqs=pc.num_freqs, freq_factor=pc.freq_factor, include_input=pc.include_input)
+        return self.mlp_fine.hip_mlp(num_freqs=pc.num_freqs, freq_factor=pc.freq_factor, include_input=pc.include_input, nv=self._nv())
+
+    def is_generic(self):
+        """A configuration outside the fused field kernels (another d_hidden / n_blocks / combine_layer / positional encoding / number of
+        views / latent width): rendered on the generic slow path, exact fp32."""
+        pc = self.poscode
+        return not self.mlp_fine.is_fused_shape(self._nv(), pc.num_freqs, pc.include_input)
+
+    def _nv(self):
+        """Source views of the encoded scene (the shipped 4 before any encode)."""
+        nv = getattr(self.encoder, "nviews", None)
+        return int(nv) if nv else 4
 
     def needs_grad(self):
         """True when a call must be differentiable: grad mode and some parameter (or the encoded latent) wants a gradient."""
@@ -87,12 +98,11 @@ class PixelNeRF(torch.nn.Module):
                                             any(p.requires_grad for p in self.mlp_fine.parameters()))
 
     def _check_poscode(self):
-        """num_freqs / include_input fix d_in = 55 (the C ABI rejects anything else with DINER_E_UNSUPPORTED as well);
-        freq_factor is honoured by the kernels.  depthcode shares poscode's configuration (pixelnerf.py:15-16)."""
-        pc = self.poscode
-        if pc.num_freqs != 6 or not pc.include_input:
-            raise NotImplementedError("diner_amd: the fused field kernel is built for poscode num_freqs=6, "
-                                      "include_input=True (every shipped DINER config)")
+        """The fused kernels (and the training path) are built for poscode num_freqs=6, include_input=True (d_in = 55); other encodings
+        run on the generic path (inference only).  depthcode shares poscode's configuration (pixelnerf.py:15-16)."""
+        if self.is_generic() and self.needs_grad():
+            raise NotImplementedError("diner_amd: training is built for the shipped configuration (d_hidden 512, 5 blocks, combine 3, NV 4, "
+                                      "poscode num_freqs=6 / include_input=True); other configurations are inference-only")
 
     def forward(self, xyz, viewdirs):
         """(r, g, b, sigma) at world-space points: xyz (SB,B,3), viewdirs (SB,B,3) -> (SB,B,4) (:55-145)."""
@@ -107,6 +117,7 @@ class PixelNeRF(torch.nn.Module):
             slabs = train.object_slabs(self.encoder.latent)
             return torch.stack([train.field_train(self.hip_scene(sb), xyz[sb], viewdirs[sb], slabs[sb], params,
                                                   self.poscode.freq_factor) for sb in range(SB)])
-        self._check_poscode()
         mlp = self.hip_mlp()
+        if isinstance(mlp, ops.GenericMlp):
+            return torch.stack([ops.field_generic(self.hip_scene(sb), mlp, xyz=xyz[sb], viewdirs=viewdirs[sb]) for sb in range(SB)])
         return torch.stack([ops.field_from_points(self.hip_scene(sb), mlp, xyz[sb], viewdirs[sb]) for sb in range(SB)])

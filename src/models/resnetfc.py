@@ -58,36 +58,49 @@ class ResnetFC(nn.Module):
 
     # ---- packed weights -----------------------------------------------------------------------------------
     def _check_supported(self):
-        if self.beta > 0 or self.combine_type != "average":
-            raise NotImplementedError("diner_amd: the fused MLP implements ReLU activations and average view fusion "
-                                      "(the configuration of every shipped DINER config)")
+        if self.combine_type != "average":      # (the reference's own combine() raises for anything else, resnetfc.py:9-14)
+            raise NotImplementedError("diner_amd: ResnetFC implements average view fusion (the only combine_type of the reference)")
 
-    def hip_mlp(self, num_freqs=6, freq_factor=6.28, include_input=True):
-        """HipMlp handle for the current parameter values (re-packed when any parameter changed).  The keyword arguments
-        describe the positional encoding of the 55 inputs (PixelNeRF passes its own; irrelevant for forward() on an
-        explicit matrix)."""
+    def is_fused_shape(self, nv=4, num_freqs=6, include_input=True):
+        """The one configuration the fused field kernels are built for (every shipped DINER config); anything else runs on the
+        generic slow path (ops.GenericMlp: exact fp32, one GEMM launch per layer)."""
+        return hasattr(self, "lin_in") and ops.fused_shape(self.d_in, self.d_latent, self.d_hidden, self.d_out, self.n_blocks,
+                                                           self.combine_layer, nv, num_freqs, include_input, self.beta)
+
+    def hip_mlp(self, num_freqs=6, freq_factor=6.28, include_input=True, nv=4):
+        """HipMlp handle (fused kernels) or GenericMlp (any other configuration) for the current parameter values, re-made when any
+        parameter changed.  The keyword arguments describe the positional encoding of the inputs (PixelNeRF passes its own;
+        irrelevant for forward() on an explicit matrix) and the number of source views."""
         self._check_supported()
         sd = {k: v for k, v in self.state_dict().items()}
+        fused = self.is_fused_shape(nv, num_freqs, include_input)
         key = (tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items())),
-               int(num_freqs), float(freq_factor), bool(include_input))
+               int(num_freqs), float(freq_factor), bool(include_input), fused)
         if self._hip is None or key != self._hip_key:
-            self._hip = ops.HipMlp(sd, combine_layer=self.combine_layer, d_latent=self.d_latent, num_freqs=num_freqs,
-                                   freq_factor=freq_factor, include_input=include_input)
+            if fused:
+                self._hip = ops.HipMlp(sd, combine_layer=self.combine_layer, d_latent=self.d_latent, num_freqs=num_freqs,
+                                       freq_factor=freq_factor, include_input=include_input)
+            else:
+                self._hip = ops.GenericMlp(sd, combine_layer=self.combine_layer, beta=self.beta, num_freqs=num_freqs,
+                                           freq_factor=freq_factor, include_input=include_input)
             self._hip_key = key
         return self._hip
 
     def forward(self, zx, combine_dim):
         """zx (SB, NV, B, d_latent + d_in) with combine_dim=1 (the reference's only call, pixelnerf.py:131-134),
-        or (NV, B, d_latent + d_in) with combine_dim=0  ->  (SB, B, d_out) / (B, d_out)."""
+        or (NV, B, d_latent + d_in) with combine_dim=0  ->  (SB, B, d_out) / (B, d_out); without a combine layer inside the network
+        (combine_layer >= n_blocks, the constructor's default) the views stay: (SB, NV, B, d_out) / (NV, B, d_out)  (resnetfc.py:129-159)."""
         assert zx.size(-1) == self.d_latent + self.d_in
         if torch.is_grad_enabled() and (zx.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("diner_amd: ResnetFC.forward on an explicit matrix is inference-only; the "
                                       "differentiable path is PixelNeRF.forward / NeRFRendererDGS.forward "
                                       "(diner_amd/train.py, DESIGN.md row f1)")
-        mlp = self.hip_mlp()
         if zx.dim() == 4 and combine_dim in (1, -3):
-            return torch.stack([ops.mlp_forward(mlp, zx[i]) for i in range(zx.shape[0])])
+            mlp = self.hip_mlp(nv=zx.shape[1])
+            run = mlp.forward if isinstance(mlp, ops.GenericMlp) else (lambda m: ops.mlp_forward(mlp, m))
+            return torch.stack([run(zx[i]) for i in range(zx.shape[0])])
         if zx.dim() == 3 and combine_dim in (0, -3):
-            return ops.mlp_forward(mlp, zx)
+            mlp = self.hip_mlp(nv=zx.shape[0])
+            return mlp.forward(zx) if isinstance(mlp, ops.GenericMlp) else ops.mlp_forward(mlp, zx)
         raise NotImplementedError(f"diner_amd: ResnetFC.forward supports (SB,NV,B,C)/combine_dim=1 and "
                                   f"(NV,B,C)/combine_dim=0, got shape {tuple(zx.shape)}, combine_dim={combine_dim}")

@@ -150,3 +150,27 @@ def test_g9_g10_render_at_metric_sample_counts_subset(name, kw):
     assert (~same).sum() <= 1, "sampler + fill must reproduce the reference's z (erf-saturation ties aside)"
     assert max_norm_rel(o["rgb"][same], T(g["rgb"])[sub][same]) < 1e-4
     assert max_norm_rel(o["depth"][same], T(g["depth"])[sub][same]) < 1e-4
+
+
+def test_oracle_generalises_to_other_mlp_shapes():
+    """G19 (oracle/make_golden_generic.py): the reference's ResnetFC in configurations outside the fused kernels -- the constructor defaults
+    (no view fusion inside the network) and d_hidden 128 / 3 blocks / combine 2 / NV 3 -- and its PixelNeRF with another positional encoding,
+    latent width and THREE views: the oracle's restatement covers them (relu configurations), so the generic HIP path has a CPU checker too."""
+    from oracle.make_golden_generic import MLP_CASES, PIX, mlp_state_dict, mlp_inputs, pix_scene
+    from tests.helpers import sha
+    g = load("g19_generic.npz")
+    for name in ("A", "B"):
+        kw, nv, SB, B, seed = MLP_CASES[name]
+        zx = mlp_inputs(kw, nv, SB, B, seed)
+        assert sha(zx) == str(g[f"mlp{name}_in_sha"])
+        w = O.MLPWeights.from_state_dict(mlp_state_dict(kw, seed), combine_layer=kw.get("combine_layer", 1000), d_latent=kw["d_latent"])
+        got = torch.stack([O.mlp_forward(w, zx[i]) for i in range(SB)])
+        assert torch.equal(got, torch.from_numpy(g[f"mlp{name}_out"])), name
+    sc, msd, rays, nz, xyz, dirs = pix_scene(g["pix_rays"])
+    Kin = sc["src_intrinsics"]
+    scene = O.Scene(latent=sc["latent"], depths=sc["depths"], depths_std=sc["depths_std"], normals=sc["normals"], poses=sc["src_extrinsics"],
+                    focal=Kin[:, [0, 1], [0, 1]], c=Kin[:, :2, -1], image_shape=sc["image_shape"], feature_padding=sc["feature_padding"])
+    w = O.MLPWeights.from_state_dict(msd, combine_layer=PIX["mlp"]["combine_layer"], d_latent=PIX["latent_ch"])
+    raw = O.mlp_forward(w, O.mlp_input(scene, xyz, dirs, PIX["num_freqs"], PIX["freq_factor"]))
+    f = torch.cat([torch.sigmoid(raw[..., :3]), torch.relu(raw[..., 3:4])], dim=-1)
+    assert torch.equal(f, torch.from_numpy(g["pix_field"]))
