@@ -177,6 +177,7 @@ struct Args {
   FieldArgs fa;
   const _Float16* w;       // n-split packed weights: lin_in, then per block b<3: fc_0, fc_1
   const _Float16* w8;      // the same seven layers in the 8-wave kernel's order (k_field_pre_h8; hi plane only), or null
+  const _Float16* w8x;     // ... with hi and lo planes (k_field_pre_h8x, the f16x3 arithmetic on eight waves), or null
   const float* b;          // biases x16: lin_in, then per block: fc_0, fc_1  (7 x 512)
   unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
   unsigned* tile_counter;     // 8 counters (one per XCD queue), zeroed per launch: see TileQueue
@@ -1466,6 +1467,352 @@ __global__ __launch_bounds__(512, 1) void k_field_pre_h8(SceneDev sc, Args a) {
   pf.end(a.prof, lane);
 }
 
+// -------------------------------------------------------------------------------------------------------------------------------------
+// The same decomposition for the f16x3 arithmetic (hi and lo planes, three MFMAs per product): k_field_pre_h8x.
+//   * weights [wave 8][k32 block][row tile 4][hi | lo][lane 64][8 halfs]: 8 KB per wave and block, two buffer loads per quarter-step,
+//     ring of R blocks (R = 2: a block is 48 MFMAs = 768 clocks of this wave, about twice that of wall time with two waves per SIMD)
+//   * B operands [k32 16][g 4][hi | lo][lane 64]: 128 KB, ONE buffer (two would not fit): barrier, publish, barrier per layer
+//   * taps: fp32 projected maps (the parity-grade mode keeps fp32 taps), 16 units (g, mo) of 4 taps per wave; the tap buffers live in the
+//     AGPR half of the file (the hidden block's 64 registers are dead while the gather-carrying GEMM runs; the arch half holds ring + B)
+constexpr size_t kLinInHalfs8x = (size_t)8 * 2 * 4 * 2 * 512, kLayerHalfs8x = (size_t)8 * 16 * 4 * 2 * 512;
+constexpr size_t kLdsBytes8x = (size_t)2 * kB8Bytes + kTapsBytes + kFeatTabBytes + kFeatSrcBytes8;      // (one B buffer of hi + lo planes)
+#ifndef DINER_H8X_RING
+#define DINER_H8X_RING 2
+#endif
+#ifndef DINER_H8X_GDEPTH
+#define DINER_H8X_GDEPTH 1
+#endif
+#ifndef DINER_H8X_G0DEPTH
+#define DINER_H8X_G0DEPTH 4
+#endif
+#ifndef DINER_H8X_TAPS_A
+#define DINER_H8X_TAPS_A 0
+#endif
+
+__device__ __forceinline__ lds_h8 bfrag8x(lds_ptr base, int t, int g, int hl) { return (lds_h8)(base + ((t * kGroups + g) * 2 + hl) * 1024); }
+
+template <int KT, int R>
+struct ARing8X {
+  h8 a[R][8];                            // [row tile m][hi | lo] = a[.][2 m + hl]
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned avoff;
+  template <int H>
+  __device__ __forceinline__ void load2(h8 (&dst)[8], int pair) {      // fragments 2 pair, 2 pair + 1 (hi, lo of row tile `pair`) of block H
+#pragma unroll
+    for (int i = 2 * pair; i < 2 * pair + 2; ++i)
+      dst[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, (H * 8 + i) * 1024, 0));
+  }
+  __device__ __forceinline__ void start(const _Float16* __restrict__ layer, int wave, int lane) {
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(layer) + (size_t)wave * KT * 8192), 0, KT * 8192, 0x00020000);
+    avoff = lane * 16;
+    static_for<(R - 1 < KT ? R - 1 : KT)>([&](auto H) {
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) load2<decltype(H)::value>(a[decltype(H)::value], pr);
+    });
+  }
+};
+
+// acc[mo][g] += W . B in three products (hi hi, lo hi, hi lo): 48 MFMAs per k32 block
+template <int KT, int R, class Side>
+__device__ __forceinline__ void gemm8x(const _Float16* __restrict__ layer, lds_ptr Bb, int wave, int lane, f32x4 (&acc)[kS8][kGroups], Side& side) {
+  ARing8X<KT, R> ring;
+  ring.start(layer, wave, lane);
+  asm volatile("" : "+v"(Bb));
+  h8 bb[kGroups][2];
+#pragma unroll
+  for (int g = 0; g < kGroups; ++g) {
+    bb[g][0] = *bfrag8x(Bb, 0, g, 0);
+    bb[g][1] = *bfrag8x(Bb, 0, g, 1);
+  }
+  static_for<KT * kGroups>([&](auto Q) {
+    constexpr int qi = decltype(Q)::value;
+    constexpr int t = qi >> 2, g = qi & 3;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (t + R - 1 < KT) ring.template load2<(t + R - 1 < KT ? t + R - 1 : 0)>(ring.a[(t + R - 1) % R], g);
+    if constexpr (g > 0 && t + 1 < KT) {
+      bb[g - 1][0] = *bfrag8x(Bb, t + 1, g - 1, 0);
+      bb[g - 1][1] = *bfrag8x(Bb, t + 1, g - 1, 1);
+    }
+    if constexpr (g == 0 && t > 0) {
+      bb[kGroups - 1][0] = *bfrag8x(Bb, t, kGroups - 1, 0);
+      bb[kGroups - 1][1] = *bfrag8x(Bb, t, kGroups - 1, 1);
+    }
+    side.template run<t, g>();
+    h8 (&ac)[8] = ring.a[t % R];
+    const h8 b0 = bb[g][0], b1 = bb[g][1];
+#pragma unroll
+    for (int m = 0; m < kS8; ++m) DINER_HN_MFMA(acc[m][g], ac[2 * m], b0);
+#pragma unroll
+    for (int m = 0; m < kS8; ++m) DINER_HN_MFMA(acc[m][g], ac[2 * m + 1], b0);
+#pragma unroll
+    for (int m = 0; m < kS8; ++m) DINER_HN_MFMA(acc[m][g], ac[2 * m], b1);
+#pragma unroll
+    for (int m = 0; m < kS8; ++m) asm volatile("" : "+a"(acc[m][g]));
+  });
+  side.finish();
+}
+
+__device__ __forceinline__ void publish8x(lds_ptr Bb, int wave, const f32x4 (&acc)[kS8][kGroups]) {
+  lds_ptr mine = Bb + wave * (2 * kGroups * 2 * 1024);
+  asm volatile("" : "+v"(mine));
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      u32x4 h, l;
+      cvt4<true, 0>(acc[2 * tl][g], kInvScale, h, l);
+      cvt4<true, 1>(acc[2 * tl + 1][g], kInvScale, h, l);
+      *bfrag8x(mine, tl, g, 0) = __builtin_bit_cast(h8, h);
+      *bfrag8x(mine, tl, g, 1) = __builtin_bit_cast(h8, l);
+    }
+}
+
+// xs[mo][g] += 16 * interp(projected map), fp32 maps: 16 units U = (g, mo) of 4 taps (one f32x4 per lane and tap: rows 4q .. 4q+3 of the
+// wave's row tile mo).  Unit U is requested during step U (tap G in quarter G) and blended D units later.  Tap buffers in AGPRs (TA).
+template <int D, bool TA>
+struct Gather8F {
+  static constexpr int kSteps = 16 + D;
+  const float* __restrict__ tz;
+  const TapRec* __restrict__ taps_lds;
+  int pt;
+  unsigned lane_off;
+  f32x4 (&xs)[kS8][kGroups];
+  f32x4 r[D + 1][4];
+  u32x4 off4;
+  f32x4 w4, bw, bv;
+  __device__ __forceinline__ Gather8F(const float* tz_, const TapRec* taps_lds_, int wave, int q, int pt_, f32x4 (&xs_)[kS8][kGroups])
+      : tz(tz_), taps_lds(taps_lds_), pt(pt_), lane_off((unsigned)((16 * wave + q) * 16)), xs(xs_) {
+    off4 = *reinterpret_cast<const u32x4*>(taps_lds[pt].off);
+  }
+  template <int U, int KTAP>
+  __device__ __forceinline__ void issue_tap() {
+    constexpr int mo = U & 3;
+    const char* base = reinterpret_cast<const char*>(tz);
+#ifdef DINER_H8X_G_NOLOAD
+    asm volatile("" : "+v"(r[U % (D + 1)][KTAP]));
+#else
+    r[U % (D + 1)][KTAP] = *reinterpret_cast<const f32x4*>(base + (off4[KTAP] * 2048u + lane_off) + mo * 64);
+#endif
+    if constexpr (TA) asm volatile("" : "+a"(r[U % (D + 1)][KTAP]));
+  }
+  template <int U, int K>
+  __device__ __forceinline__ void blend_step() {
+    constexpr int g = U >> 2, mo = U & 3;
+    f32x4 t;
+    if constexpr (TA) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ti;
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(ti) : "a"(r[U % (D + 1)][K][i]));
+        t[i] = __int_as_float(ti);
+      }
+    } else {
+      t = r[U % (D + 1)][K];
+    }
+#ifdef DINER_H8X_NO_BLEND
+    asm volatile("" :: "v"(t));
+    return;
+#endif
+    if constexpr (K == 0) {
+      bw = w4;
+      asm volatile("" : "+v"(bw));           // (see GatherSide::blend_step)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = K == 0 ? mul1(t[i], bw[0]) : fma1(t[i], bw[K], bv[i]);
+    if constexpr (K == 3) {
+      asm volatile("" : "+a"(xs[mo][g]));
+      f32x4 acc = xs[mo][g];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = add1(acc[i], bv[i]);
+      xs[mo][g] = acc;
+      asm volatile("" : "+a"(xs[mo][g]));
+    }
+  }
+  template <int T, int G>
+  __device__ __forceinline__ void run() {
+    constexpr int V = T - D;
+    if constexpr (V >= 0 && V < 16) blend_step<(V >= 0 && V < 16 ? V : 0), G>();
+    if constexpr (T < 16) issue_tap<(T < 16 ? T : 0), G>();
+    if constexpr (G == 1) {
+      // tap rows of the next group: its first unit is requested in step T + 1 = 4 g'.  This step's requests (quarters 2, 3 still to come) use
+      // the old rows: read into a spare and swap behind quarter 3 -- done by reading in quarter 3 instead (below)
+    }
+    if constexpr (G == 3) {
+      if constexpr ((T & 3) == 3 && (T + 1) / 4 < kGroups) off4 = *reinterpret_cast<const u32x4*>(taps_lds[((T + 1) / 4) * 16 + pt].off);
+    }
+    if constexpr (G == 1) {
+      // blend weights of group gw, first used in step 4 gw + D = T + 1 (this step's blend copied the previous group's in quarter 0)
+      if constexpr (T + 1 >= D && ((T + 1 - D) & 3) == 0 && (T + 1 - D) / 4 < kGroups)
+        w4 = *reinterpret_cast<const f32x4*>(taps_lds[((T + 1 - D) / 4) * 16 + pt].w) * kScale;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    static_for<D>([&](auto I) {
+      constexpr int T = 16 + decltype(I)::value;
+      run<T, 0>(); run<T, 1>(); run<T, 2>(); run<T, 3>();
+    });
+  }
+  __device__ __forceinline__ void all() {
+    static_for<kSteps>([&](auto I) {
+      constexpr int T = decltype(I)::value;
+      run<T, 0>(); run<T, 1>(); run<T, 2>(); run<T, 3>();
+    });
+  }
+};
+
+__global__ __launch_bounds__(512, 1) void k_field_pre_h8x(SceneDev sc, Args a) {
+  constexpr int R = DINER_H8X_RING;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  h8* B = reinterpret_cast<h8*>(smem);
+  TapRec* taps_lds = reinterpret_cast<TapRec*>(reinterpret_cast<char*>(smem) + (size_t)2 * kB8Bytes);
+  FeatRec* feat_tab = reinterpret_cast<FeatRec*>(reinterpret_cast<char*>(taps_lds) + kTapsBytes);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, pt = lane & 15;
+  const int view = wave & 3, tin = wave >> 2;
+  float* feat_src = reinterpret_cast<float*>(reinterpret_cast<char*>(feat_tab) + kFeatTabBytes) + wave * 64 * kSrcStride;
+  const FieldArgs& fa = a.fa;
+  if (threadIdx.x < 64) {
+    const int sl = threadIdx.x & 15;
+    feat_tab[threadIdx.x] = feat_recipe(16 * (sl >> 2) + 4 * (threadIdx.x >> 4) + (sl & 3), fa.freq_factor);
+  }
+  const long long n_tiles = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
+  __shared__ unsigned s_tile;
+  TileQueue tq;
+  tq.begin();
+  tq.first(a.tile_counter, n_tiles, a.qmap, &s_tile);
+  __syncthreads();
+  lds_ptr Bb = (lds_ptr)(reinterpret_cast<char*>(B)) + lane * 16;
+  const _Float16* w_in = a.w8x;
+  const _Float16* w_blk = a.w8x + kLinInHalfs8x;
+
+  Prof pf;
+  pf.begin();
+  for (long long tile = tq.initial(&s_tile); tile < n_tiles; tile = tq.next(tile, &s_tile)) {
+    tq.request(a.tile_counter, n_tiles, a.qmap);
+    long long p = tile * kPtsPerWave + pt;
+    if (p >= fa.P) p = fa.P - 1;
+    MapDims dims{sc.Wf, sc.Hf, sc.Ws, sc.Hs};
+    asm volatile("" : "+s"(dims.Wf), "+s"(dims.Hf), "+s"(dims.Ws), "+s"(dims.Hs));
+    h8 fin_h, fin_l;
+    Taps taps;
+    {
+      float px, py, pz, dx, dy, dz;
+      load_point(fa, p, px, py, pz, dx, dy, dz);
+      float xc[3], vd[3];
+      world_to_cam(sc.R[view], sc.t[view], px, py, pz, xc[0], xc[1], xc[2]);
+      vd[0] = rot_row(sc.R[view] + 0, dx, dy, dz);
+      vd[1] = rot_row(sc.R[view] + 3, dx, dy, dz);
+      vd[2] = rot_row(sc.R[view] + 6, dx, dy, dz);
+      const float u = project_axis(xc[0], xc[2], sc.focal[view][0], sc.c[view][0], sc.img_w);
+      const float w = project_axis(xc[1], xc[2], sc.focal[view][1], sc.c[view][1], sc.img_h);
+      const int ix = nearest_border(u, dims.Ws), iy = nearest_border(w, dims.Hs);
+      const float dd = __fsub_rn(sc.depth[(size_t)view * dims.Hs * dims.Ws + (size_t)iy * dims.Ws + ix], xc[2]);
+      float* mine = feat_src + lane * kSrcStride;
+      mine[0] = xc[0]; mine[1] = xc[1]; mine[2] = xc[2];
+      mine[3] = vd[0]; mine[4] = vd[1]; mine[5] = vd[2];
+      mine[6] = dd;    mine[7] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const FeatRec r = feat_tab[q * 16 + 8 * tin + j];
+        const float x = mine[r.src];
+        const float e = sin_posenc(__fmaf_rn(x, r.freq, r.phase));
+        const float v = r.sin ? e : x;
+        const _Float16 hh = (_Float16)v;
+        fin_h[j] = hh;
+        fin_l[j] = (_Float16)(v - (float)hh);
+      }
+      bilinear_taps(dims.Wf, dims.Hf, sc.feature_padding, view, u, w, taps);
+    }
+    pf.mark(0);
+    __syncthreads();                              // previous tile's readers of B / taps are done
+    pf.mark(1);
+    *bfrag8x(Bb, tin, view, 0) = fin_h;
+    *bfrag8x(Bb, tin, view, 1) = fin_l;
+    if (tin == 0 && q == 0) {
+      TapRec r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        r.off[k] = (unsigned)(taps.off[k] >> 9);
+        r.w[k] = taps.w[k];
+      }
+      taps_lds[view * 16 + pt] = r;
+    }
+    pf.mark(2);
+    __syncthreads();
+    pf.mark(3);
+    f32x4 xs[kS8][kGroups];
+    set_bias8(xs, a.b, wave, q);
+    pin_acc8(xs);
+    {
+      NoSide8 none;
+      gemm8x<2, 2>(w_in, Bb, wave, lane, xs, none);
+      pf.mark(4);
+      Gather8F<DINER_H8X_G0DEPTH, false> g0(fa.tz, taps_lds, wave, q, pt, xs);
+      g0.all();
+      pf.mark(5);
+    }
+    auto block = [&](int b, auto&& side) {
+      const float* bias = a.b + kHidden * (1 + 2 * b);
+      __syncthreads();                            // everybody finished reading the previous B
+      pf.mark(6);
+      publish8x(Bb, wave, xs);
+      pf.mark(7);
+      __syncthreads();
+      pf.mark(8);
+      {
+        f32x4 ns[kS8][kGroups];
+        set_bias8(ns, bias, wave, q);
+        NoSide8 none;
+        gemm8x<16, R>(w_blk + (size_t)(2 * b) * kLayerHalfs8x, Bb, wave, lane, ns, none);
+        pf.mark(9);
+        __syncthreads();
+        pf.mark(10);
+        publish8x(Bb, wave, ns);
+        pf.mark(11);
+      }
+      __syncthreads();
+      pf.mark(12);
+      pin_acc8(xs);
+      gemm8x<16, R>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs8x, Bb, wave, lane, xs, side);
+      pf.mark(13);
+    };
+#pragma nounroll
+    for (int b = 0; b < 2; ++b) {
+#ifdef DINER_H8X_NO_GATHER      // ablation
+      NoSide8 gs;
+#else
+      Gather8F<DINER_H8X_GDEPTH, DINER_H8X_TAPS_A != 0> gs(fa.tz + (size_t)(b + 1) * fa.tz_stride, taps_lds, wave, q, pt, xs);
+#endif
+      block(b, gs);
+    }
+    {
+      NoSide8 none;
+      block(2, none);
+    }
+    f32x4* out = reinterpret_cast<f32x4*>(fa.xpre) + (size_t)tile * (kTiles * 64) + lane;
+#pragma unroll
+    for (int mo = 0; mo < kS8; ++mo)
+      out[(4 * wave + mo) * 64] = (((xs[mo][0] + xs[mo][1]) + xs[mo][2]) + xs[mo][3]) * (0.25f * kInvScale);
+    pf.mark(14);
+  }
+  pf.end(a.prof, lane);
+}
+
+// layer packing for k_field_pre_h8x: [w 8][t KT][mo 4][hl 2][lane 64][8]: hi / lo of W * scale
+__global__ void k_pack_layer_h8x(const float* __restrict__ W, int rows, int cols, int KT, float scale, _Float16* __restrict__ dst) {
+  const long long total = (long long)8 * KT * 4096;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63, hl = (i >> 9) & 1, mo = (i >> 10) & 3;
+    const int wt = (int)(i >> 12), t = wt % KT, w = wt / KT;
+    const int row = 64 * w + 16 * mo + (lane & 15);
+    const int col = 32 * t + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+    const float x = (row < rows && col < cols) ? W[(size_t)row * cols + col] * scale : 0.0f;
+    const _Float16 h = (_Float16)x;
+    dst[i] = hl ? (_Float16)(x - (float)h) : h;
+  }
+}
+
 // layer packing for k_field_pre_h8: [w 8][t KT][mo 4][lane 64][8] = W[64 w + 16 mo + (lane & 15)][32 t + 16 (j >> 2) + 4 (lane >> 4) + (j & 3)] * scale
 __global__ void k_pack_layer_h8(const float* __restrict__ W, int rows, int cols, int KT, float scale, _Float16* __restrict__ dst) {
   const long long total = (long long)8 * KT * 2048;
@@ -1776,7 +2123,8 @@ __global__ void k_scale_pad(const float* __restrict__ src, int n, int n_pad, flo
 int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float** w_lin_out, float** b_pre, float** b_post) {
   using namespace h3n;
   const size_t halfs4 = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
-  const size_t halfs = halfs4 + w8::kLinInHalfs8 + 6 * w8::kLayerHalfs8;            // + the per-view layers in the 8-wave kernel's order (hi plane)
+  const size_t halfs8 = w8::kLinInHalfs8 + 6 * w8::kLayerHalfs8;                    // the per-view layers in the 8-wave kernels' order: hi plane,
+  const size_t halfs = halfs4 + halfs8 + w8::kLinInHalfs8x + 6 * w8::kLayerHalfs8x;  // and hi + lo planes
   DINER_HIP_OK(hipMalloc(w_out, halfs * sizeof(_Float16)));
   DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16) + kLinOutWBytes));      // MFMA fragments + the fp32 pack of the vector-ALU lin_out
   DINER_HIP_OK(hipMalloc(b_pre, 7 * kHidden * sizeof(float)));
@@ -1827,10 +2175,22 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
       w8p += w8::kLayerHalfs8;
     }
   }
+  {
+    _Float16* wx = (_Float16*)*w_out + halfs4 + halfs8;
+    hipLaunchKernelGGL(w8::k_pack_layer_h8x, dim3(64), dim3(256), 0, stream, p->lin_in_w, kHidden, kDIn, 2, kScale, wx);
+    wx += w8::kLinInHalfs8x;
+    for (int b = 0; b < 3; ++b) {
+      hipLaunchKernelGGL(w8::k_pack_layer_h8x, dim3(512), dim3(256), 0, stream, p->fc0_w[b], kHidden, kHidden, 16, kScale, wx);
+      wx += w8::kLayerHalfs8x;
+      hipLaunchKernelGGL(w8::k_pack_layer_h8x, dim3(512), dim3(256), 0, stream, p->fc1_w[b], kHidden, kHidden, 16, kScale, wx);
+      wx += w8::kLayerHalfs8x;
+    }
+  }
   DINER_LAUNCH_OK();
   return 0;
 }
 int h3n_set_attributes() {
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::w8::k_field_pre_h8x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h3n::w8::kLdsBytes8x));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::w8::k_field_pre_h8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h3n::w8::kLdsBytes8));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_pre_h3n<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h3n::kLdsBytes));
@@ -1848,7 +2208,10 @@ void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, con
   const _Float16* w8p = (const _Float16*)w + ((size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192);
   // DINER_F16_W8=0: the plain-fp16 mode on the 4-wave kernel (A/B measurement aid)
   static const bool use_w8 = [] { const char* e = getenv("DINER_F16_W8"); return !(e && *e == '0'); }();
-  h3n::Args a{fa, (const _Float16*)w, w8p, b, nullptr, tile_counter,
+  const _Float16* w8xp = w8p + (h3n::w8::kLinInHalfs8 + 6 * h3n::w8::kLayerHalfs8);
+  // DINER_F16X3_W8=1: the f16x3 mode on the eight-wave kernel (round 5 experiment; default off until measured)
+  static const bool use_w8x = [] { const char* e = getenv("DINER_F16X3_W8"); return e && *e == '1'; }();
+  h3n::Args a{fa, (const _Float16*)w, w8p, w8xp, b, nullptr, tile_counter,
               h3n::QueueMap::make((fa.P + kPtsPerWave - 1) / kPtsPerWave, fa.K, fa.rays != nullptr && fa.xyz == nullptr && fa.direct_feat == nullptr)};
 #ifdef DINER_HN_PROF
   static unsigned long long* prof = nullptr;
@@ -1856,7 +2219,8 @@ void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, con
   hipMemsetAsync(prof, 0, 32 * sizeof(unsigned long long), stream);
   a.prof = prof;
 #endif
-  if (split) hipLaunchKernelGGL(h3n::k_field_pre_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
+  if (split && use_w8x) hipLaunchKernelGGL(h3n::w8::k_field_pre_h8x, dim3(grid), dim3(512), h3n::w8::kLdsBytes8x, stream, sc, a);
+  else if (split) hipLaunchKernelGGL(h3n::k_field_pre_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
   else if (use_w8) hipLaunchKernelGGL(h3n::w8::k_field_pre_h8, dim3(grid), dim3(512), h3n::w8::kLdsBytes8, stream, sc, a);
   else hipLaunchKernelGGL(h3n::k_field_pre_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
 #ifdef DINER_HN_PROF
