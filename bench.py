@@ -367,9 +367,11 @@ def main():
     def mode_facts(m):
         """(kernel name, MFMA products issued per fp32 product, peak TFLOP/s, dtype label) of arithmetic mode m."""
         if m == ops.PRECISION_F16X3:
-            return "k_field_pre_h3n<true>", 3, PEAK_F16_MFMA_TFLOPS, "f16 (3 MFMA products per fp32 product, fp32 accumulate)"
+            return ("k_field_pre_h8x" if os.environ.get("DINER_F16X3_W8") == "1" else "k_field_pre_h3n<true>"), 3, PEAK_F16_MFMA_TFLOPS, "f16 (3 MFMA products per fp32 product, fp32 accumulate)"
         if m == ops.PRECISION_F16:
-            return "k_field_pre_h3n<false>", 1, PEAK_F16_MFMA_TFLOPS, "f16 operands, fp32 accumulate (reduced precision: ~1e-3, outside the parity bar)"
+            # round 5: the plain-fp16 mode runs on the eight-wave kernel (two waves per SIMD) unless DINER_F16_W8=0 selects the four-wave one
+            kn = "k_field_pre_h3n<false>" if os.environ.get("DINER_F16_W8") == "0" else "k_field_pre_h8"
+            return kn, 1, PEAK_F16_MFMA_TFLOPS, "f16 operands, fp32 accumulate (reduced precision: ~1e-3, outside the parity bar)"
         return "k_field_pre", 1, PEAK_FP32_MFMA_TFLOPS, "f32"
 
     def traffic_for(kname, dims, prof):

@@ -152,25 +152,46 @@ __device__ __forceinline__ void frontend_h3n(const SceneDev& sc, const MapDims& 
 // group e / m, slot q m + e % m, segment = slot / R, ray = group R + slot % R.  (No ray structure -- explicit points, K not a
 // multiple of 16 --: S = 8, R = 1, which is tile % 8.)  An XCD that runs dry takes from the others' queues.
 struct QueueMap {
-  unsigned S, R, m;              // segments per ray, rays per group, entries per queue and group
+  unsigned S, R, m;              // segments per ray (of one pass), rays per group, entries per queue and group
   unsigned per_queue;            // entries per queue (the last group may hold tiles beyond the launch: skipped)
+  unsigned passes, per_pass, S_all;   // round 5: the segments of a ray dealt in `passes` passes of S each (S_all = passes * S): entry e of a
+                                      // queue belongs to pass e / per_pass -- all rays' near segments first, then the far ones (1: as before)
   __host__ static QueueMap make(long long n_tiles, int K, bool rays) {
-    QueueMap q{8, 1, 1, 0};
+    QueueMap q{8, 1, 1, 0, 1, 0, 8};
+    // measurement aids (round 5, BASELINE configs[4]: K = 192 -> 12 segments): DINER_QMAP_PASSES = p splits the segments into p passes
+    // (12 = 2 x 6: a queue then holds 0.75 segments at a time instead of 1.5), DINER_QMAP_RMUL = k takes k times the rays per group
+    static const int env_passes = [] { const char* e = getenv("DINER_QMAP_PASSES"); return e ? atoi(e) : 0; }();
+    static const int env_rmul = [] { const char* e = getenv("DINER_QMAP_RMUL"); return e ? atoi(e) : 1; }();
     if (rays && K >= 16 && K % 16 == 0 && K / 16 <= 4096) {
-      q.S = (unsigned)(K / 16);
+      unsigned S_all = (unsigned)(K / 16);
+      // default: more than 8 segments per ray are dealt in passes of the largest power of two <= 8 (and >= 4) that divides them -- K = 192:
+      // 3 passes of 4 segments, every queue then holds ONE (segment, ray phase) at a time instead of 1.5 segments: per-view kernel 23.1-23.4
+      // -> 22.5-22.8 ms per launch at 1024^2 in f16x3 (passes 2 / 4 / 6 / 12: 22.9-23.2; profiles/r05_qmap_passes_ab.txt); K = 128 (8 segments)
+      // stays one pass (2 / 4 / 8 passes measured 0.4-3.7 % slower)
+      unsigned def_passes = 1;
+      if (S_all > 8)
+        for (unsigned sp = 8; sp >= 4; sp >>= 1)
+          if (S_all % sp == 0) { def_passes = S_all / sp; break; }
+      unsigned passes = env_passes >= 1 && S_all % (unsigned)env_passes == 0 ? (unsigned)env_passes : def_passes;
+      q.S_all = S_all;
+      q.passes = passes;
+      q.S = S_all / passes;
       unsigned g = q.S & (0u - q.S);
       g = g > 8 ? 8 : g;
-      q.R = 8 / g;
+      q.R = 8 / g * (env_rmul > 1 ? (unsigned)env_rmul : 1u);
       q.m = q.S * q.R / 8;
     }
-    const unsigned long long n_rays = ((unsigned long long)n_tiles + q.S - 1) / q.S;
-    q.per_queue = (unsigned)(((n_rays + q.R - 1) / q.R) * q.m);
+    const unsigned long long n_rays = ((unsigned long long)n_tiles + q.S_all - 1) / q.S_all;
+    q.per_pass = (unsigned)(((n_rays + q.R - 1) / q.R) * q.m);
+    q.per_queue = q.per_pass * q.passes;
     return q;
   }
   __device__ __forceinline__ unsigned long long tile(unsigned q, unsigned e) const {
+    const unsigned pass = passes > 1 ? e / per_pass : 0;
+    e -= pass * per_pass;
     const unsigned group = e / m, slot = q * m + (e - group * m);
     const unsigned seg = slot / R, phase = slot - seg * R;
-    return (unsigned long long)(group * R + phase) * S + seg;
+    return (unsigned long long)(group * R + phase) * S_all + (pass * S + seg);
   }
 };
 struct Args {

@@ -39,6 +39,18 @@ __global__ __launch_bounds__(256, 1) void k_fwd512_f16x3(Run512 r) {
   if (b < r.n[0]) return lin512_part_f16(r.part[0], r.shape[0], b, r.n[0]);
   lin512_part_f16(r.part[1], r.shape[1], b - r.n[0], r.n[1]);
 }
+// round 5 experiment (DINER_L512_W2=1): the forward products with TWO workgroups per CU (two waves per SIMD, 256 registers each): 64- and
+// 32-row tiles only (128 accumulator registers), 66 KB of LDS per workgroup -- one workgroup's epilogue and staging stalls under the other's MFMAs
+__device__ __forceinline__ void lin512_part_f16_w2(const Lin512Args& a, int shape, int bid, int nblk) {
+  if (shape == kShape64) lin512_body<DINER_L512_RING, 2, 1, 1>(a, bid, nblk);
+  else if (shape == kShape32) lin512_body<DINER_L512_RING, 1, 1, 1>(a, bid, nblk);
+  else lin512_body<DINER_L512_RING, 1, 2, 1>(a, bid, nblk);
+}
+__global__ __launch_bounds__(256, 2) void k_fwd512_f16x3_w2(Run512 r) {
+  int b = blockIdx.x;
+  if (b < r.n[0]) return lin512_part_f16_w2(r.part[0], r.shape[0], b, r.n[0]);
+  lin512_part_f16_w2(r.part[1], r.shape[1], b - r.n[0], r.n[1]);
+}
 // round 4: the backward's launch (data gradient in its shapes + the weight gradient of the same layer) in the f16x3 arithmetic
 __global__ __launch_bounds__(256, 1) void k_run512_f16x3(Run512 r) {
   int b = blockIdx.x;
@@ -69,6 +81,7 @@ int device_cus(int* cus) {                                   // per device: dyna
   if (!attr_set[dev].load()) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512F16));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3_w2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512F16W2));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
@@ -169,7 +182,11 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream, int arith) {
   Run512 r;
   plan_lin512(a, cus, &r, arith == 1);
   memset(&r.wg, 0, sizeof(r.wg));
-  if (arith == 1) hipLaunchKernelGGL(k_fwd512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytes512F16, stream, r);
+  static const bool w2 = [] { const char* e = getenv("DINER_L512_W2"); return e && *e == '1'; }();
+  if (arith == 1 && w2) {
+    plan_lin512(a, 2 * cus, &r, false);      // (no 128-row shape: 256 accumulator registers do not fit two waves per SIMD)
+    hipLaunchKernelGGL(k_fwd512_f16x3_w2, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytes512F16W2, stream, r);
+  } else if (arith == 1) hipLaunchKernelGGL(k_fwd512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytes512F16, stream, r);
   else hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
   DINER_LAUNCH_OK();
   return 0;

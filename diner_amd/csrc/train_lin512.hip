@@ -38,6 +38,7 @@ constexpr int kSlabs = 512 / (16 * kStepsPerSlab);
 #endif
 constexpr int kStepPad = DINER_L512_STEP_PAD;
 constexpr size_t kLdsBytes512 = (size_t)2 * kStepsPerSlab * (2 * 3 * 1024 + kStepPad);  // two slab buffers of [step 8][row half CT][plane 3] 1 KB fragments: 96 KB at CT = 2
+constexpr size_t kLdsBytes512F16W2 = (size_t)2 * kStepsPerSlab * (2 * 2 * 1024 + kStepPad);  // f16x3 at CT = 2: 66 KB (two workgroups per CU, experiment)
 constexpr size_t kLdsBytes512F16 = (size_t)2 * kStepsPerSlab * (4 * 2 * 1024 + kStepPad);  // f16x3 (two planes) at CT = 4 (128-row tiles): 128 KB
 
 // fp32 -> three bf16 planes (round to nearest each time; the residuals are exact in fp32), 8 values at once

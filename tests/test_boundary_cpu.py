@@ -201,6 +201,36 @@ def test_no_spill_code_inside_nsplit_gemms(tmp_path):
         assert len([l for l in body if "scratch_" in l]) <= 16, m.group(1)
 
 
+def test_eight_wave_kernels_codegen(tmp_path):
+    """Round 5: the eight-wave per-view kernels (two waves per SIMD, 256 registers each; csrc/mlp_h3n.hip namespace w8).  A spill reload is a
+    scratch LOAD, and loads return in order: one reload inside a GEMM waits for every weight fragment and tap in flight (the first version
+    kept the hidden block alive across the gather-carrying GEMM, spilled 8 accumulator tuples inside it and ran 13 % slower than the
+    four-wave kernel, profiles/r05_f16_w8_ab_runs.txt).  Pinned: the plain-fp16 kernel has at most 2 scratch accesses between its first and
+    last MFMA, the f16x3 experiment at most 16; both use the 16 x 16 x 32 fp16 MFMA and buffer loads for the weight ring."""
+    import re
+    import shutil
+    import subprocess
+    from diner_amd import build as B
+    hipcc = B._hipcc()
+    if not (hipcc and (shutil.which(hipcc) or os.path.exists(hipcc))):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "mlp_h3n.s"
+    subprocess.check_call([hipcc] + B.FLAGS + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(B.CSRC, "mlp_h3n.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    for name, n_mfma, max_inside in (("k_field_pre_h8", 1056, 2), ("k_field_pre_h8x", 3168, 16)):
+        m = re.search(r"^(\w*\d" + name + r"E\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
+        assert m, name
+        body = m.group(2).split("\n")
+        idx = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_f16" in l]
+        assert len(idx) == n_mfma, (name, len(idx))
+        inside = [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
+        assert len(inside) <= max_inside, (name, len(inside))
+        assert sum("buffer_load_dwordx4" in l for l in body) >= 200, name
+        meta = re.search(r"\.amdhsa_kernel " + re.escape(m.group(1)) + r"(.*?)\.end_amdhsa_kernel", txt, re.S).group(1)
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 256, name      # two waves per SIMD
+
+
 def test_no_spill_code_in_the_training_kernels(tmp_path):
     """Codegen guard for the 512 x 512 layer products of the training path (csrc/train_512.hip): k_run512 (three tile shapes of the bf16x6
     forward / data-gradient body + the weight-gradient body in one kernel, one wave per SIMD at 496 registers), k_fwd512_f16x3 and k_run512_f16x3 carry no
@@ -229,7 +259,8 @@ def test_no_spill_code_in_the_training_kernels(tmp_path):
             # round 4: the 128-row shape of the f16x3 bodies (256 accumulator registers) keeps ~10 loop-invariant scalars-in-VGPRs (row
             # strides, epilogue pointers) in scratch: stored once in front of the tile loop, reloaded in the epilogue -- none of it inside the
             # slab loop (no spill / reload is interleaved with MFMAs).  Bounded here.
-            assert len(spills) <= 64 * 2, (name, len(spills))
+            # round 5: the counts are pinned -- 35 / 49 with hipcc of ROCm 7.2 -- so that drift is visible
+            assert len(spills) <= {"k_fwd512_f16x3": 35, "k_run512_f16x3": 49}[name], (name, len(spills))
             for i, l in enumerate(body):
                 if "scratch_" in l:      # not interleaved with MFMAs: none within 25 instructions on BOTH sides
                     before = any("v_mfma" in x for x in body[max(0, i - 25):i])
