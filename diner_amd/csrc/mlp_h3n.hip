@@ -1115,6 +1115,9 @@ constexpr size_t kLinInHalfs8 = (size_t)8 * 2 * 4 * 512, kLayerHalfs8 = (size_t)
 #ifndef DINER_H8_G0DEPTH
 #define DINER_H8_G0DEPTH 4
 #endif
+#ifndef DINER_H8_FLAGS           // 1: the 512-wide GEMMs wait for the data they need next (per-wave publish flags) instead of a barrier per layer
+#define DINER_H8_FLAGS 0
+#endif
 #ifndef DINER_H8_TAPS_A          // 1: the tap buffers of the side task in AGPRs
 #define DINER_H8_TAPS_A 0
 #endif
@@ -1155,21 +1158,51 @@ struct NoSide8 {
 // after its last use for block t
 // ACC_A: the accumulator block lives in the AGPR half of the file (the residual stream xs); false: in arch VGPRs (the hidden block ns, dead
 // while the gather-carrying GEMM runs -- with both blocks pinned to AGPRs the arch half is 128 registers and the ring + taps spill)
-template <int KT, int R, bool ACC_A, class Side>
-__device__ __forceinline__ void gemm8(const _Float16* __restrict__ layer, lds_ptr Bb, int wave, int lane, f32x4 (&acc)[kS8][kGroups], Side& side) {
+// FL (round 5, 512-wide contractions): NO barrier in front of the GEMM.  Wave w walks the k32 blocks in ITS OWN order -- step s is block
+// (2 w + s) & 15: its own two blocks first (it published them itself), then the next wave's, ... -- and, one step before it first reads
+// the blocks of wave j, waits until that wave has published this layer's operands: `flags[j] >= need` (an LDS word per wave, stored with
+// release semantics behind the wave's publish).  The weights are packed in the same rotated order (k_pack_layer_h8).  A wave that is
+// done with its GEMM publishes at once into the other B buffer; nobody waits for the slowest wave any more, only for the data it needs
+// next.  (Two buffers are enough: to FINISH layer L + 1 a wave needs every wave's layer-L operands, which a wave publishes after its
+// own layer-L GEMM -- so nobody can still be reading the buffer a finished layer-(L+1) wave writes into.)
+template <int KT, int R, bool ACC_A, bool FL = false, class Side>
+__device__ __forceinline__ void gemm8(const _Float16* __restrict__ layer, lds_ptr Bb, int wave, int lane, f32x4 (&acc)[kS8][kGroups], Side& side,
+                                      const unsigned* flags = nullptr, unsigned need = 0) {
+  static_assert(!FL || KT == 16, "flag-synchronised walk: 512-wide contractions");
   ARing8<KT, R> ring;
   ring.start(layer, wave, lane);
   asm volatile("" : "+v"(Bb));
   h8 bb[kGroups];
+  // FL: the lane's pointer to block step s (fragment offsets then are immediates below 4 KB); otherwise Bb + immediates
+  auto step_ptr = [&](int s) -> lds_ptr {
+    if constexpr (FL) {
+      const int blk = (2 * wave + s) & 15;          // (scalar)
+      lds_ptr pp = Bb + blk * (kGroups * 1024);
+      asm volatile("" : "+v"(pp));
+      return pp;
+    } else {
+      return Bb + s * (kGroups * 1024);
+    }
+  };
+  lds_ptr pcur = step_ptr(0), pnext = KT > 1 ? step_ptr(1) : pcur;
 #pragma unroll
-  for (int g = 0; g < kGroups; ++g) bb[g] = *bfrag8(Bb, 0, g);
+  for (int g = 0; g < kGroups; ++g) bb[g] = *(lds_h8)(pcur + g * 1024);
   static_for<KT * kGroups>([&](auto Q) {
     constexpr int qi = decltype(Q)::value;
     constexpr int t = qi >> 2, g = qi & 3;
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (t + R - 1 < KT) ring.template load1<(t + R - 1 < KT ? t + R - 1 : 0)>(ring.a[(t + R - 1) % R], g);
-    if constexpr (g > 0 && t + 1 < KT) bb[g - 1] = *bfrag8(Bb, t + 1, g - 1);
-    if constexpr (g == 0 && t > 0) bb[kGroups - 1] = *bfrag8(Bb, t, kGroups - 1);
+    if constexpr (g == 0 && t > 0) {
+      bb[kGroups - 1] = *(lds_h8)(pcur + (kGroups - 1) * 1024);
+      if constexpr (t + 1 < KT) pnext = step_ptr(t + 1);
+    }
+    if constexpr (FL && g == 1 && (t & 1) == 1 && t + 1 < KT) {
+      // the blocks of step t + 1, t + 2 belong to wave (w + (t + 1) / 2) & 7: its publish of this layer must have happened
+      const int j = (wave + (t + 1) / 2) & 7;
+      while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) - (int)need < 0)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if constexpr (g > 0 && t + 1 < KT) bb[g - 1] = *(lds_h8)(pnext + (g - 1) * 1024);
     side.template run<t, g>();
     h8 (&ac)[4] = ring.a[t % R];
     const h8 b0 = bb[g];
@@ -1180,6 +1213,7 @@ __device__ __forceinline__ void gemm8(const _Float16* __restrict__ layer, lds_pt
       if constexpr (ACC_A) asm volatile("" : "+a"(acc[m][g]));
       else asm volatile("" : "+v"(acc[m][g]));
     }
+    if constexpr (g == kGroups - 1) pcur = pnext;
   });
   side.finish();
 }
@@ -1360,6 +1394,9 @@ __global__ __launch_bounds__(512, 1) void k_field_pre_h8(SceneDev sc, Args a) {
     feat_tab[threadIdx.x] = feat_recipe(16 * (sl >> 2) + 4 * (threadIdx.x >> 4) + (sl & 3), fa.freq_factor);
   }
   const long long n_tiles = (fa.P + kPtsPerWave - 1) / kPtsPerWave;
+  __shared__ unsigned s_flag[8];             // per wave: number of publishes done (DINER_H8_FLAGS)
+  if (threadIdx.x < 8) s_flag[threadIdx.x] = 0;
+  unsigned seq = 0;
   __shared__ unsigned s_tile;
   TileQueue tq;
   tq.begin();
@@ -1438,28 +1475,36 @@ __global__ __launch_bounds__(512, 1) void k_field_pre_h8(SceneDev sc, Args a) {
     }
     // one residual block: x += fc_1(relu(fc_0(relu(x)))) (+ the next block's projected taps riding on the fc_1 GEMM).  The hidden block
     // lives inside the lambda: dead behind its publish, its 64 registers are free while the gather-carrying GEMM runs
+    auto published = [&]() {                       // this wave's operands of the next layer are in LDS: tell the others
+      ++seq;
+#if DINER_H8_FLAGS
+      if (lane == 0) __hip_atomic_store(&s_flag[wave], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+      __syncthreads();
+#endif
+    };
     auto block = [&](int b, auto&& side) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
       pf.mark(6);
       publish8<true>(Bwr, wave, xs);                // (the other buffer: nobody reads it now)
       pf.mark(7);
-      __syncthreads();                            // everybody has published
+      published();
       pf.mark(8);
       {
         f32x4 ns[kS8][kGroups];
         set_bias8(ns, bias, wave, q);
         NoSide8 none;
-        gemm8<16, R0, true>(w_blk + (size_t)(2 * b) * kLayerHalfs8, Bwr, wave, lane, ns, none);
+        gemm8<16, R0, true, DINER_H8_FLAGS != 0>(w_blk + (size_t)(2 * b) * kLayerHalfs8, Bwr, wave, lane, ns, none, s_flag, seq);
         pf.mark(9);
         pf.mark(10);
         publish8<true>(Brd, wave, ns);
         pf.mark(11);
       }
-      __syncthreads();
+      published();
       pf.mark(12);
       pin_acc8(xs);
       constexpr int R1 = std::is_same<std::decay_t<decltype(side)>, NoSide8>::value ? R0 : R;
-      gemm8<16, R1, true>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs8, Brd, wave, lane, xs, side);
+      gemm8<16, R1, true, DINER_H8_FLAGS != 0>(w_blk + (size_t)(2 * b + 1) * kLayerHalfs8, Brd, wave, lane, xs, side, s_flag, seq);
       pf.mark(13);
     };
 #pragma nounroll
@@ -1835,11 +1880,13 @@ __global__ void k_pack_layer_h8x(const float* __restrict__ W, int rows, int cols
 }
 
 // layer packing for k_field_pre_h8: [w 8][t KT][mo 4][lane 64][8] = W[64 w + 16 mo + (lane & 15)][32 t + 16 (j >> 2) + 4 (lane >> 4) + (j & 3)] * scale
+// (512-wide layers, DINER_H8_FLAGS: position s of wave w's stream is k32 block (2 w + s) & 15 -- the wave's own blocks first, see gemm8)
 __global__ void k_pack_layer_h8(const float* __restrict__ W, int rows, int cols, int KT, float scale, _Float16* __restrict__ dst) {
   const long long total = (long long)8 * KT * 2048;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int j = i & 7, lane = (i >> 3) & 63, mo = (i >> 9) & 3;
-    const int wt = (int)(i >> 11), t = wt % KT, w = wt / KT;
+    const int wt = (int)(i >> 11), ts = wt % KT, w = wt / KT;
+    const int t = (KT == 16 && DINER_H8_FLAGS != 0) ? ((2 * w + ts) & 15) : ts;
     const int row = 64 * w + 16 * mo + (lane & 15);
     const int col = 32 * t + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
     dst[i] = (_Float16)((row < rows && col < cols) ? W[(size_t)row * cols + col] * scale : 0.0f);
