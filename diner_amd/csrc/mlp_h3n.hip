@@ -1897,6 +1897,7 @@ __global__ void k_pack_layer_h8(const float* __restrict__ W, int rows, int cols,
 struct PostArgsN {
   PostArgs pa;
   const _Float16* w;        // n-split packed fc_0 / fc_1 of blocks 3, 4 (4 layers of 4 * 16 * 16 KB)
+  const _Float16* w8;       // the same four layers in the eight-wave kernels' order (hi plane; k_field_post_h8), or null
   const _Float16* w_out;    // lin_out fragments [t 16][hl 2][lane 64][8] (rows >= 4 zero), x16; behind them (32 KB on) the fp32 pack
                             // [wave 4][mo 8][q 4][o 4][j 4] = Wout[o][128 wave + 16 mo + 4 q + j] / 16 of the vector-ALU lin_out
   unsigned long long* prof; // DINER_HN_PROF builds: phase counters, else unused
@@ -2144,6 +2145,201 @@ __global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) {
   pf.end(a.prof, lane);
 }
 
+// Round 5: the post kernel of the plain-fp16 mode on eight waves (two per SIMD), the scheme of k_field_pre_h8: wave w owns features
+// [64 w, 64 w + 64) of the 64 points of a tile (four 16-point tiles = the four column groups); two B buffers, one barrier per layer; lin_out
+// on the vector ALU straight from the accumulators as in k_field_post_h3n (the same fp32 weight pack: wave pair = one wave of that kernel),
+// the eight waves' shares summed through 8 KB of LDS, waves 0..3 finish column group w.
+namespace w8 {
+constexpr size_t kLinOutPartBytes8 = 8 * 4 * 16 * 16;
+constexpr size_t kLdsBytesPost8 = (size_t)2 * kB8Bytes + kLinOutWBytes + kLinOutPartBytes8;
+static_assert(kLdsBytesPost8 <= 160 * 1024, "LDS of one CU");
+
+__global__ __launch_bounds__(512, 1) void k_field_post_h8(PostArgsN a) {
+  constexpr int R0 = DINER_H8_RING0;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const PostArgs& pa = a.pa;
+  const long long n_t16 = (pa.P + kPtsPerWave - 1) / kPtsPerWave;
+  const long long n_tiles = (n_t16 + 3) / 4;
+  lds_ptr Brd = (lds_ptr)(reinterpret_cast<char*>(smem)) + lane * 16, Bwr = Brd + kB8Bytes;
+  typedef __attribute__((address_space(3))) f32x4* lds_f4;
+  const lds_f4 lo_w = (lds_f4)((lds_ptr)(reinterpret_cast<char*>(smem)) + (size_t)2 * kB8Bytes);
+  const lds_f4 lo_part = (lds_f4)((lds_ptr)(reinterpret_cast<char*>(smem)) + (size_t)2 * kB8Bytes + kLinOutWBytes);
+  {
+    const f32x4* gw = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.w_out) + 32768);
+    for (int i = threadIdx.x; i < (int)(kLinOutWBytes / 16); i += 512) lo_w[i] = gw[i];
+  }
+  Prof pf;
+  pf.begin();
+  __shared__ unsigned s_tile2[2];
+  int par = 0;
+  TileQueue tq;
+  tq.begin();
+  __syncthreads();
+  f32x4 xs[kS8][kGroups];
+  auto request_handover = [&](long long t) {
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      long long t16 = t * 4 + g;
+      if (t16 >= n_t16) t16 = n_t16 - 1;
+      const f32x4* xp = reinterpret_cast<const f32x4*>(pa.xpre);
+      asm volatile("" : "+s"(xp));
+      const f32x4* in = xp + (size_t)t16 * (kTiles * 64) + lane_here();
+#pragma unroll
+      for (int mo = 0; mo < kS8; ++mo) xs[mo][g] = in[(4 * wave + mo) * 64];
+    }
+  };
+  long long tile = blockIdx.x;
+  if (tile < n_tiles) request_handover(tile);
+  while (tile < n_tiles) {
+    long long tile_next_v = n_tiles;
+    const int q = lane_here() >> 4;
+    tq.request(a.tile_counter, n_tiles, a.qmap);
+    const float* bpost = pa.b_post;
+    asm volatile("" : "+s"(bpost));
+#pragma unroll
+    for (int mo = 0; mo < kS8; ++mo) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(bpost + 4 * kHidden + 16 + 64 * wave + 16 * mo + 4 * q);
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) xs[mo][g] = xs[mo][g] * kScale + b2;
+    }
+    pin_acc8(xs);
+    pf.mark(8);
+#pragma nounroll
+    for (int b = 0; b < 2; ++b) {
+      const float* bias = bpost + 2 * kHidden * b;
+      pf.mark(0);
+      publish8<true>(Bwr, wave, xs);
+      pf.mark(1);
+      __syncthreads();
+      pf.mark(2);
+      {
+        f32x4 ns[kS8][kGroups];
+        set_bias8(ns, bias, wave, q);
+        NoSide8 none;
+        gemm8<16, R0, true>(a.w8 + (size_t)(2 * b) * kLayerHalfs8, Bwr, wave, lane, ns, none);
+        pf.mark(3);
+        if (b == 0) tq.park(&s_tile2[par]);         // (the request went out at the top of the tile)
+        publish8<true>(Brd, wave, ns);
+        pf.mark(5);
+      }
+      __syncthreads();
+      pf.mark(6);
+      pin_acc8(xs);
+      {     // + fc_1's bias: into the accumulators the GEMM adds to
+#pragma unroll
+        for (int mo = 0; mo < kS8; ++mo) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + kHidden + 64 * wave + 16 * mo + 4 * q);
+#pragma unroll
+          for (int g = 0; g < kGroups; ++g) xs[mo][g] += bv;
+        }
+        pin_acc8(xs);
+        NoSide8 none;
+        gemm8<16, R0, true>(a.w8 + (size_t)(2 * b + 1) * kLayerHalfs8, Brd, wave, lane, xs, none);
+      }
+      pf.mark(7);
+    }
+    pin_acc8(xs);
+    // ---- lin_out on relu(x), fp32 on the vector ALU straight from the accumulators (see k_field_post_h3n), + the range check of the launch
+    f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int lane_o = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_o));
+    const int q_o = lane_o >> 4, pt = lane_o & 15;
+    bool wave_bad = false;
+    {
+      int m_pos = 0;
+      unsigned m_neg = 0;
+      f32x4 po[kGroups];
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) po[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int wrow = (wave >> 1) * 8 + (wave & 1) * 4;        // this wave's first row tile in the four-wave kernel's pack
+      f32x4 wn[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) wn[o] = lo_w[((wrow + 0) * 4 + q_o) * 4 + o];
+#pragma unroll
+      for (int mo = 0; mo < kS8; ++mo) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 wv[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) wv[o] = wn[o];
+        if (mo + 1 < kS8) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) wn[o] = lo_w[((wrow + mo + 1) * 4 + q_o) * 4 + o];
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+          float v[4];
+          int xi[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(xi[jj]) : "a"(xs[mo][g][jj]));
+            v[jj] = __int_as_float(max(xi[jj], 0));
+          }
+          m_pos = max(max(m_pos, xi[0]), xi[1]);
+          m_pos = max(max(m_pos, xi[2]), xi[3]);
+          m_neg = max(max(m_neg, (unsigned)xi[0]), (unsigned)xi[1]);
+          m_neg = max(max(m_neg, (unsigned)xi[2]), (unsigned)xi[3]);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            float t = po[g][o];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) t = fmaf(wv[o][jj], v[jj], t);
+            po[g][o] = t;
+          }
+        }
+      }
+      // x is dead from here on: the next tile's hand-over is requested now (its index was parked in LDS behind the first GEMM)
+      const long long tile_nx = tq.take(tile, &s_tile2[par]);
+      if (tile_nx < n_tiles) request_handover(tile_nx);
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float t = po[g][o];
+          t += __int_as_float(__builtin_amdgcn_ds_bpermute((lane_o ^ 16) << 2, __float_as_int(t)));
+          t += __int_as_float(__builtin_amdgcn_ds_bpermute((lane_o ^ 32) << 2, __float_as_int(t)));
+          po[g][o] = t;
+        }
+        if (q_o == 0) lo_part[(wave * kGroups + g) * 16 + pt] = po[g];
+      }
+      wave_bad = __any(m_pos >= 0x497fe000 || m_neg >= 0xff800000u);
+      __syncthreads();
+      pf.mark(9);
+      if (wave < kGroups) {      // wave w finishes column group w (its 16 points): the eight waves' shares
+        const lds_f4 lp = lo_part + wave * 16 + pt;
+        res = ((lp[0 * kGroups * 16] + lp[1 * kGroups * 16]) + (lp[2 * kGroups * 16] + lp[3 * kGroups * 16])) +
+              ((lp[4 * kGroups * 16] + lp[5 * kGroups * 16]) + (lp[6 * kGroups * 16] + lp[7 * kGroups * 16]));
+      }
+      pf.mark(10);
+      tile_next_v = tile_nx;
+    }
+    if (pa.overflow && wave_bad && lane_here() == 0) *pa.overflow = 1;
+    if (wave < kGroups) {
+      res += *reinterpret_cast<const f32x4*>(bpost + 4 * kHidden + 4 * q_o);     // lin_out bias kept at scale 1
+      const long long t16 = tile * 4 + wave;
+      const long long p = t16 * kPtsPerWave + pt;
+      if (t16 < n_t16 && q_o == 0 && p < pa.P) {
+        const float probe = (res[0] - res[0]) + (res[1] - res[1]) + (res[2] - res[2]) + (res[3] - res[3]);   // 0 or NaN
+        if (pa.overflow && (probe != 0.0f || wave_bad)) *pa.overflow = 1;
+        if (!pa.raw) {
+          res[0] = 1.0f / (1.0f + expf(-res[0]));
+          res[1] = 1.0f / (1.0f + expf(-res[1]));
+          res[2] = 1.0f / (1.0f + expf(-res[2]));
+          res[3] = fmaxf(res[3], 0.0f);
+        }
+        reinterpret_cast<f32x4*>(pa.out)[p] = res;
+      }
+    }
+    pf.mark(11);
+    // (the partial sums of this tile are read before the next tile's can be written: two barriers of the next tile's first block lie between)
+    tile = tile_next_v;
+    par ^= 1;
+  }
+  pf.end(a.prof, lane);
+}
+}  // namespace w8
+
 // layer packing: [w 4][ts KT][mo 8][hl 2][lane 64][8]: W[128 w + 16 mo + (lane&15)][32 t(w, ts) + 16 (j>>2) + 4 (lane>>4) + (j&3)] * scale
 __global__ void k_pack_layer_h3n(const float* __restrict__ W, int rows, int cols, int KT, float scale,
                                  _Float16* __restrict__ dst) {
@@ -2192,7 +2388,8 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
   using namespace h3n;
   const size_t halfs4 = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
   const size_t halfs8 = w8::kLinInHalfs8 + 6 * w8::kLayerHalfs8;                    // the per-view layers in the 8-wave kernels' order: hi plane,
-  const size_t halfs = halfs4 + halfs8 + w8::kLinInHalfs8x + 6 * w8::kLayerHalfs8x;  // and hi + lo planes
+  const size_t halfs8x = w8::kLinInHalfs8x + 6 * w8::kLayerHalfs8x;                 // ... hi + lo planes,
+  const size_t halfs = halfs4 + halfs8 + halfs8x + 4 * w8::kLayerHalfs8;             // and the four post layers (hi plane)
   DINER_HIP_OK(hipMalloc(w_out, halfs * sizeof(_Float16)));
   DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16) + kLinOutWBytes));      // MFMA fragments + the fp32 pack of the vector-ALU lin_out
   DINER_HIP_OK(hipMalloc(b_pre, 7 * kHidden * sizeof(float)));
@@ -2254,10 +2451,20 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
       wx += w8::kLayerHalfs8x;
     }
   }
+  {
+    _Float16* wq = (_Float16*)*w_out + halfs4 + halfs8 + halfs8x;
+    for (int b = 3; b < 5; ++b) {
+      hipLaunchKernelGGL(w8::k_pack_layer_h8, dim3(512), dim3(256), 0, stream, p->fc0_w[b], kHidden, kHidden, 16, kScale, wq);
+      wq += w8::kLayerHalfs8;
+      hipLaunchKernelGGL(w8::k_pack_layer_h8, dim3(512), dim3(256), 0, stream, p->fc1_w[b], kHidden, kHidden, 16, kScale, wq);
+      wq += w8::kLayerHalfs8;
+    }
+  }
   DINER_LAUNCH_OK();
   return 0;
 }
 int h3n_set_attributes() {
+  DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::w8::k_field_post_h8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h3n::w8::kLdsBytesPost8));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::w8::k_field_pre_h8x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h3n::w8::kLdsBytes8x));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::w8::k_field_pre_h8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h3n::w8::kLdsBytes8));
   DINER_HIP_OK(hipFuncSetAttribute((const void*)h3n::k_field_pre_h3n<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2313,7 +2520,11 @@ void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out,
   const _Float16* wn = (const _Float16*)w + (size_t)4 * 2 * 8192 + (size_t)6 * 4 * 16 * 8192;
   const _Float16* wo = (const _Float16*)w_lin_out;
   const long long n_t16 = (pa.P + kPtsPerWave - 1) / kPtsPerWave;
-  h3n::PostArgsN a{pa, wn, wo, nullptr, tile_counter, h3n::QueueMap::make((n_t16 + 3) / 4, 0, false)};
+  const _Float16* w8post = (const _Float16*)w + ((size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192) + (h3n::w8::kLinInHalfs8 + 6 * h3n::w8::kLayerHalfs8) +
+                           (h3n::w8::kLinInHalfs8x + 6 * h3n::w8::kLayerHalfs8x);
+  // DINER_F16_W8=0 / DINER_F16_POST_W8=0: the plain-fp16 post kernel on four waves (A/B measurement aids)
+  static const bool use_w8 = [] { const char* e = getenv("DINER_F16_W8"); const char* f = getenv("DINER_F16_POST_W8"); return !(e && *e == '0') && !(f && *f == '0'); }();
+  h3n::PostArgsN a{pa, wn, w8post, wo, nullptr, tile_counter, h3n::QueueMap::make((n_t16 + 3) / 4, 0, false)};
 #ifdef DINER_HN_PROF
   static unsigned long long* prof = nullptr;
   if (!prof) hipMalloc(&prof, 32 * sizeof(unsigned long long));
@@ -2321,6 +2532,7 @@ void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out,
   a.prof = prof;
 #endif
   if (split) hipLaunchKernelGGL(h3n::k_field_post_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
+  else if (use_w8) hipLaunchKernelGGL(h3n::w8::k_field_post_h8, dim3(grid), dim3(512), h3n::w8::kLdsBytesPost8, stream, a);
   else hipLaunchKernelGGL(h3n::k_field_post_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
 #ifdef DINER_HN_PROF
   unsigned long long h[32];

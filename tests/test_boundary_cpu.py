@@ -218,7 +218,7 @@ def test_eight_wave_kernels_codegen(tmp_path):
     subprocess.check_call([hipcc] + B.FLAGS + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(B.CSRC, "mlp_h3n.hip"), "-o", str(out)],
                           stderr=subprocess.DEVNULL)
     txt = out.read_text()
-    for name, n_mfma, max_inside in (("k_field_pre_h8", 1056, 2), ("k_field_pre_h8x", 3168, 16)):
+    for name, n_mfma, max_inside in (("k_field_pre_h8", 1056, 2), ("k_field_pre_h8x", 3168, 16), ("k_field_post_h8", 512, 0)):
         m = re.search(r"^(\w*\d" + name + r"E\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
         assert m, name
         body = m.group(2).split("\n")
@@ -226,7 +226,7 @@ def test_eight_wave_kernels_codegen(tmp_path):
         assert len(idx) == n_mfma, (name, len(idx))
         inside = [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
         assert len(inside) <= max_inside, (name, len(inside))
-        assert sum("buffer_load_dwordx4" in l for l in body) >= 200, name
+        assert sum("buffer_load_dwordx4" in l for l in body) >= 100, name
         meta = re.search(r"\.amdhsa_kernel " + re.escape(m.group(1)) + r"(.*?)\.end_amdhsa_kernel", txt, re.S).group(1)
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 256, name      # two waves per SIMD
 
