@@ -139,6 +139,27 @@ def test_renderer_contract_and_no_fallback():
     assert z.shape == (1, 1, 10) and bool(((z >= 0.5) & (z <= 1.5)).all())
 
 
+def test_configurations_outside_the_fused_kernels_are_routed_to_the_generic_path():
+    """Round 5: only the shipped configuration (55 / 512 / 512 / 4, 5 blocks, combine 3, NV 4, poscode 6 + input, ReLU) takes the fused
+    kernels; the reference's constructor defaults and every other variation are classified for the generic slow path (csrc/generic.hip) --
+    no configuration the reference accepts is refused any more (GPU parity: tests/test_generic_gpu.py)."""
+    from src.models.resnetfc import ResnetFC
+    shipped = ResnetFC(d_in=55, d_latent=512, n_blocks=5, d_hidden=512, combine_layer=3)
+    assert shipped.is_fused_shape() and shipped.is_fused_shape(nv=4, num_freqs=6, include_input=True)
+    assert not shipped.is_fused_shape(nv=3) and not shipped.is_fused_shape(num_freqs=4) and not shipped.is_fused_shape(include_input=False)
+    for kw in (dict(d_in=55, d_latent=512), dict(d_in=55, d_latent=512, d_hidden=512, n_blocks=5, combine_layer=2),
+               dict(d_in=55, d_latent=512, d_hidden=512, n_blocks=4, combine_layer=3), dict(d_in=55, d_latent=512, d_hidden=512, n_blocks=5, combine_layer=3, beta=1.0),
+               dict(d_in=39, d_latent=512, d_hidden=512, n_blocks=5, combine_layer=3), dict(d_in=55, d_latent=0, d_hidden=512, n_blocks=5, combine_layer=3)):
+        assert not ResnetFC(**kw).is_fused_shape(), kw
+    with pytest.raises(NotImplementedError):
+        ResnetFC(d_in=55, d_latent=512, combine_type="max")._check_supported()
+    from diner_amd import _lib
+    lib = _lib.load()
+    for sym in ("diner_mlp_generic_forward_f32", "diner_mlp_generic_workspace_bytes", "diner_field_inputs_generic_f32"):
+        assert hasattr(lib, sym)
+    assert lib.diner_mlp_generic_workspace_bytes(None, 4, 10) == 0          # argument validation without a device
+
+
 def test_shard_range_partition():
     from diner_amd.render import shard_range
     for n in (1, 7, 120000, 480000):

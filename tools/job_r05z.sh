@@ -22,6 +22,7 @@ PY
 timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench rc=$?"
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?"
 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --no-configs > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks.err; echo "bench 2 ranks rc=$?"
+timeout 900 python bench.py --gpus 1 --force-dist --check-frame --steps 3 --warmup 1 --no-modes --no-configs --cpu-rays 0 > $O/bench_rccl_one_rank.json 2> $O/bench_rccl_one_rank.err; echo "bench rccl one rank rc=$?"
 timeout 900 python tools/time_train.py --objects 4 --rays 4096 --steps 3 2>&1 | grep "rays x" | tee $O/time_train.txt | cut -c1-200
 timeout 900 python tools/time_train.py --objects 1 --rays 4096 --steps 5 2>&1 | grep "rays x" | tee -a $O/time_train.txt | cut -c1-200
 cut -c1-300 $O/bench_driver_cmd.json
