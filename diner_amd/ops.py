@@ -236,7 +236,7 @@ class GenericMlp:
     the library on the general exact-fp32 MFMA GEMM, one launch per layer.  No packing: the struct points at the parameter tensors
     (kept alive here)."""
 
-    def __init__(self, sd, prefix="", combine_layer=1000, beta=0.0, num_freqs=6, freq_factor=6.28, include_input=True):
+    def __init__(self, sd, prefix="", combine_layer=1000, beta=0.0, num_freqs=6, freq_factor=6.28, include_input=True, d_latent=None):
         g = lambda k: _f32c(sd[prefix + k])
         n_blocks = len([k for k in sd if k.startswith(prefix + "blocks.") and k.endswith("fc_0.weight")])
         n_z = len([k for k in sd if k.startswith(prefix + "lin_z.") and k.endswith(".weight")])
@@ -258,7 +258,8 @@ class GenericMlp:
         p = _lib.DinerMlpParams()
         p.d_hidden, p.d_out = self._keep["lin_out_w"].shape[1], self._keep["lin_out_w"].shape[0]
         p.d_in = self._keep["lin_in_w"].shape[1] if has_in else 0
-        p.d_latent = lists["lin_z_w"][0].shape[1] if n_z else 0
+        # the latent width is the module's (resnetfc.py:140-142 slices zx by self.d_latent whether or not a lin_z layer exists: combine_layer = 0)
+        p.d_latent = int(d_latent) if d_latent is not None else (lists["lin_z_w"][0].shape[1] if n_z else 0)
         p.n_blocks, p.combine_layer = n_blocks, int(min(combine_layer, 2 ** 30))
         p.num_freqs, p.include_input, p.freq_factor = int(num_freqs), int(bool(include_input)), float(freq_factor)
         if has_in:

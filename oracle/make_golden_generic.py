@@ -8,6 +8,7 @@ own constructor defaults.  The reference's modules are run as they are (resnetfc
      averaged -> (SB, NV, B, 4)), NV = 4
   B  ResnetFC(d_in=23, d_latent=40, d_out=5, d_hidden=128, n_blocks=3, combine_layer=2), NV = 3, SB = 2
   C  ResnetFC(d_in=20, d_latent=0, d_hidden=256, n_blocks=2, combine_layer=1, beta=1.5) (Softplus, no latent), NV = 2
+  E  ResnetFC(d_in=7, d_latent=5, n_blocks=2, combine_layer=0) (views averaged before block 0; latent columns without a lin_z layer), NV = 3
   D  PixelNeRF with poscode num_freqs=4 / freq_factor=3.0, SpatialEncoder(num_layers=2) (latent width 128), the MLP
      n_blocks=3 / d_hidden=128 / combine_layer=2, NV = 3 source views: forward(xyz, viewdirs) and renderer.forward on 192 rays
      (K = 32, G = 12, injected noise)
@@ -33,6 +34,7 @@ MLP_CASES = {      # name: (constructor kwargs, NV, SB, B, seed)
     "A": (dict(d_in=55, d_latent=512), 4, 1, 64, 501),
     "B": (dict(d_in=23, d_latent=40, d_out=5, d_hidden=128, n_blocks=3, combine_layer=2), 3, 2, 50, 502),
     "C": (dict(d_in=20, d_latent=0, d_hidden=256, n_blocks=2, combine_layer=1, beta=1.5), 2, 1, 33, 503),
+    "E": (dict(d_in=7, d_latent=5, n_blocks=2, combine_layer=0), 3, 1, 20, 505),      # views averaged BEFORE block 0: latent columns present, no lin_z layer
 }
 PIX = dict(W=48, H=40, nv=3, latent_ch=128, seed=7, num_freqs=4, freq_factor=3.0,
            mlp=dict(n_blocks=3, d_hidden=128, combine_layer=2, combine_type="average"), K=32, G=12, n_cand=1000, NR=192, B=300)

@@ -82,7 +82,7 @@ class ResnetFC(nn.Module):
                                        freq_factor=freq_factor, include_input=include_input)
             else:
                 self._hip = ops.GenericMlp(sd, combine_layer=self.combine_layer, beta=self.beta, num_freqs=num_freqs,
-                                           freq_factor=freq_factor, include_input=include_input)
+                                           freq_factor=freq_factor, include_input=include_input, d_latent=self.d_latent)
             self._hip_key = key
         return self._hip
 

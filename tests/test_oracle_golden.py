@@ -159,7 +159,7 @@ def test_oracle_generalises_to_other_mlp_shapes():
     from oracle.make_golden_generic import MLP_CASES, PIX, mlp_state_dict, mlp_inputs, pix_scene
     from tests.helpers import sha
     g = load("g19_generic.npz")
-    for name in ("A", "B"):
+    for name in ("A", "B", "E"):
         kw, nv, SB, B, seed = MLP_CASES[name]
         zx = mlp_inputs(kw, nv, SB, B, seed)
         assert sha(zx) == str(g[f"mlp{name}_in_sha"])
