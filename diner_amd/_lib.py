@@ -92,6 +92,9 @@ SIGNATURES = {
                                                 C.c_void_p, C.c_void_p]),
     "diner_field_inputs_generic_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "diner_field_train_forward_fused_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.POINTER(DinerMlpParams), C.c_void_p, C.c_void_p,
+                                                      C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_train_fused_overflowed": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "diner_quantize_rgb_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_minmax_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "diner_colormap_u8": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),

@@ -296,6 +296,15 @@ __device__ __forceinline__ void field_frontend(const SceneDev& sc, const FieldAr
 
 }
 
+// Training forward on the inference kernels (round 5, k_train_fwd_pre / k_train_fwd_post): where the pre-activations the backward needs are
+// stored -- fp32, row-major (rows, 512), values at scale 1.  X[b]: the residual stream entering block b, H[b]: fc_0's output of block b;
+// b < 3: rows v P + p (per view), b >= 3 and x_last (the stream entering lin_out): rows p; raw: lin_out's outputs (P, 4).
+struct SaveActs {
+  float* X[5];
+  float* H[5];
+  float* x_last;
+  float* raw;
+};
 struct PostArgs {
   const float* xpre;
   const float* w_post;

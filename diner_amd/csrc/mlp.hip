@@ -61,9 +61,9 @@ struct DinerMlpImpl {
 int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w, float** w_out, float** b_pre, float** b_post);
 int h3n_set_attributes();
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
-                    unsigned* tile_counter, hipStream_t stream);
+                    unsigned* tile_counter, hipStream_t stream, const SaveActs* sv = nullptr);
 void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_out, int grid, bool split, unsigned* tile_counter,
-                     hipStream_t stream);
+                     hipStream_t stream, const SaveActs* sv = nullptr);
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing (runs once per parameter version, on the device)
@@ -951,6 +951,52 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
   fa.tz16 = scene->latent_proj_f16;
   fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
   return launch_field(&sd, &mlp->impl, fa, sd.nv, field_out, 0, workspace, precision, (hipStream_t)stream);
+}
+
+// Training forward on the inference kernels (round 5; train.hip, DINER_TRAIN_FUSED_FWD): the f16x3 per-view and post kernels of the
+// field path, storing the pre-activations the backward needs into `sv`.  `workspace`: diner_field_workspace_bytes(P) bytes (hand-over +
+// flags).  No exact-fp32 repeat behind it: *overflow_flag (device, zeroed here) stays raised when an activation left the fp16 range --
+// the caller checks it (the saved activations are then not usable).  Weights outside the fp16 split: DINER_E_UNSUPPORTED (the caller
+// keeps the layer-wise forward).
+int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs, long long P, float* out,
+                       void* workspace, const SaveActs& sv, int** overflow_flag, hipStream_t stream) {
+  SceneDev sd;
+  int rc = check_field_scene(scene, mlp, &sd, DINER_PRECISION_F16X3);
+  if (rc) return rc;
+  const DinerMlpImpl* im = &mlp->impl;
+  const int cus = prepare_device();
+  if (cus < 0) return cus;
+  if (!(im->wmax == im->wmax && im->wmax < 1024.0f)) {
+    set_error("field_forward_save: weights outside the fp16 split (max |w| %g)", (double)im->wmax);
+    return DINER_E_UNSUPPORTED;
+  }
+  FieldArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.xyz = xyz;
+  fa.viewdirs = viewdirs;
+  fa.K = 1;
+  fa.P = P;
+  fa.tz = scene->latent_proj;
+  fa.tz_stride = (size_t)sd.nv * sd.Hf * sd.Wf * kLatent;
+  if (fa.tz_stride * sizeof(float) >= ((size_t)1 << 32)) {
+    set_error("field_forward_save: projected map beyond the 32-bit addressing of the fp16-operand kernels");
+    return DINER_E_UNSUPPORTED;
+  }
+  fa.xpre = (float*)workspace;
+  fa.freq_factor = im->freq_factor;
+  int* flag = reinterpret_cast<int*>((char*)workspace + xpre_bytes(P, sd.nv));
+  DINER_HIP_OK(hipMemsetAsync(flag, 0, 24 * sizeof(int), stream));
+  const long long n_t16 = (P + kPtsPerWave - 1) / kPtsPerWave;
+  const int grid_pre = (int)(n_t16 < cus ? n_t16 : cus);
+  const long long n_tiles = (n_t16 + 3) / 4;
+  const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
+  h3n_launch_pre(sd, fa, im->hn_w, im->hn_b_pre, grid_pre, true, reinterpret_cast<unsigned*>(flag) + 8, stream, &sv);
+  DINER_LAUNCH_OK();
+  PostArgs pn{(const float*)workspace, im->w_post, im->hn_b_post, out, P, sd.nv, 0, nullptr, flag, im->fallback_dev};
+  h3n_launch_post(pn, im->hn_w, im->hn_w_out, grid_post, true, reinterpret_cast<unsigned*>(flag) + 16, stream, &sv);
+  DINER_LAUNCH_OK();
+  if (overflow_flag) *overflow_flag = flag;
+  return 0;
 }
 
 extern "C" int diner_mlp_forward_f32(const DinerMlp* mlp, const float* zx, long long B, float* out, void* workspace,

@@ -1329,6 +1329,62 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
   return 0;
 }
 
+// ---- training forward on the INFERENCE kernels (round 5, experiment behind DINER_TRAIN_FUSED_FWD=1 of the Python host) ------------------
+// The layer-wise forward above reads and writes every activation tensor of the 13 products through HBM (44 KB per per-view row); the
+// inference path computes the same network with the activations on chip (k_field_pre_h3n / k_field_post_h3n, f16x3).  Here those kernels
+// run in their storing variants (k_train_fwd_pre / k_train_fwd_post, mlp_h3n.hip): the ten pre-activation tensors, the stream entering
+// lin_out and lin_out's raw outputs go to the SAME places of the workspace the layer-wise forward uses, so the backward is unchanged.  The
+// gather inputs (MLP inputs, tap rows / weights, interpolated latent) and the packed weights of the backward's products are made as before.
+// Needs the packed-weights handle and the hoisted projections of the scene (diner_scene_prepare_f32 with THIS handle: the weights of the
+// step).  No exact repeat: an activation beyond the fp16 range leaves a flag up (diner_field_train_fused_overflowed) instead.
+int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs, long long P, float* out,
+                       void* workspace, const SaveActs& sv, int** overflow_flag, hipStream_t stream);
+namespace {
+__global__ void k_copy_flag(const int* __restrict__ src, int* __restrict__ dst) { *dst = *src; }
+enum { kFlagFusedOvf = 14 };
+}  // namespace
+
+extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
+                                                   const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
+  DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && out && workspace && P > 0, "field_train_forward_fused: bad arguments");
+  int rc = check_train_params(p, true);
+  if (rc) return rc;
+  DINER_CHECK_ARG(use_lin512() && (use_fwd_f16() || use_bwd_f16()), "field_train_forward_fused: needs the 512-layer kernels of the backward");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const TrainWs w = train_ws(P, scene->nv);
+  rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
+  if (rc) return rc;
+  {   // packed weights of the backward's products + the flag block, as the layer-wise forward leaves them
+    PackMany pm;
+    for (int b = 0; b < 5; ++b) { pm.W[kSlotFc0 + b] = p->fc0_w[b]; pm.W[kSlotFc1 + b] = p->fc1_w[b]; }
+    for (int b = 0; b < 3; ++b) pm.W[kSlotLinZ + b] = p->lin_z_w[b];
+    DINER_HIP_OK(hipMemsetAsync(ws + w.flags, 0, 16 * sizeof(int), st));
+    if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st, 4, reinterpret_cast<int*>(ws + w.flags) + kFlagWBad))) return rc;
+  }
+  SaveActs sv;
+  for (int b = 0; b < 5; ++b) { sv.X[b] = ws + w.X[b]; sv.H[b] = ws + w.H[b]; }
+  sv.x_last = ws + w.x_last;
+  sv.raw = ws + w.raw;
+  int* ovf = nullptr;
+  // hand-over + tile counters of the two kernels: the backward's dx buffer is free in the forward (8 KB per point; 2 KB + flags needed)
+  if ((rc = field_forward_save(scene, mlp, xyz, viewdirs, P, out, ws + w.dx, sv, &ovf, st))) return rc;
+  hipLaunchKernelGGL(k_copy_flag, dim3(1), dim3(1), 0, st, ovf, reinterpret_cast<int*>(ws + w.flags) + kFlagFusedOvf);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+
+// 1 when the fused forward that filled `workspace` met an activation beyond the fp16 range (its saved activations are not usable), else 0;
+// waits for `stream` (one 4-byte read back)
+extern "C" int diner_field_train_fused_overflowed(const void* workspace, long long P, int nv, int* overflowed, void* stream) {
+  DINER_CHECK_ARG(workspace && overflowed && P > 0 && nv > 0, "field_train_fused_overflowed: bad arguments");
+  const TrainWs w = train_ws(P, nv);
+  DINER_HIP_OK(hipMemcpyAsync(overflowed, reinterpret_cast<const int*>((const float*)workspace + w.flags) + kFlagFusedOvf, sizeof(int),
+                              hipMemcpyDeviceToHost, (hipStream_t)stream));
+  DINER_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 // grads: the same structure as the parameters, device buffers of the parameters' shapes (overwritten);
 // d_latent_cl (nv, Hf, Wf, 512) or NULL: overwritten with the gradient of the channels-last feature map
 extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* p, const DinerMlpParams* grads,

@@ -19,6 +19,8 @@ fused kernels.  Sizes: the shipped configs train SB = 4 objects x 4096 rays (a 6
 4 views = 655 k columns per object and step (configs/train_dtu.yaml:16,52-63); the workspace of saved activations is 94 KB per sample
 point = 14.7 GiB per object at that size (diner_field_train_workspace_bytes), four of them alive between forward and backward.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -114,6 +116,22 @@ def _param_struct(tensors, freq_factor=6.28):
     return p, keep
 
 
+def fused_forward_enabled():
+    return os.environ.get("DINER_TRAIN_FUSED_FWD", "0") == "1"
+
+
+_STEP_MLP = [None, None]
+
+
+def _step_mlp(params, freq_factor):
+    """Packed-weights handle of THIS step's parameters (shared by the SB objects of a step: rebuilt when a parameter was written)."""
+    from .ops import HipMlp
+    key = tuple((p.data_ptr(), p._version) for p in params) + (float(freq_factor),)
+    if _STEP_MLP[0] != key:
+        _STEP_MLP[0], _STEP_MLP[1] = key, HipMlp(dict(zip(PARAM_ORDER, params)), freq_factor=float(freq_factor))
+    return _STEP_MLP[1]
+
+
 class FieldFunction(torch.autograd.Function):
     """PixelNeRF.forward (pixelnerf.py:55-145) for one object: (xyz, viewdirs) (P,3) -> (P,4) [sigmoid rgb, relu sigma],
     differentiable with respect to the encoder's latent (NV,512,Hf,Wf) and the MLP parameters.  One library call for the
@@ -138,8 +156,22 @@ class FieldFunction(torch.autograd.Function):
             ws = torch.empty(int(lib.diner_field_train_workspace_bytes(P, NV)), dtype=torch.uint8, device=dev)
             out = torch.empty(P, 4, device=dev)
             ps, keep = _param_struct(params, freq_factor)
-            _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
-                                                         _ptr(ws), _stream()))
+            if fused_forward_enabled():
+                # round-5 experiment: the forward on the inference kernels' storing variants (activations stay on chip between the layers,
+                # the backward's operands are written once); needs this step's packed weights and the latent projected with them
+                mlp = _step_mlp(params, freq_factor)
+                scene.prepare(mlp)
+                _lib.check(lib.diner_field_train_forward_fused_f32(scene.ref, mlp.handle, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P,
+                                                                   _ptr(out), _ptr(ws), _stream()))
+                if os.environ.get("DINER_TRAIN_FUSED_CHECK", "0") == "1":
+                    ovf = C.c_int(0)
+                    _lib.check(lib.diner_field_train_fused_overflowed(_ptr(ws), P, NV, C.byref(ovf), _stream()))
+                    if ovf.value:
+                        raise FloatingPointError("diner_amd: an activation left the fp16 range in the fused training forward "
+                                                 "(unset DINER_TRAIN_FUSED_FWD: the layer-wise forward repeats such products exactly)")
+            else:
+                _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
+                                                             _ptr(ws), _stream()))
             # the backward's outputs are allocated here, while the device works on the forward: the host is idle now and is the one the
             # device waits for at the start of the backward (64 us of the reference batch's 3.9 ms step)
             ctx.ps = (ps, keep)

@@ -298,6 +298,15 @@ int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams*
                                   const float* viewdirs, long long P, float* out, void* workspace, void* stream);
 int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* params, const DinerMlpParams* grads,
                                    long long P, const float* d_out, void* workspace, float* d_latent_cl, void* stream);
+/* Round 5 (experiment; the Python host uses it when DINER_TRAIN_FUSED_FWD=1): the training forward on the INFERENCE kernels -- the f16x3
+ * per-view and post kernels of diner_field_from_points_f32 in variants that store the pre-activations into the places of `workspace`
+ * the layer-wise forward uses (diner_field_train_ws_layout), so that diner_field_train_backward_f32 follows unchanged.  `mlp`: the
+ * packed-weights handle of THIS step's parameters, `scene->latent_proj` prepared with it (diner_scene_prepare_f32).  No exact repeat:
+ * diner_field_train_fused_overflowed reports (after a stream wait) whether an activation left the fp16 range (pixelnerf.py:55-145,
+ * resnetfc.py:129-159 as diner_field_train_forward_f32). */
+int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
+                                        const float* viewdirs, long long P, float* out, void* workspace, void* stream);
+int diner_field_train_fused_overflowed(const void* workspace, long long P, int nv, int* overflowed, void* stream);
 /* Test aid: float offsets into the training workspace of the pre-activations the forward saved -- [0..4] X_b, the residual stream
  * entering block b (P*nv rows of 512 for b < 3, P rows behind the view mean), [5..9] H_b, the fc_0 outputs of block b, [10] the
  * stream entering lin_out (P x 512), [11] lin_out's raw outputs (P x 4).  The signs of these values are the relu decisions of the

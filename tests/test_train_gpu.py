@@ -81,13 +81,18 @@ def _oracle_grads(scene, w, xyz, dirs, G, relu_masks=None):
     return out.detach(), scene.latent.grad, {(k, i): t.grad for k, i, t in names}
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["layerwise", "fused_forward"])
 @pytest.mark.parametrize("P", [200, 5120])
-def test_field_forward_and_backward_against_oracle_autograd(ops, P):
+def test_field_forward_and_backward_against_oracle_autograd(ops, P, fused, monkeypatch):
     """P = 200: 800 / 200 rows per layer (the general kernel serves the post-mean layers).  P = 5120: the reference training batch's row
     counts (128 rays x 40 samples: 20480 rows per view layer, 5120 behind the view mean) -- the launch plans of k_run512 that the timing
     runs use: one round of 64-row tiles + shared 32-row tiles, the weight-gradient product in the same launch, the deferred summing pass."""
     from diner_amd import train
     from tests.tests_train_util import module_param_list
+    # fused_forward (round 5, DINER_TRAIN_FUSED_FWD=1): the forward on the storing variants of the inference kernels (k_train_fwd_pre /
+    # k_train_fwd_post); the backward reads what they saved -- the same bars hold, including the one conditioned on the saved relu decisions
+    monkeypatch.setenv("DINER_TRAIN_FUSED_FWD", "1" if fused else "0")
+    monkeypatch.setenv("DINER_TRAIN_FUSED_CHECK", "1")
     g = load("g6_pixelnerf.npz")
     sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
     reps = (P + g["pts"].shape[0] - 1) // g["pts"].shape[0]
