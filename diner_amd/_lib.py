@@ -93,7 +93,7 @@ SIGNATURES = {
     "diner_field_inputs_generic_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "diner_field_train_forward_fused_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.POINTER(DinerMlpParams), C.c_void_p, C.c_void_p,
-                                                      C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                                      C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_train_fused_overflowed": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "diner_quantize_rgb_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_minmax_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
@@ -128,6 +128,9 @@ def load():
         raise ImportError(f"libdiner_hip.so ABI version {lib.diner_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
+
+
+E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3            # include/diner_hip.h:31-33
 
 
 def check(rc):

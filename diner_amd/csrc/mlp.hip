@@ -958,6 +958,10 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
 // flags).  No exact-fp32 repeat behind it: *overflow_flag (device, zeroed here) stays raised when an activation left the fp16 range --
 // the caller checks it (the saved activations are then not usable).  Weights outside the fp16 split: DINER_E_UNSUPPORTED (the caller
 // keeps the layer-wise forward).
+// (3, 512): the constants the projected latent maps carry -- plane b: lin_z[b]'s bias, planes 1 and 2 also fc_1's bias of the block before
+// (diner_mlp_create folds them: the interpolation weights sum to one)
+const float* mlp_hoist_bias(const DinerMlp* mlp) { return mlp->impl.b_hoist; }
+
 int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs, long long P, float* out,
                        void* workspace, const SaveActs& sv, int** overflow_flag, hipStream_t stream) {
   SceneDev sd;

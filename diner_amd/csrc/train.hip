@@ -1335,17 +1335,19 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
 // run in their storing variants (k_train_fwd_pre / k_train_fwd_post, mlp_h3n.hip): the ten pre-activation tensors, the stream entering
 // lin_out and lin_out's raw outputs go to the SAME places of the workspace the layer-wise forward uses, so the backward is unchanged.  The
 // gather inputs (MLP inputs, tap rows / weights, interpolated latent) and the packed weights of the backward's products are made as before.
-// Needs the packed-weights handle and the hoisted projections of the scene (diner_scene_prepare_f32 with THIS handle: the weights of the
-// step).  No exact repeat: an activation beyond the fp16 range leaves a flag up (diner_field_train_fused_overflowed) instead.
+// Needs the packed-weights handle of the step's weights and the latent map projected with them: made here into latent_proj_out (below), or
+// by the caller (diner_scene_prepare_f32 with THIS handle) when latent_proj_out is null.  No exact repeat: an activation beyond the fp16 range leaves a flag up (diner_field_train_fused_overflowed) instead.
 int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs, long long P, float* out,
                        void* workspace, const SaveActs& sv, int** overflow_flag, hipStream_t stream);
+const float* mlp_hoist_bias(const DinerMlp* mlp);
 namespace {
 __global__ void k_copy_flag(const int* __restrict__ src, int* __restrict__ dst) { *dst = *src; }
 enum { kFlagFusedOvf = 14 };
 }  // namespace
 
 extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
-                                                   const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
+                                                   const float* viewdirs, long long P, float* out, void* workspace, float* latent_proj_out,
+                                                   void* stream) {
   DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && out && workspace && P > 0, "field_train_forward_fused: bad arguments");
   int rc = check_train_params(p, true);
   if (rc) return rc;
@@ -1362,13 +1364,37 @@ extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, cons
     DINER_HIP_OK(hipMemsetAsync(ws + w.flags, 0, 16 * sizeof(int), st));
     if ((rc = lin512_pack_many(pm, 13, ws + w.wpack, st, 4, reinterpret_cast<int*>(ws + w.flags) + kFlagWBad))) return rc;
   }
+  // latent_proj_out: the projection of the whole latent map through lin_z[0..2] (what diner_scene_prepare_f32 makes on the exact fp32
+  // kernel, 112 TFLOP/s: 3.2 ms for four 264 x 214 maps -- a training step pays it per object, the latent is new every step) as three
+  // products of the 512-layer kernel in the arithmetic of the other training products: f16x3, the bf16x6 twin behind a flag
+  DinerScene own = *scene;
+  if (latent_proj_out) {
+    DINER_CHECK_ARG(scene->latent_cl && scene->C == kLatent && scene->Hf > 0 && scene->Wf > 0, "field_train_forward_fused: channels-last latent missing");
+    const long long rows = (long long)scene->nv * scene->Hf * scene->Wf;
+    DINER_CHECK_ARG(lin512_ok(scene->latent_cl, kLatent, latent_proj_out, kHidden, nullptr, nullptr), "field_train_forward_fused: unaligned latent / projection buffer");
+    for (int b = 0; b < 3; ++b) {
+      // (the handle's constants: planes 1 and 2 also carry fc_1's bias of the block before, as the per-view kernel expects them)
+      Lin512Args a{scene->latent_cl, wpack_slot(ws, w, kSlotLinZ + b, false), latent_proj_out + (size_t)b * rows * kHidden, mlp_hoist_bias(mlp) + kHidden * b,
+                   nullptr, nullptr, rows, kLatent, kHidden, 0};
+      int* flag = reinterpret_cast<int*>(ws + w.flags) + kSlotLinZ + b;
+      Lin512Args h = a;
+      h.Wp = wpack_slot(ws, w, kSlotLinZ + b, false, true);
+      h.ovf = flag;
+      h.skip = reinterpret_cast<int*>(ws + w.flags) + kFlagWBad;
+      if ((rc = lin512_launch(h, st, 1))) return rc;
+      a.gate = flag;
+      if ((rc = lin512_launch(a, st))) return rc;
+    }
+    own.latent_proj = latent_proj_out;
+    own.proj_stamp = diner_mlp_stamp(mlp);
+  }
   SaveActs sv;
   for (int b = 0; b < 5; ++b) { sv.X[b] = ws + w.X[b]; sv.H[b] = ws + w.H[b]; }
   sv.x_last = ws + w.x_last;
   sv.raw = ws + w.raw;
   int* ovf = nullptr;
   // hand-over + tile counters of the two kernels: the backward's dx buffer is free in the forward (8 KB per point; 2 KB + flags needed)
-  if ((rc = field_forward_save(scene, mlp, xyz, viewdirs, P, out, ws + w.dx, sv, &ovf, st))) return rc;
+  if ((rc = field_forward_save(&own, mlp, xyz, viewdirs, P, out, ws + w.dx, sv, &ovf, st))) return rc;
   hipLaunchKernelGGL(k_copy_flag, dim3(1), dim3(1), 0, st, ovf, reinterpret_cast<int*>(ws + w.flags) + kFlagFusedOvf);
   DINER_LAUNCH_OK();
   return 0;

@@ -14,8 +14,11 @@ Here that is two `torch.autograd.Function`s whose forward AND backward are ONE c
     synchronisation (DESIGN.md section 6.3);
   * lin_in, lin_out, the view mean, the latent gather / scatter and the output activations on small dedicated kernels; a general
     split-bf16 GEMM (`gemm`, `_linear`, `_linear_backward` below drive it from Python; the tests use them) for everything ragged.
-The forward is the un-fused one that keeps every pre-activation, which is what a backward pass needs; inference keeps using the
-fused kernels.  Sizes: the shipped configs train SB = 4 objects x 4096 rays (a 64 x 64 patch: w_vgg != 0, diner.py:57) x 40 samples x
+The forward (round 5) runs on the inference path's fused f16x3 kernels in their STORING variants (k_train_fwd_pre / k_train_fwd_post,
+diner_field_train_forward_fused_f32): activations stay on chip between the layers and every pre-activation the backward needs is written
+once; an activation beyond the fp16 range (flag, one 4-byte read back per object) or weights outside the fp16 split send the object to
+the layer-wise forward (diner_field_train_forward_f32: one product per launch, exact repeats on the device; DINER_TRAIN_FUSED_FWD=0
+makes it the only one).  Sizes: the shipped configs train SB = 4 objects x 4096 rays (a 64 x 64 patch: w_vgg != 0, diner.py:57) x 40 samples x
 4 views = 655 k columns per object and step (configs/train_dtu.yaml:16,52-63); the workspace of saved activations is 94 KB per sample
 point = 14.7 GiB per object at that size (diner_field_train_workspace_bytes), four of them alive between forward and backward.
 """
@@ -116,8 +119,28 @@ def _param_struct(tensors, freq_factor=6.28):
     return p, keep
 
 
-def fused_forward_enabled():
-    return os.environ.get("DINER_TRAIN_FUSED_FWD", "0") == "1"
+def fused_forward_enabled(P=None, scene=None):
+    """DINER_TRAIN_FUSED_FWD: 1 = always, 0 = never, unset = by size.  The fused forward projects the WHOLE latent map through lin_z[0..2]
+    (the inference path's hoist) where the layer-wise forward projects the P x NV gathered rows: it pays from about half a map of sample
+    points per object (the shipped 4096 rays x 40 samples: 3 maps' worth -- 156.1 -> 134.5 ms per four-object step; a 128-ray batch: a
+    tenth of a map, host-bound, 13.2 ms fused with its flag read back against 12.5 ms layer-wise: profiles/r05_train_fused_forward.txt)."""
+    e = os.environ.get("DINER_TRAIN_FUSED_FWD", "")
+    if e in ("0", "1"):
+        return e == "1"
+    return P is None or scene is None or 2 * P >= scene.Hf * scene.Wf
+
+
+_PROJ = {}
+
+
+def _proj_buffer(scene, dev):
+    """The latent map projected through lin_z[0..2] with the step's weights: written and read inside the forward call only, so the objects
+    of a step (and the steps) share one buffer per device (stream order keeps them apart)."""
+    n = int(lib.diner_scene_proj_bytes(scene.ref)) // 4
+    buf = _PROJ.get(dev)
+    if buf is None or buf.numel() < n:
+        buf = _PROJ[dev] = torch.empty(n, dtype=torch.float32, device=dev)
+    return buf
 
 
 _STEP_MLP = [None, None]
@@ -156,20 +179,23 @@ class FieldFunction(torch.autograd.Function):
             ws = torch.empty(int(lib.diner_field_train_workspace_bytes(P, NV)), dtype=torch.uint8, device=dev)
             out = torch.empty(P, 4, device=dev)
             ps, keep = _param_struct(params, freq_factor)
-            if fused_forward_enabled():
-                # round-5 experiment: the forward on the inference kernels' storing variants (activations stay on chip between the layers,
-                # the backward's operands are written once); needs this step's packed weights and the latent projected with them
+            done = False
+            if fused_forward_enabled(P, scene):
+                # round 5: the forward on the inference kernels' storing variants (activations stay on chip between the layers, the
+                # backward's operands are written once); needs this step's packed weights and the latent projected with them
                 mlp = _step_mlp(params, freq_factor)
-                scene.prepare(mlp)
-                _lib.check(lib.diner_field_train_forward_fused_f32(scene.ref, mlp.handle, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P,
-                                                                   _ptr(out), _ptr(ws), _stream()))
-                if os.environ.get("DINER_TRAIN_FUSED_CHECK", "0") == "1":
-                    ovf = C.c_int(0)
-                    _lib.check(lib.diner_field_train_fused_overflowed(_ptr(ws), P, NV, C.byref(ovf), _stream()))
-                    if ovf.value:
-                        raise FloatingPointError("diner_amd: an activation left the fp16 range in the fused training forward "
-                                                 "(unset DINER_TRAIN_FUSED_FWD: the layer-wise forward repeats such products exactly)")
-            else:
+                rc = lib.diner_field_train_forward_fused_f32(scene.ref, mlp.handle, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P,
+                                                             _ptr(out), _ptr(ws), _ptr(_proj_buffer(scene, dev)), _stream())
+                if rc != _lib.E_UNSUPPORTED:         # (weights outside the fp16 split, maps beyond 4 GiB: the layer-wise forward below)
+                    _lib.check(rc)
+                    done = True
+                    if os.environ.get("DINER_TRAIN_FUSED_CHECK", "1") != "0":
+                        # the fused kernels have no exact repeat on the device: an activation beyond the fp16 range leaves a flag up and the
+                        # layer-wise forward (whose products repeat themselves in bf16x6) redoes the object -- one 4-byte read back per call
+                        ovf = C.c_int(0)
+                        _lib.check(lib.diner_field_train_fused_overflowed(_ptr(ws), P, NV, C.byref(ovf), _stream()))
+                        done = not ovf.value
+            if not done:
                 _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
                                                              _ptr(ws), _stream()))
             # the backward's outputs are allocated here, while the device works on the forward: the host is idle now and is the one the

@@ -301,11 +301,14 @@ int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams
 /* Round 5 (experiment; the Python host uses it when DINER_TRAIN_FUSED_FWD=1): the training forward on the INFERENCE kernels -- the f16x3
  * per-view and post kernels of diner_field_from_points_f32 in variants that store the pre-activations into the places of `workspace`
  * the layer-wise forward uses (diner_field_train_ws_layout), so that diner_field_train_backward_f32 follows unchanged.  `mlp`: the
- * packed-weights handle of THIS step's parameters, `scene->latent_proj` prepared with it (diner_scene_prepare_f32).  No exact repeat:
+ * packed-weights handle of THIS step's parameters.  latent_proj_out (diner_scene_proj_bytes; free again when the call's work is done):
+ * the library projects scene->latent_cl through lin_z[0..2] into it on the training products' kernel (f16x3 with its bf16x6 repeat)
+ * and gathers from it; NULL: `scene->latent_proj` prepared with `mlp` (diner_scene_prepare_f32) is used.  No exact repeat of the field:
  * diner_field_train_fused_overflowed reports (after a stream wait) whether an activation left the fp16 range (pixelnerf.py:55-145,
  * resnetfc.py:129-159 as diner_field_train_forward_f32). */
 int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
-                                        const float* viewdirs, long long P, float* out, void* workspace, void* stream);
+                                        const float* viewdirs, long long P, float* out, void* workspace, float* latent_proj_out,
+                                        void* stream);
 int diner_field_train_fused_overflowed(const void* workspace, long long P, int nv, int* overflowed, void* stream);
 /* Test aid: float offsets into the training workspace of the pre-activations the forward saved -- [0..4] X_b, the residual stream
  * entering block b (P*nv rows of 512 for b < 3, P rows behind the view mean), [5..9] H_b, the fc_0 outputs of block b, [10] the

@@ -92,7 +92,6 @@ def test_field_forward_and_backward_against_oracle_autograd(ops, P, fused, monke
     # fused_forward (round 5, DINER_TRAIN_FUSED_FWD=1): the forward on the storing variants of the inference kernels (k_train_fwd_pre /
     # k_train_fwd_post); the backward reads what they saved -- the same bars hold, including the one conditioned on the saved relu decisions
     monkeypatch.setenv("DINER_TRAIN_FUSED_FWD", "1" if fused else "0")
-    monkeypatch.setenv("DINER_TRAIN_FUSED_CHECK", "1")
     g = load("g6_pixelnerf.npz")
     sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
     reps = (P + g["pts"].shape[0] - 1) // g["pts"].shape[0]
@@ -455,12 +454,15 @@ def test_scatter_latent_merged_and_layout_pass_against_torch():
         assert torch.equal(dst, src.permute(0, 3, 1, 2).contiguous()), (n, H, W, C)
 
 
-def test_training_forward_beyond_the_fp16_range(ops):
-    """The training forward runs its 512 x 512 products in the f16x3 arithmetic first; an operand beyond the fp16 range raises the product's
+@pytest.mark.parametrize("fused", [False, True], ids=["layerwise", "fused_forward"])
+def test_training_forward_beyond_the_fp16_range(ops, fused, monkeypatch):
+    """fused_forward (the default since round 5): the storing inference kernels raise their flag and the host repeats the object on the
+    layer-wise forward.  The layer-wise training forward runs its 512 x 512 products in the f16x3 arithmetic first; an operand beyond the fp16 range raises the product's
     flag and the bf16x6 launch behind it recomputes it (no host synchronisation).  One feature of the residual stream sits at 1e5 (the
     f16x3 products that stage it would turn it into inf and their outputs into NaN): outputs and gradients follow the oracle's autograd."""
     from diner_amd import train
     from tests.tests_train_util import module_param_list
+    monkeypatch.setenv("DINER_TRAIN_FUSED_FWD", "1" if fused else "0")
     g = load("g6_pixelnerf.npz")
     sc, scene, w, msd, rays = oracle_setup(int(g["W"]), int(g["H"]), int(g["seed"]))
     big = {k: v.clone() for k, v in msd.items()}

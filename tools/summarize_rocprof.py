@@ -12,7 +12,7 @@ rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 with open(dst, "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n")
     f.write("| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|\n")
-    for r in rows[:12]:
+    for r in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 12]:
         name = r["Name"].split("(")[0]
         if len(name) > 70:
             name = name[:67] + "..."

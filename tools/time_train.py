@@ -52,10 +52,14 @@ for NR in args.rays:
     gt = torch.rand(SB, NR, 3, device=dev)
     ren = R(n_samples=K, n_depth_candidates=1000, n_gaussian=G, white_bkgd=True)
 
+    mlp_params = [p for p in nerf.parameters()]
+
     def step():
         for p in nerf.parameters():
             p.grad = None
         nerf.encoder.latent.grad = None
+        with torch.no_grad():        # an optimiser step's in-place write: the parameters are "new" every step, as in training -- whatever is
+            torch._foreach_add_(mlp_params, 0.0)      # cached per parameter version (packed weights, projected latent maps) is redone per step
         out = ren.forward(nerf, r)
         torch.nn.functional.mse_loss(out.fine.rgb, gt).backward()
 
