@@ -33,6 +33,7 @@ struct GemmArgs {
                         // of a layer is the row sum of the dy^T operand of its weight-gradient product, read by that product anyway
   long long M;
   int N, K, lda, ldb, ldc, flags, k_chunk;      // k_chunk: K range per blockIdx.z (split-K, needs kAtomic)
+  const int* gate;      // null, or: the launch does nothing unless *gate != 0 (bf16x6 kernel: the layer-wise repeat behind the fused training forward)
 };
 
 // C tile 64 x 64 per workgroup, four waves 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles; operands staged k-major in LDS.
@@ -365,6 +366,7 @@ __device__ __forceinline__ void tile_stash(const TileRegs& r, __bf16* lds, bool 
 // EPI: 0 plain, 1 + resid in the epilogue, 2 + row sums of op(A) (separate instantiations: the plain kernel must stay at 3 waves per SIMD)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
+  if (g.gate && *g.gate == 0) return;
   __shared__ __attribute__((aligned(16))) __bf16 As[3 * kPlaneElems], Bs[3 * kPlaneElems];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -657,7 +659,8 @@ __global__ __launch_bounds__(256) void k_cl_to_nchw(const float* __restrict__ sr
 }
 
 // y[p][c] = mean_v x[v][p][c]   (combine_interleaved, resnetfc.py:150-152); adjoint: dx[v][p][c] = dy[p][c] / nv
-__global__ void k_view_mean(const float* __restrict__ x, int nv, long long PC, float* __restrict__ y) {
+__global__ void k_view_mean(const float* __restrict__ x, int nv, long long PC, float* __restrict__ y, const int* __restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < PC; i += (long long)gridDim.x * blockDim.x) {
     float s = 0.0f;
     for (int v = 0; v < nv; ++v) s += x[(size_t)v * PC + i];
@@ -696,7 +699,8 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, lo
 }
 
 // out = [sigmoid(raw rgb), relu(raw sigma)]  (pixelnerf.py:139-143) and its adjoint
-__global__ void k_field_act(const float* __restrict__ raw, long long P, int ld, float* __restrict__ out) {
+__global__ void k_field_act(const float* __restrict__ raw, long long P, int ld, float* __restrict__ out, const int* __restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
     const float* r = raw + (size_t)p * ld;
     f32x4 o;
@@ -728,7 +732,9 @@ __global__ void k_field_act_bwd(const float* __restrict__ raw, const float* __re
 // columns 4 lane .. + 3 and 256 + 4 lane .. + 3 of the row and of the four weight rows; explicit fmaf chains, wave sums by shuffles.
 // forward: raw = relu(x) W^T + b and out = [sigmoid(raw rgb), relu(raw sigma)] (resnetfc.py:157-158 + pixelnerf.py:139-143)
 __global__ __launch_bounds__(256) void k_lin_out_fwd(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
-                                                     long long P, float* __restrict__ raw, float* __restrict__ out) {
+                                                     long long P, float* __restrict__ raw, float* __restrict__ out,
+                                                     const int* __restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;
   const int lane = threadIdx.x & 63;
   f32x4 w[4][2];
 #pragma unroll
@@ -898,8 +904,9 @@ using namespace diner::train;
 
 static int gemm_launch(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc,
                        int flags, const float* bias, const float* mask, int k_split, hipStream_t stream,
-                       const float* resid = nullptr, float* rowsum = nullptr) {
+                       const float* resid = nullptr, float* rowsum = nullptr, const int* gate = nullptr) {
   DINER_CHECK_ARG(A && B && C, "gemm: null pointer argument");
+  DINER_CHECK_ARG(!gate || !(flags & kExact), "gemm: a gated launch runs on the bf16x6 kernel");
   DINER_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad sizes M=%lld N=%d K=%d", M, N, K);
   DINER_CHECK_ARG((flags & ~127) == 0, "gemm: unknown flags 0x%x", flags);
   DINER_CHECK_ARG(k_split >= 1 && (k_split == 1 || (flags & kAtomic)), "gemm: split-K needs the atomic output flag");
@@ -912,7 +919,7 @@ static int gemm_launch(const float* A, const float* B, float* C, long long M, in
   chunk = (chunk + XK - 1) / XK * XK;               // (a multiple of every kernel's k-tile)
   static const bool no_xcd = [] { const char* e = getenv("DINER_TRAIN_NO_XCD"); return e && *e == '1'; }();
   if (no_xcd) flags |= kNoXcdOrder;
-  GemmArgs g{A, B, C, bias, mask, resid, rowsum, M, N, K, lda, ldb, ldc, flags, chunk};
+  GemmArgs g{A, B, C, bias, mask, resid, rowsum, M, N, K, lda, ldb, ldc, flags, chunk, gate};
   if (!(flags & kExact)) {
     // split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6); ragged and skinny shapes (lin_out: N = 4,
     // its adjoints: K = 4 / M = 4) ride along zero-padded -- a partly empty 128 x 128 tile is still faster than the fp32 kernels
@@ -1007,7 +1014,7 @@ extern "C" int diner_channels_last_to_nchw_f32(const float* src, int n, long lon
 extern "C" int diner_view_mean_f32(const float* x, int nv, long long PC, float* y, int adjoint, void* stream) {
   DINER_CHECK_ARG(x && y && nv > 0 && PC > 0, "view_mean: bad arguments");
   if (adjoint) hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y, (const unsigned*)nullptr, (unsigned*)nullptr);
-  else hipLaunchKernelGGL(k_view_mean, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y);
+  else hipLaunchKernelGGL(k_view_mean, dim3(grid1d(PC)), dim3(256), 0, (hipStream_t)stream, x, nv, PC, y, (const int*)nullptr);
   DINER_LAUNCH_OK();
   return 0;
 }
@@ -1024,7 +1031,7 @@ extern "C" int diner_colsum_f32(const float* dY, long long M, int N, int ld, flo
 extern "C" int diner_field_act_f32(const float* raw, const float* dout, long long P, int ld, float* out, void* stream) {
   DINER_CHECK_ARG(raw && out && P > 0 && ld >= 4, "field_act: bad arguments");
   if (dout) hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, (hipStream_t)stream, raw, dout, P, ld, out);
-  else hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, (hipStream_t)stream, raw, P, ld, out);
+  else hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, (hipStream_t)stream, raw, P, ld, out, (const int*)nullptr);
   DINER_LAUNCH_OK();
   return 0;
 }
@@ -1229,20 +1236,22 @@ extern "C" int diner_field_train_ws_layout(long long P, int nv, long long* float
   return 0;
 }
 
-extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
-                                             const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
-  DINER_CHECK_ARG(scene && xyz && viewdirs && out && workspace && P > 0, "field_train_forward: bad arguments");
-  int rc = check_train_params(p, true);
-  if (rc) return rc;
+// The layer-wise forward.  gate != null: the repeat behind the fused forward (below) -- inputs, packed weights and the flag block are in
+// place, every launch returns at once unless *gate != 0 (the fused kernels met an activation beyond the fp16 range).
+static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, const float* xyz, const float* viewdirs, long long P,
+                             float* out, void* workspace, void* stream, const int* gate) {
+  int rc = 0;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const TrainWs w = train_ws(P, scene->nv);
   const long long cols = P * scene->nv;
-  rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
-  if (rc) return rc;
+  if (!gate) {
+    rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
+    if (rc) return rc;
+  }
   // the 512 x 512 layers: weights packed once per step (three bf16 planes in the consuming wave's order; one launch for the 13 matrices
   // in both orientations -- the backward call of the step reads the transposed ones from the workspace), products on k_lin512
-  if (use_lin512()) {
+  if (use_lin512() && !gate) {
     PackMany pm;
     for (int b = 0; b < 5; ++b) { pm.W[kSlotFc0 + b] = p->fc0_w[b]; pm.W[kSlotFc1 + b] = p->fc1_w[b]; }
     for (int b = 0; b < 3; ++b) pm.W[kSlotLinZ + b] = p->lin_z_w[b];
@@ -1275,14 +1284,18 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
         }
         h.ovf = flag;
         h.skip = reinterpret_cast<int*>(ws + w.flags) + kFlagWBad;      // weights beyond the fp16 split: raises the flag and returns
+        h.gate = gate;
         int hrc = lin512_launch(h, st, 1);
         if (hrc) return hrc;
         a.gate = flag;                           // the bf16x6 product below runs only if the f16x3 one left the range
+        a.gate2 = gate;                          // (repeat mode: the lin_z flags may be up from the map projection of the fused forward)
+      } else {
+        a.gate = gate;
       }
       return lin512_launch(a, st);
     }
     DINER_CHECK_ARG(!resid2 && !x2, "field_train_forward: second residual / second segment off the 512-kernel path");
-    return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid);
+    return gemm_launch(x, W, y, M, N, K, ldx, K, N, kTB | (relu ? kReluA : 0) | (accum ? kAccum : 0), b, nullptr, 1, st, resid, nullptr, gate);
   };
   // The lin_z term of block b, Z_b = lat Wz_b^T + bz_b, is a product of its own into a scratch buffer (d_lat is free in the forward) and
   // enters the residual stream through the epilogue of fc_1 of block b - 1, the product that writes X[b] (second residual; block 0: below): no accumulating product is left in the forward, so every 512 x 512 product can run in the f16x3 arithmetic with
@@ -1316,17 +1329,25 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
                     ws + w.lat, kSlotLinZ + b + 1, p->lin_z_b[b + 1]))) return rc;
     } else if ((rc = lin(ws + w.H[b], kHidden, p->fc1_w[b], p->fc1_b[b], nx, M, kHidden, kHidden, true, false, X, kSlotFc1 + b, z_next ? Z : nullptr))) return rc;
     if (b == 2)
-      hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3]);
+      hipLaunchKernelGGL(k_view_mean, dim3(grid1d(P * kHidden)), dim3(256), 0, st, nx, scene->nv, P * kHidden, ws + w.X[3], gate);
   }
   if (use_lin_out() && (reinterpret_cast<size_t>(p->lin_out_w) & 15) == 0 && (reinterpret_cast<size_t>(p->lin_out_b) & 15) == 0 &&
       (reinterpret_cast<size_t>(out) & 15) == 0) {
-    hipLaunchKernelGGL(k_lin_out_fwd, dim3(grid1d(P, 4, 1024)), dim3(256), 0, st, ws + w.x_last, p->lin_out_w, p->lin_out_b, P, ws + w.raw, out);
+    hipLaunchKernelGGL(k_lin_out_fwd, dim3(grid1d(P, 4, 1024)), dim3(256), 0, st, ws + w.x_last, p->lin_out_w, p->lin_out_b, P, ws + w.raw, out, gate);
   } else {
     if ((rc = lin(ws + w.x_last, kHidden, p->lin_out_w, p->lin_out_b, ws + w.raw, P, 4, kHidden, true, false))) return rc;
-    hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, P, 4, out);
+    hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, P, 4, out, gate);
   }
   DINER_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
+                                             const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
+  DINER_CHECK_ARG(scene && xyz && viewdirs && out && workspace && P > 0, "field_train_forward: bad arguments");
+  int rc = check_train_params(p, true);
+  if (rc) return rc;
+  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, stream, nullptr);
 }
 
 // ---- training forward on the INFERENCE kernels (round 5, experiment behind DINER_TRAIN_FUSED_FWD=1 of the Python host) ------------------
@@ -1336,7 +1357,9 @@ extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const Dine
 // lin_out and lin_out's raw outputs go to the SAME places of the workspace the layer-wise forward uses, so the backward is unchanged.  The
 // gather inputs (MLP inputs, tap rows / weights, interpolated latent) and the packed weights of the backward's products are made as before.
 // Needs the packed-weights handle of the step's weights and the latent map projected with them: made here into latent_proj_out (below), or
-// by the caller (diner_scene_prepare_f32 with THIS handle) when latent_proj_out is null.  No exact repeat: an activation beyond the fp16 range leaves a flag up (diner_field_train_fused_overflowed) instead.
+// by the caller (diner_scene_prepare_f32 with THIS handle) when latent_proj_out is null.  An activation beyond the fp16 range raises a flag
+// (diner_field_train_fused_overflowed reads it back: a test aid) and the layer-wise forward, enqueued behind the fused kernels and gated on that
+// flag, redoes the object -- no host synchronisation.
 int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs, long long P, float* out,
                        void* workspace, const SaveActs& sv, int** overflow_flag, hipStream_t stream);
 const float* mlp_hoist_bias(const DinerMlp* mlp);
@@ -1397,7 +1420,8 @@ extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, cons
   if ((rc = field_forward_save(&own, mlp, xyz, viewdirs, P, out, ws + w.dx, sv, &ovf, st))) return rc;
   hipLaunchKernelGGL(k_copy_flag, dim3(1), dim3(1), 0, st, ovf, reinterpret_cast<int*>(ws + w.flags) + kFlagFusedOvf);
   DINER_LAUNCH_OK();
-  return 0;
+  // the exact repeat, on the device: the layer-wise forward behind the flag (its ~25 launches return at once when it stayed down)
+  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, stream, reinterpret_cast<const int*>(ws + w.flags) + kFlagFusedOvf);
 }
 
 // 1 when the fused forward that filled `workspace` met an activation beyond the fp16 range (its saved activations are not usable), else 0;

@@ -154,6 +154,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   constexpr int kStepBytes = CT * NP * 1024 + kStepPad, kSlabBytes = kStepsPerSlab * kStepBytes;
   constexpr int NRT = 4 / FH, NF = NP * NRT;                 // MFMA row (= feature) tiles per wave, weight fragments per k16 step
   if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
+  if (a.gate2 && *a.gate2 == 0) return;
   if (a.skip && *a.skip != 0) {                              // f16x3 launch of a step whose weights do not fit: the bf16x6 twin works
     if (a.ovf && threadIdx.x == 0) {                         // (the forward's twin is gated on this product's flag)
       *a.ovf = 1;

@@ -33,6 +33,8 @@ struct Lin512Args {
   const float* bias2;        // 512 or null
   int relu2;                 // relu on the second segment's operand
   int* ovf2;                 // f16x3: a second flag raised together with ovf (the weight gradient of the fused layer looks at its own slot)
+  const int* gate2;          // null, or a second condition like gate (round 5: the layer-wise forward as the repeat behind the fused training forward --
+                             // its bf16x6 twins run only if the fused kernels left the range AND their own f16x3 product did)
 };
 
 // W (512, 512) row-major fp32 -> packed planes; transpose = 0: y = x W^T (W as nn.Linear stores it), 1: y = x W

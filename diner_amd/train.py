@@ -16,9 +16,9 @@ Here that is two `torch.autograd.Function`s whose forward AND backward are ONE c
     split-bf16 GEMM (`gemm`, `_linear`, `_linear_backward` below drive it from Python; the tests use them) for everything ragged.
 The forward (round 5) runs on the inference path's fused f16x3 kernels in their STORING variants (k_train_fwd_pre / k_train_fwd_post,
 diner_field_train_forward_fused_f32): activations stay on chip between the layers and every pre-activation the backward needs is written
-once; an activation beyond the fp16 range (flag, one 4-byte read back per object) or weights outside the fp16 split send the object to
-the layer-wise forward (diner_field_train_forward_f32: one product per launch, exact repeats on the device; DINER_TRAIN_FUSED_FWD=0
-makes it the only one).  Sizes: the shipped configs train SB = 4 objects x 4096 rays (a 64 x 64 patch: w_vgg != 0, diner.py:57) x 40 samples x
+once; an activation beyond the fp16 range raises a flag and the layer-wise forward enqueued behind the fused kernels (gated on the flag,
+no host synchronisation) redoes the object; weights outside the fp16 split go to the layer-wise forward at once
+(diner_field_train_forward_f32: one product per launch; DINER_TRAIN_FUSED_FWD=0 makes it the only one).  Sizes: the shipped configs train SB = 4 objects x 4096 rays (a 64 x 64 patch: w_vgg != 0, diner.py:57) x 40 samples x
 4 views = 655 k columns per object and step (configs/train_dtu.yaml:16,52-63); the workspace of saved activations is 94 KB per sample
 point = 14.7 GiB per object at that size (diner_field_train_workspace_bytes), four of them alive between forward and backward.
 """
@@ -122,8 +122,8 @@ def _param_struct(tensors, freq_factor=6.28):
 def fused_forward_enabled(P=None, scene=None):
     """DINER_TRAIN_FUSED_FWD: 1 = always, 0 = never, unset = by size.  The fused forward projects the WHOLE latent map through lin_z[0..2]
     (the inference path's hoist) where the layer-wise forward projects the P x NV gathered rows: it pays from about half a map of sample
-    points per object (the shipped 4096 rays x 40 samples: 3 maps' worth -- 156.1 -> 134.5 ms per four-object step; a 128-ray batch: a
-    tenth of a map, host-bound, 13.2 ms fused with its flag read back against 12.5 ms layer-wise: profiles/r05_train_fused_forward.txt)."""
+    points per object (the shipped 4096 rays x 40 samples: 3 maps' worth -- 157.0 -> 143.0 ms per four-object step; a 128-ray batch: a
+    tenth of a map: profiles/r05_train_fused_forward.txt)."""
     e = os.environ.get("DINER_TRAIN_FUSED_FWD", "")
     if e in ("0", "1"):
         return e == "1"
@@ -187,14 +187,8 @@ class FieldFunction(torch.autograd.Function):
                 rc = lib.diner_field_train_forward_fused_f32(scene.ref, mlp.handle, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P,
                                                              _ptr(out), _ptr(ws), _ptr(_proj_buffer(scene, dev)), _stream())
                 if rc != _lib.E_UNSUPPORTED:         # (weights outside the fp16 split, maps beyond 4 GiB: the layer-wise forward below)
-                    _lib.check(rc)
+                    _lib.check(rc)                   # (an activation beyond the fp16 range: the library's gated layer-wise repeat, on the device)
                     done = True
-                    if os.environ.get("DINER_TRAIN_FUSED_CHECK", "1") != "0":
-                        # the fused kernels have no exact repeat on the device: an activation beyond the fp16 range leaves a flag up and the
-                        # layer-wise forward (whose products repeat themselves in bf16x6) redoes the object -- one 4-byte read back per call
-                        ovf = C.c_int(0)
-                        _lib.check(lib.diner_field_train_fused_overflowed(_ptr(ws), P, NV, C.byref(ovf), _stream()))
-                        done = not ovf.value
             if not done:
                 _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
                                                              _ptr(ws), _stream()))

@@ -303,9 +303,10 @@ int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams
  * the layer-wise forward uses (diner_field_train_ws_layout), so that diner_field_train_backward_f32 follows unchanged.  `mlp`: the
  * packed-weights handle of THIS step's parameters.  latent_proj_out (diner_scene_proj_bytes; free again when the call's work is done):
  * the library projects scene->latent_cl through lin_z[0..2] into it on the training products' kernel (f16x3 with its bf16x6 repeat)
- * and gathers from it; NULL: `scene->latent_proj` prepared with `mlp` (diner_scene_prepare_f32) is used.  No exact repeat of the field:
- * diner_field_train_fused_overflowed reports (after a stream wait) whether an activation left the fp16 range (pixelnerf.py:55-145,
- * resnetfc.py:129-159 as diner_field_train_forward_f32). */
+ * and gathers from it; NULL: `scene->latent_proj` prepared with `mlp` (diner_scene_prepare_f32) is used.  The exact repeat is the layer-wise
+ * forward, enqueued by this call behind the fused kernels and gated on their range flag (no host synchronisation);
+ * diner_field_train_fused_overflowed reads that flag back after a stream wait (a test aid).  DINER_E_UNSUPPORTED (weights outside the fp16
+ * split, a projected map of 4 GiB or more): call diner_field_train_forward_f32 (pixelnerf.py:55-145, resnetfc.py:129-159). */
 int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
                                         const float* viewdirs, long long P, float* out, void* workspace, float* latent_proj_out,
                                         void* stream);

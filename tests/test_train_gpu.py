@@ -482,6 +482,12 @@ def test_training_forward_beyond_the_fp16_range(ops, fused, monkeypatch):
     params, names = module_param_list(big)
     out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
     assert torch.isfinite(out).all()
+    if fused:       # the fused kernels did raise their flag: what is compared below is the gated layer-wise repeat
+        import ctypes as C
+        from diner_amd import _lib
+        ovf = C.c_int(0)
+        _lib.check(_lib.load().diner_field_train_fused_overflowed(out.grad_fn.saved_tensors[0].data_ptr(), P, 4, C.byref(ovf), None))
+        assert ovf.value == 1
     e_fwd = float((out.detach().cpu() - out_o).abs().max())          # sigmoid / relu outputs of O(1) .. O(1e5): absolute on rgb, relative on sigma
     (out * G.cuda()).sum().backward()
     worst = 0.0
