@@ -304,6 +304,8 @@ struct SaveActs {
   float* H[5];
   float* x_last;
   float* raw;
+  unsigned* bX[5];     // the relu decisions of X[b] / H[b] as bits, 16 dwords per row (train_lin512.hpp, Lin512Args.maskbits)
+  unsigned* bH[5];
 };
 struct PostArgs {
   const float* xpre;

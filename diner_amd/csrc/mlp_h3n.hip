@@ -203,7 +203,6 @@ struct Args {
   unsigned long long* prof;   // DINER_HN_PROF builds: 32 phase counters (shader clocks summed over waves), else unused
   unsigned* tile_counter;     // 8 counters (one per XCD queue), zeroed per launch: see TileQueue
   QueueMap qmap;              // which tiles a queue holds (h3n_launch_pre fills it in)
-  SaveActs sv;                // k_train_fwd_pre only
 };
 
 struct TileQueue {
@@ -934,14 +933,20 @@ struct GatherSideH {
 
 // one accumulator block (this wave's 128 features x the 64 columns of the tile) -> a saved activation tensor (see SaveActs), x 1/16;
 // column group g is view g (per-view kernel: rows g P + p) or the g-th 16-point tile of the workgroup's 64 points (post kernel: rows p)
+// bits: the relu decisions of the same values, one dword per lane and row -- the lane's 32 features 16 mo + 4 q + i of the wave's slice at bit
+// 4 mo + i, dword 4 wave + q of the row's 16 (the layout the training data gradients read, Lin512Args.maskbits)
 template <bool PER_VIEW>
-__device__ __forceinline__ void save_block(float* __restrict__ dst, long long P, long long tile, int wave, int lane, const f32x4 (&acc)[kSlice][kGroups]) {
+__device__ __forceinline__ void save_block(float* __restrict__ dst, unsigned* __restrict__ bits, long long P, long long tile, int wave, int lane,
+                                           const f32x4 (&acc)[kSlice][kGroups]) {
+  static_assert(kSlice == 8, "one dword of decisions per lane");
   const int q = lane >> 4, n = lane & 15;
 #pragma unroll
   for (int g = 0; g < kGroups; ++g) {
     const long long p = PER_VIEW ? tile * kPtsPerWave + n : (tile * 4 + g) * kPtsPerWave + n;
     if (p >= P) continue;
-    float* row = dst + ((PER_VIEW ? (size_t)g * P : (size_t)0) + (size_t)p) * kHidden + 128 * wave + 4 * q;
+    const size_t r = (PER_VIEW ? (size_t)g * P : (size_t)0) + (size_t)p;
+    float* row = dst + r * kHidden + 128 * wave + 4 * q;
+    unsigned m = 0;
 #pragma unroll
     for (int mo = 0; mo < kSlice; ++mo) {
       f32x4 v;
@@ -950,14 +955,16 @@ __device__ __forceinline__ void save_block(float* __restrict__ dst, long long P,
         int xi;
         asm("v_accvgpr_read_b32 %0, %1" : "=v"(xi) : "a"(acc[mo][g][i]));
         v[i] = __int_as_float(xi) * kInvScale;
+        m |= (v[i] > 0.0f ? 1u : 0u) << (4 * mo + i);
       }
       *reinterpret_cast<f32x4*>(row + 16 * mo) = v;
     }
+    if (bits) bits[r * 16 + 4 * wave + q] = m;
   }
 }
 
 template <bool LO, bool SAVE>
-__device__ __forceinline__ void field_pre_body(const SceneDev& sc, const Args& a) {
+__device__ __forceinline__ void field_pre_body(const SceneDev& sc, const Args& a, const SaveActs& sv) {
   constexpr int kRing = LO ? DINER_HN_RING : DINER_HN_RING_F16, kRing0 = LO ? DINER_HN_RING0 : DINER_HN_RING0_F16;
   constexpr int kGDepth = LO ? DINER_HN_GDEPTH : DINER_HN_GDEPTH_F16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1056,13 +1063,13 @@ __device__ __forceinline__ void field_pre_body(const SceneDev& sc, const Args& a
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
       const float* bias = a.b + kHidden * (1 + 2 * b);
-      if constexpr (SAVE) save_block<true>(a.sv.X[b], fa.P, tile, wave, lane, xs);
+      if constexpr (SAVE) save_block<true>(sv.X[b], sv.bX[b], fa.P, tile, wave, lane, xs);
       {
         NoSide none;
         publish_gemm<kRing0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
             w_blk + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] { set_bias(ns, bias, wave, q); }, pf, 6);
       }
-      if constexpr (SAVE) save_block<true>(a.sv.H[b], fa.P, tile, wave, lane, ns);
+      if constexpr (SAVE) save_block<true>(sv.H[b], sv.bH[b], fa.P, tile, wave, lane, ns);
       // the next block's lin_z contribution rides on the fc_1 GEMM (additions into xs commute); this block's fc_1 bias comes with it
       // (folded into the projected map's bias when the weights are packed, mlp.hip)
       const _Float16* w1 = w_blk + (size_t)(2 * b + 1) * kLayerHalfs;
@@ -1090,10 +1097,10 @@ __device__ __forceinline__ void field_pre_body(const SceneDev& sc, const Args& a
     {   // block 2: no gather left (and its fc_1 bias is added by the post kernel)
       const float* bias = a.b + kHidden * 5;
       NoSide none;
-      if constexpr (SAVE) save_block<true>(a.sv.X[2], fa.P, tile, wave, lane, xs);
+      if constexpr (SAVE) save_block<true>(sv.X[2], sv.bX[2], fa.P, tile, wave, lane, xs);
       publish_gemm<kRing0, LO, DINER_HN_EARLYA != 0, DINER_HN_OWN != 0>(
           w_blk + (size_t)4 * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] { set_bias(ns, bias, wave, q); }, pf, 6);
-      if constexpr (SAVE) save_block<true>(a.sv.H[2], fa.P, tile, wave, lane, ns);
+      if constexpr (SAVE) save_block<true>(sv.H[2], sv.bH[2], fa.P, tile, wave, lane, ns);
       publish_gemm<kRing, LO, DINER_HN_EARLY1 != 0, DINER_HN_OWN != 0>(w_blk + (size_t)5 * kLayerHalfs, Bl, wave, lane, ns, xs, none,
                                                                 [&] { pin_acc(xs); }, pf, 10);
     }
@@ -1107,9 +1114,9 @@ __device__ __forceinline__ void field_pre_body(const SceneDev& sc, const Args& a
   pf.end(a.prof, lane);
 }
 template <bool LO>
-__global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) { field_pre_body<LO, false>(sc, a); }
+__global__ __launch_bounds__(256, 1) void k_field_pre_h3n(SceneDev sc, Args a) { field_pre_body<LO, false>(sc, a, SaveActs{}); }
 // the same kernel storing the pre-activations of blocks 0-2 (training forward, DINER_TRAIN_FUSED_FWD)
-__global__ __launch_bounds__(256, 1) void k_train_fwd_pre(SceneDev sc, Args a) { field_pre_body<true, true>(sc, a); }
+__global__ __launch_bounds__(256, 1) void k_train_fwd_pre(SceneDev sc, Args a, SaveActs sv) { field_pre_body<true, true>(sc, a, sv); }
 
 // =====================================================================================================================================
 // Round 5: the plain-fp16 per-view kernel with EIGHT waves per workgroup (two per SIMD): k_field_pre_h8.
@@ -1936,7 +1943,6 @@ struct PostArgsN {
   unsigned long long* prof; // DINER_HN_PROF builds: phase counters, else unused
   unsigned* tile_counter;   // see TileQueue
   QueueMap qmap;            // the default map (tile % 8): the post kernel's tiles are 64 consecutive points, no taps
-  SaveActs sv;              // k_train_fwd_post only
 };
 
 // The lane index, opaque to the optimiser: what is derived from it is derived at the point of use.  (Lane-derived values hoisted out
@@ -1950,7 +1956,7 @@ __device__ __forceinline__ int lane_here() {
 // Blocks 3-4 + lin_out + output activations on the view-averaged hidden state, same feature-sliced scheme: a
 // workgroup takes 64 points (four 16-point tiles = the four column groups), wave w owns features [128 w, 128 w + 128).
 template <bool LO, bool SAVE>
-__device__ __forceinline__ void field_post_body(const PostArgsN& a) {
+__device__ __forceinline__ void field_post_body(const PostArgsN& a, const SaveActs& sv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   h8* B = reinterpret_cast<h8*>(smem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2017,20 +2023,20 @@ __device__ __forceinline__ void field_post_body(const PostArgsN& a) {
 #pragma nounroll
     for (int b = 0; b < 2; ++b) {
       const float* bias = bpost + 2 * kHidden * b;
-      if constexpr (SAVE) save_block<false>(a.sv.X[3 + b], pa.P, tile, wave, lane_here(), xs);
+      if constexpr (SAVE) save_block<false>(sv.X[3 + b], sv.bX[3 + b], pa.P, tile, wave, lane_here(), xs);
       publish_gemm<(LO ? DINER_HN_RING0 : DINER_HN_RING0_F16), LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0>(a.w + (size_t)(2 * b) * kLayerHalfs, Bl, wave, lane, xs, ns, none, [&] {
         set_bias(ns, bias, wave, lane_here() >> 4);
         pin_acc(xs);                              // the residual stream stays in registers across the fc_0 GEMM
       }, pf, 0);
       if (b == 0) tq.park(&s_tile2[par]);           // (the request went out at the top of the tile)
-      if constexpr (SAVE) save_block<false>(a.sv.H[3 + b], pa.P, tile, wave, lane_here(), ns);
+      if constexpr (SAVE) save_block<false>(sv.H[3 + b], sv.bH[3 + b], pa.P, tile, wave, lane_here(), ns);
       pin_acc(xs);
       publish_gemm<(LO ? DINER_HN_RING : DINER_HN_RING_F16), LO, DINER_HN_EARLYP != 0, DINER_HN_OWN != 0, false>(a.w + (size_t)(2 * b + 1) * kLayerHalfs, Bl, wave, lane, ns, xs, none,
                                       [&] { add_bias(xs, bias + kHidden, wave, lane_here() >> 4); }, pf, 4);
     }
 #if DINER_HN_LINOUT_VALU
     pin_acc(xs);                                  // (else the block is copied to vector registers here and back for the reads below)
-    if constexpr (SAVE) save_block<false>(a.sv.x_last, pa.P, tile, wave, lane_here(), xs);
+    if constexpr (SAVE) save_block<false>(sv.x_last, nullptr, pa.P, tile, wave, lane_here(), xs);
     // ---- lin_out on relu(x), fp32 on the vector ALU straight from the accumulators: a lane holds 4 features x 4 columns of each of its 8
     // row tiles; 512 fused multiply-adds give its share of the four outputs of its four columns, two shuffles sum the four feature
     // quarters, 4 KB of LDS the four waves.  (Until round 3 the block was published to LDS as fp16 hi / lo like a hidden layer and
@@ -2166,7 +2172,7 @@ __device__ __forceinline__ void field_post_body(const PostArgsN& a) {
         // point as inf / NaN (so does a non-finite input): raise the flag that un-gates the exact-fp32 pass (mlp.hip).
         const float probe = (res[0] - res[0]) + (res[1] - res[1]) + (res[2] - res[2]) + (res[3] - res[3]);   // 0 or NaN
         if (pa.overflow && (probe != 0.0f || wave_bad)) *pa.overflow = 1;
-        if constexpr (SAVE) reinterpret_cast<f32x4*>(a.sv.raw)[p] = res;      // lin_out's outputs in front of the activations
+        if constexpr (SAVE) reinterpret_cast<f32x4*>(sv.raw)[p] = res;      // lin_out's outputs in front of the activations
         if (!pa.raw) {
           res[0] = 1.0f / (1.0f + expf(-res[0]));
           res[1] = 1.0f / (1.0f + expf(-res[1]));
@@ -2183,9 +2189,9 @@ __device__ __forceinline__ void field_post_body(const PostArgsN& a) {
   pf.end(a.prof, lane);
 }
 template <bool LO>
-__global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) { field_post_body<LO, false>(a); }
+__global__ __launch_bounds__(256, 1) void k_field_post_h3n(PostArgsN a) { field_post_body<LO, false>(a, SaveActs{}); }
 // the same kernel storing the pre-activations of blocks 3-4, the stream entering lin_out and lin_out's raw outputs (training forward)
-__global__ __launch_bounds__(256, 1) void k_train_fwd_post(PostArgsN a) { field_post_body<true, true>(a); }
+__global__ __launch_bounds__(256, 1) void k_train_fwd_post(PostArgsN a, SaveActs sv) { field_post_body<true, true>(a, sv); }
 
 // Round 5: the post kernel of the plain-fp16 mode on eight waves (two per SIMD), the scheme of k_field_pre_h8: wave w owns features
 // [64 w, 64 w + 64) of the 64 points of a tile (four 16-point tiles = the four column groups); two B buffers, one barrier per layer; lin_out
@@ -2539,8 +2545,7 @@ void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, con
   a.prof = prof;
 #endif
   if (sv) {          // training forward: the f16x3 kernel storing the pre-activations
-    a.sv = *sv;
-    hipLaunchKernelGGL(h3n::k_train_fwd_pre, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
+    hipLaunchKernelGGL(h3n::k_train_fwd_pre, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a, *sv);
   } else if (split && use_w8x) hipLaunchKernelGGL(h3n::w8::k_field_pre_h8x, dim3(grid), dim3(512), h3n::w8::kLdsBytes8x, stream, sc, a);
   else if (split) hipLaunchKernelGGL(h3n::k_field_pre_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytes, stream, sc, a);
   else if (use_w8) hipLaunchKernelGGL(h3n::w8::k_field_pre_h8, dim3(grid), dim3(512), h3n::w8::kLdsBytes8, stream, sc, a);
@@ -2579,8 +2584,7 @@ void h3n_launch_post(const PostArgs& pa, const float* w, const float* w_lin_out,
   a.prof = prof;
 #endif
   if (sv) {
-    a.sv = *sv;
-    hipLaunchKernelGGL(h3n::k_train_fwd_post, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
+    hipLaunchKernelGGL(h3n::k_train_fwd_post, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a, *sv);
   } else if (split) hipLaunchKernelGGL(h3n::k_field_post_h3n<true>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);
   else if (use_w8) hipLaunchKernelGGL(h3n::w8::k_field_post_h8, dim3(grid), dim3(512), h3n::w8::kLdsBytesPost8, stream, a);
   else hipLaunchKernelGGL(h3n::k_field_post_h3n<false>, dim3(grid), dim3(256), h3n::kLdsBytesPost, stream, a);

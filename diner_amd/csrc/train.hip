@@ -658,6 +658,29 @@ __global__ __launch_bounds__(256) void k_cl_to_nchw(const float* __restrict__ sr
     if (c0 + r < C && p0 + tx < HW) dst[img + (size_t)(c0 + r) * HW + p0 + tx] = tile[tx][r];
 }
 
+// relu decisions of (rows, 512) pre-activations as bits in the layout Lin512Args.maskbits names: one thread per dword = 32 features
+// 128 s + 16 mo + 4 q + i (s = dword / 4, q = dword % 4; bit 4 mo + i) -- eight 16-byte reads; blockIdx.y = tensor
+struct MakeBits { const float* src[10]; unsigned* dst[10]; long long rows[10]; };
+__global__ void k_make_bits(MakeBits m, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
+  const float* __restrict__ src = m.src[blockIdx.y];
+  unsigned* __restrict__ dst = m.dst[blockIdx.y];
+  const long long n = m.rows[blockIdx.y] * 16;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i >> 4;
+    const int d = (int)(i & 15), s = d >> 2, q = d & 3;
+    const float* x = src + (size_t)row * kHidden + 128 * s + 4 * q;
+    unsigned bits = 0;
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + 16 * mo);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bits |= (v[c] > 0.0f ? 1u : 0u) << (4 * mo + c);
+    }
+    dst[i] = bits;
+  }
+}
+
 // y[p][c] = mean_v x[v][p][c]   (combine_interleaved, resnetfc.py:150-152); adjoint: dx[v][p][c] = dy[p][c] / nv
 __global__ void k_view_mean(const float* __restrict__ x, int nv, long long PC, float* __restrict__ y, const int* __restrict__ gate = nullptr) {
   if (gate && *gate == 0) return;
@@ -1057,8 +1080,8 @@ constexpr int kWPackSlots = 4 * 13;      // forward, transposed (bf16x6); forwar
 enum { kFlagWBad = 13, kAmax0 = 32, kFlagInts = 128 };
 enum { kSlotFc0 = 0, kSlotFc1 = 5, kSlotLinZ = 10 };
 struct TrainWs {               // float offsets into the workspace
-  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, wgpart, flags, total;
-};
+  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, wgpart, flags, bX[5], bH[5], total;
+};      // bX / bH (round 5): the relu decisions of X[b] / H[b] as bits, 16 dwords per row (Lin512Args.maskbits): what the data gradients read
 TrainWs train_ws(long long P, int nv) {
   TrainWs w;
   const size_t cols = (size_t)P * nv;
@@ -1082,6 +1105,11 @@ TrainWs train_ws(long long P, int nv) {
   w.wpack = take(kWPackSlots * (kL512PackBytes / sizeof(float)));      // packed 512 x 512 weights of train_lin512.hip
   w.wgpart = take(13 * (wgrad512_part_bytes() / sizeof(float)));     // per-chunk partial weight gradients of the 13 512 x 512 layers (train_wgrad512.hip)
   w.flags = take(kFlagInts);                                       // flag block (ints), see kFlagWBad
+  for (int b = 0; b < 5; ++b) {
+    const size_t m = b < 3 ? cols : (size_t)P;
+    w.bX[b] = take(m * 16);
+    w.bH[b] = take(m * 16);
+  }
   w.total = o;
   return w;
 }
@@ -1133,7 +1161,8 @@ struct BwdArith {
 // adjoint of y = act(x) W^T + b: dW = dy^T act(x) (split-K atomics into zeroed dW), db = column sums, dx (+)= (dy W) [masked]
 int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, const float* W, float* dW, float* db,
                long long M, int N, int K, float* dx, const float* dx_mask, bool dx_accum, hipStream_t st,
-               const void* Wt_packed = nullptr, float* wgpart = nullptr, WgReduceJob* defer = nullptr, const BwdArith* f16 = nullptr) {
+               const void* Wt_packed = nullptr, float* wgpart = nullptr, WgReduceJob* defer = nullptr, const BwdArith* f16 = nullptr,
+               const unsigned* dx_maskbits = nullptr) {      // dx_maskbits: the decisions of dx_mask as bits, read instead of it by the 512-kernels
   // split-K so that the 16 output tiles of a 512 x 512 weight gradient become 500-1000 workgroups of >= 15 k-tiles each (measured:
   // 128 / 512 / 2048-ray steps 5.70 / 15.6 / 53.1 ms with M / 1024 capped at 32, 5.07 / 14.5 / 51.8 ms with M / 480 capped at 64);
   // round 3: M / 640 -- the row-sum instance of the kernel runs two workgroups per CU, 16 tiles x 32 chunks fill the chip once for the
@@ -1160,6 +1189,7 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
     static const bool one_launch = [] { const char* e = getenv("DINER_TRAIN_BWD_FUSED"); return !(e && *e == '0'); }();
     const bool dgrad512 = dx && Wt_packed && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask);
     Lin512Args da{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+    if (dx_maskbits) { da.mask = nullptr; da.maskbits = dx_maskbits; }
     if (f16 && wgpart && defer && one_launch && (dgrad512 || !dx)) {
       // the f16x3 launch (works unless a flag is up) and its bf16x6 twin (works only then); an accumulating data gradient is safe: exactly
       // one of the two runs, decided by a flag that does not change during the step
@@ -1206,6 +1236,7 @@ int linear_bwd(const float* dy, int ldy, const float* x, int ldx, bool relu_in, 
   if (dx && Wt_packed && N == 512 && K == 512 && lin512_ok(dy, ldy, dx, K, nullptr, dx_mask)) {
     // dx = dy W on the feature-sliced kernel (train_lin512.hip): D[k][row] = sum_f W[f][k] dy[row][f], W packed transposed
     Lin512Args a{dy, Wt_packed, dx, nullptr, nullptr, dx_mask, M, ldy, K, dx_accum ? kL512Accum : 0};
+    if (dx_maskbits) { a.mask = nullptr; a.maskbits = dx_maskbits; }
     if (f16) a.amax_out = f16->amax_dx;            // (fewer than 256 rows or an odd alignment: bf16x6 here, the consumers may still run f16x3)
     return lin512_launch(a, st);
   }
@@ -1338,6 +1369,15 @@ static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, c
     if ((rc = lin(ws + w.x_last, kHidden, p->lin_out_w, p->lin_out_b, ws + w.raw, P, 4, kHidden, true, false))) return rc;
     hipLaunchKernelGGL(k_field_act, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, P, 4, out, gate);
   }
+  {   // the relu decisions of the ten saved pre-activations as bits, for the backward's data gradients (the fused forward writes them itself)
+    MakeBits mb;
+    for (int b = 0; b < 5; ++b) {
+      const long long m = b < 3 ? cols : P;
+      mb.src[2 * b] = ws + w.X[b];      mb.dst[2 * b] = reinterpret_cast<unsigned*>(ws + w.bX[b]);      mb.rows[2 * b] = m;
+      mb.src[2 * b + 1] = ws + w.H[b];  mb.dst[2 * b + 1] = reinterpret_cast<unsigned*>(ws + w.bH[b]);  mb.rows[2 * b + 1] = m;
+    }
+    hipLaunchKernelGGL(k_make_bits, dim3(grid1d(cols * 16, 256, 2048), 10), dim3(256), 0, st, mb, gate);
+  }
   DINER_LAUNCH_OK();
   return 0;
 }
@@ -1415,6 +1455,7 @@ extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, cons
   for (int b = 0; b < 5; ++b) { sv.X[b] = ws + w.X[b]; sv.H[b] = ws + w.H[b]; }
   sv.x_last = ws + w.x_last;
   sv.raw = ws + w.raw;
+  for (int b = 0; b < 5; ++b) { sv.bX[b] = reinterpret_cast<unsigned*>(ws + w.bX[b]); sv.bH[b] = reinterpret_cast<unsigned*>(ws + w.bH[b]); }
   int* ovf = nullptr;
   // hand-over + tile counters of the two kernels: the backward's dx buffer is free in the forward (8 KB per point; 2 KB + flags needed)
   if ((rc = field_forward_save(&own, mlp, xyz, viewdirs, P, out, ws + w.dx, sv, &ovf, st))) return rc;
@@ -1488,6 +1529,10 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
     // (lin_out off its skinny kernel -- a weight or d_out that is not 16-byte aligned: the general path keeps no maximum of dx)
     if (bwd16) hipLaunchKernelGGL(k_absmax, dim3(grid1d(P * (long long)kHidden)), dim3(256), 0, st, dx, P * (long long)kHidden, amax + 0);
   }
+  // round 5: the data gradients of the 512-kernels read the relu decisions as bits (64 B per row instead of 2 KB; DINER_TRAIN_MASKBITS=0: the
+  // saved pre-activations themselves, A/B measurement)
+  static const bool maskbits_on = [] { const char* e = getenv("DINER_TRAIN_MASKBITS"); return !(e && *e == '0'); }();
+  auto bits = [&](size_t off) { return maskbits_on ? reinterpret_cast<const unsigned*>(ws + off) : nullptr; };
   for (int b = 4; b >= 0; --b) {
     const long long M = b < 3 ? cols : P;
     const float* X = ws + w.X[b];
@@ -1495,11 +1540,11 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
     const int a_h = a_next++;                                 // dH = (dx W1) masked
     if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
                          kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job(),
-                         arith(kSlotFc1 + b, a_cur, a_h)))) return rc;
+                         arith(kSlotFc1 + b, a_cur, a_h), bits(w.bH[b])))) return rc;
     const int a_x = a_next++;                                 // dx += (dH W0) masked
     if ((rc = linear_bwd(dH, kHidden, X, kHidden, true, p->fc0_w[b], (float*)grads->fc0_w[b], (float*)grads->fc0_b[b], M,
                          kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b), part(kSlotFc0 + b), job(),
-                         arith(kSlotFc0 + b, a_h, a_x)))) return rc;
+                         arith(kSlotFc0 + b, a_h, a_x), bits(w.bX[b])))) return rc;
     a_cur = a_x;
     if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
                                   (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st,

@@ -104,6 +104,7 @@ void plan_lin512(const Lin512Args& a, int cus, Run512* r, bool f16 = false) {
     b.Y += (size_t)row0 * a.ldy;
     if (a.resid) b.resid += (size_t)row0 * a.ldy;
     if (a.mask) b.mask += (size_t)row0 * a.ldy;
+    if (a.maskbits) b.maskbits += (size_t)row0 * 16;
     if (a.resid2) b.resid2 += (size_t)row0 * a.ldy;
     if (a.X2) b.X2 += (size_t)row0 * a.ldx;
     b.M = rows;

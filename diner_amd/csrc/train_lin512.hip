@@ -423,6 +423,19 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
           for (int c = 0; c < 4; ++c) v[n][c] = m[c] > 0.0f ? v[n][c] : 0.0f;
         }
       }
+      if (a.maskbits) {
+        // one 16-byte load per row: the 128 decisions of the wave's feature slice; v[n][c] is feature 32 (rt0 + rt) + 8 q4 + 4 h + c of it
+        // (n = 4 rt + q4, h = lane / 32): dword 2 (q4 % 2) + h, bit 8 (rt0 + rt) + 4 (q4 / 2) + c
+        const u32x4 mb = *reinterpret_cast<const u32x4*>(a.maskbits + (size_t)row * 16 + 4 * wslice);
+        const bool hi = lane >= 32;
+        const unsigned m0 = (hi ? mb[1] : mb[0]) >> (8 * rt0), m1 = (hi ? mb[3] : mb[2]) >> (8 * rt0);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+          const unsigned m = (n & 1) ? m1 : m0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[n][c] = ((m >> (8 * (n >> 2) + 4 * ((n & 3) >> 1) + c)) & 1u) ? v[n][c] : 0.0f;
+        }
+      }
       if (a.flags & kL512Accum) {
 #pragma unroll
         for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3));

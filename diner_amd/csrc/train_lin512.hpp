@@ -33,6 +33,9 @@ struct Lin512Args {
   const float* bias2;        // 512 or null
   int relu2;                 // relu on the second segment's operand
   int* ovf2;                 // f16x3: a second flag raised together with ovf (the weight gradient of the fused layer looks at its own slot)
+  const unsigned* maskbits;  // null, or (instead of mask) the relu decisions of the saved pre-activation as bits: 16 dwords per row (round 5;
+                             // written by the forward -- save_block of mlp_h3n.hip / k_make_bits of train.hip: feature f of the row sits in
+                             // dword 4 (f / 128) + (f % 16) / 4 at bit 4 ((f % 128) / 16) + f % 4); Y = 0 where the bit is down
   const int* gate2;          // null, or a second condition like gate (round 5: the layer-wise forward as the repeat behind the fused training forward --
                              // its bf16x6 twins run only if the fused kernels left the range AND their own f16x3 product did)
 };

@@ -280,8 +280,9 @@ def test_no_spill_code_in_the_training_kernels(tmp_path):
             # round 4: the 128-row shape of the f16x3 bodies (256 accumulator registers) keeps ~10 loop-invariant scalars-in-VGPRs (row
             # strides, epilogue pointers) in scratch: stored once in front of the tile loop, reloaded in the epilogue -- none of it inside the
             # slab loop (no spill / reload is interleaved with MFMAs).  Bounded here.
-            # round 5: the counts are pinned -- 35 / 49 with hipcc of ROCm 7.2 -- so that drift is visible
-            assert len(spills) <= {"k_fwd512_f16x3": 35, "k_run512_f16x3": 49}[name], (name, len(spills))
+            # round 5: the counts are pinned -- 40 / 54 with hipcc of ROCm 7.2 (35 / 49 before the bit-mask branch of the epilogue,
+            # which keeps one more pointer) -- so that drift is visible
+            assert len(spills) <= {"k_fwd512_f16x3": 40, "k_run512_f16x3": 54}[name], (name, len(spills))
             for i, l in enumerate(body):
                 if "scratch_" in l:      # not interleaved with MFMAs: none within 25 instructions on BOTH sides
                     before = any("v_mfma" in x for x in body[max(0, i - 25):i])

@@ -81,10 +81,13 @@ def _oracle_grads(scene, w, xyz, dirs, G, relu_masks=None):
     return out.detach(), scene.latent.grad, {(k, i): t.grad for k, i, t in names}
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["layerwise", "fused_forward"])
-@pytest.mark.parametrize("P", [200, 5120])
+@pytest.mark.parametrize("P,fused", [(200, False), (200, True), (5120, False), (5120, True), (20480, True)],
+                         ids=["200-layerwise", "200-fused_forward", "5120-layerwise", "5120-fused_forward", "20480-fused_forward"])
 def test_field_forward_and_backward_against_oracle_autograd(ops, P, fused, monkeypatch):
-    """P = 200: 800 / 200 rows per layer (the general kernel serves the post-mean layers).  P = 5120: the reference training batch's row
+    """P = 20480 (round 5): 512 rays x 40 samples = 81920 rows per view layer -- whole rounds of 128-row tiles + a
+    ragged rest in the f16x3 backward, the 256 x 256 weight-gradient tiles over 64 row chunks and the fused forward at a size where every
+    CU owns several tiles, against the ORACLE's autograd (until now these launch shapes were tied to it only through HIP-vs-HIP sums).
+    P = 200: 800 / 200 rows per layer (the general kernel serves the post-mean layers).  P = 5120: the reference training batch's row
     counts (128 rays x 40 samples: 20480 rows per view layer, 5120 behind the view mean) -- the launch plans of k_run512 that the timing
     runs use: one round of 64-row tiles + shared 32-row tiles, the weight-gradient product in the same launch, the deferred summing pass."""
     from diner_amd import train
