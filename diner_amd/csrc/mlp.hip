@@ -994,7 +994,9 @@ int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float
   const int grid_pre = (int)(n_t16 < cus ? n_t16 : cus);
   const long long n_tiles = (n_t16 + 3) / 4;
   const int grid_post = (int)(n_tiles < cus ? n_tiles : cus);
-  h3n_launch_pre(sd, fa, im->hn_w, im->hn_b_pre, grid_pre, true, reinterpret_cast<unsigned*>(flag) + 8, stream, &sv);
+  // DINER_TRAIN_NOSAVE=1 (timing aid, WRONG gradients): the per-view kernel without its stores -- what the saved tensors cost
+  static const bool nosave = [] { const char* e = getenv("DINER_TRAIN_NOSAVE"); return e && *e == '1'; }();
+  h3n_launch_pre(sd, fa, im->hn_w, im->hn_b_pre, grid_pre, true, reinterpret_cast<unsigned*>(flag) + 8, stream, nosave ? nullptr : &sv);
   DINER_LAUNCH_OK();
   PostArgs pn{(const float*)workspace, im->w_post, im->hn_b_post, out, P, sd.nv, 0, nullptr, flag, im->fallback_dev};
   h3n_launch_post(pn, im->hn_w, im->hn_w_out, grid_post, true, reinterpret_cast<unsigned*>(flag) + 16, stream, &sv);
