@@ -93,7 +93,12 @@ SIGNATURES = {
     "diner_field_inputs_generic_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "diner_field_train_forward_fused_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.POINTER(DinerMlpParams), C.c_void_p, C.c_void_p,
-                                                      C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                                      C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_train_workspace_split": (C.c_int, [C.c_longlong, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "diner_field_train_forward_s_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams), C.c_void_p, C.c_void_p,
+                                                  C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_train_backward_s_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams), C.POINTER(DinerMlpParams),
+                                                   C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_train_fused_overflowed": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "diner_quantize_rgb_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_minmax_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),

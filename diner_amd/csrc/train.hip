@@ -1080,8 +1080,10 @@ constexpr int kWPackSlots = 4 * 13;      // forward, transposed (bf16x6); forwar
 enum { kFlagWBad = 13, kAmax0 = 32, kFlagInts = 128 };
 enum { kSlotFc0 = 0, kSlotFc1 = 5, kSlotLinZ = 10 };
 struct TrainWs {               // float offsets into the workspace
-  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, d_raw, dx, dH, d_lat, wpack, wgpart, flags, bX[5], bH[5], total;
-};      // bX / bH (round 5): the relu decisions of X[b] / H[b] as bits, 16 dwords per row (Lin512Args.maskbits): what the data gradients read
+  size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, wpack, flags, bX[5], bH[5], saved_total, d_raw, dx, dH, d_lat, wgpart, total;
+};      // [0, saved_total): what the forward leaves for the backward; [saved_total, total): work buffers of either call, nothing in them lives
+        // from the forward to the backward (round 5: they may sit in a buffer of their own that the objects of a step share -- `scratch` of
+        // the _s entry points; one workspace: they follow the saved part).  bX / bH (round 5): the relu decisions of X[b] / H[b] as bits, 16 dwords per row (Lin512Args.maskbits): what the data gradients read
 TrainWs train_ws(long long P, int nv) {
   TrainWs w;
   const size_t cols = (size_t)P * nv;
@@ -1098,21 +1100,24 @@ TrainWs train_ws(long long P, int nv) {
   }
   w.x_last = take((size_t)P * kHidden);
   w.raw = take((size_t)P * 4);
-  w.d_raw = take((size_t)P * 4);
-  w.dx = take(cols * kHidden);
-  w.dH = take(cols * kHidden);
-  w.d_lat = take(cols * kLatent);
   w.wpack = take(kWPackSlots * (kL512PackBytes / sizeof(float)));      // packed 512 x 512 weights of train_lin512.hip
-  w.wgpart = take(13 * (wgrad512_part_bytes() / sizeof(float)));     // per-chunk partial weight gradients of the 13 512 x 512 layers (train_wgrad512.hip)
   w.flags = take(kFlagInts);                                       // flag block (ints), see kFlagWBad
   for (int b = 0; b < 5; ++b) {
     const size_t m = b < 3 ? cols : (size_t)P;
     w.bX[b] = take(m * 16);
     w.bH[b] = take(m * 16);
   }
+  w.saved_total = o;
+  w.d_raw = take((size_t)P * 4);
+  w.dx = take(cols * kHidden);
+  w.dH = take(cols * kHidden);
+  w.d_lat = take(cols * kLatent);
+  w.wgpart = take(13 * (wgrad512_part_bytes() / sizeof(float)));     // per-chunk partial weight gradients of the 13 512 x 512 layers (train_wgrad512.hip)
   w.total = o;
   return w;
 }
+// base pointer for the work buffers' offsets: `scratch` (a buffer of its own, diner_field_train_workspace_split) or the workspace itself
+float* scratch_base(float* ws, void* scratch, const TrainWs& w) { return scratch ? (float*)scratch - w.saved_total : ws; }
 int check_train_params(const DinerMlpParams* p, bool poscode) { return check_mlp_config(p, "field_train", poscode); }
 // DINER_TRAIN_LIN512=0 routes the 512 x 512 layer products back to the general kernel (A/B measurement)
 bool use_lin512() {
@@ -1270,11 +1275,12 @@ extern "C" int diner_field_train_ws_layout(long long P, int nv, long long* float
 // The layer-wise forward.  gate != null: the repeat behind the fused forward (below) -- inputs, packed weights and the flag block are in
 // place, every launch returns at once unless *gate != 0 (the fused kernels met an activation beyond the fp16 range).
 static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, const float* xyz, const float* viewdirs, long long P,
-                             float* out, void* workspace, void* stream, const int* gate) {
+                             float* out, void* workspace, void* scratch, void* stream, const int* gate) {
   int rc = 0;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const TrainWs w = train_ws(P, scene->nv);
+  float* sc = scratch_base(ws, scratch, w);
   const long long cols = P * scene->nv;
   if (!gate) {
     rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
@@ -1331,7 +1337,7 @@ static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, c
   // The lin_z term of block b, Z_b = lat Wz_b^T + bz_b, is a product of its own into a scratch buffer (d_lat is free in the forward) and
   // enters the residual stream through the epilogue of fc_1 of block b - 1, the product that writes X[b] (second residual; block 0: below): no accumulating product is left in the forward, so every 512 x 512 product can run in the f16x3 arithmetic with
   // its gated bf16x6 repeat.  (Without the 512-kernels: lin_z accumulates onto X[b] as before.)
-  float* Z = ws + w.d_lat;
+  float* Z = sc + w.d_lat;
   const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, Z, kHidden, nullptr, nullptr);
   auto lin_z = [&](int b, float* dst) { return lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], dst, cols, kHidden, kLatent, false, false, nullptr, kSlotLinZ + b); };
   // block 0: lin_in (general kernel, plain instance, runs once) writes into the scratch buffer and the lin_z product of block 0 takes it as its
@@ -1346,7 +1352,7 @@ static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, c
     if (!z_sep && b < 3 && (rc = lin(ws + w.lat, kLatent, p->lin_z_w[b], p->lin_z_b[b], X, M, kHidden, kLatent, false, true, nullptr, kSlotLinZ + b))) return rc;
     if ((rc = lin(X, kHidden, p->fc0_w[b], p->fc0_b[b], ws + w.H[b], M, kHidden, kHidden, true, false, nullptr, kSlotFc0 + b))) return rc;
     // next residual stream: X + fc_1(relu(H)); the view mean comes after block 2
-    float* nx = b == 4 ? ws + w.x_last : (b == 2 ? ws + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
+    float* nx = b == 4 ? ws + w.x_last : (b == 2 ? sc + w.dx : ws + w.X[b + 1]);      // (dx doubles as scratch in the forward)
     const bool z_next = z_sep && b + 1 < 3;
     // round 4: the lin_z term of block b + 1 as a SECOND CONTRACTION SEGMENT of this block's fc_1 product (K = 512 + 512: relu(H) W1^T +
     // lat Wz^T + both biases + X in one pass over the rows) -- no Z tensor written and read back (2 of this block's ~8 tensor passes).
@@ -1382,12 +1388,26 @@ static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, c
   return 0;
 }
 
-extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
-                                             const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
+extern "C" int diner_field_train_forward_s_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz, const float* viewdirs,
+                                               long long P, float* out, void* workspace, void* scratch, void* stream) {
   DINER_CHECK_ARG(scene && xyz && viewdirs && out && workspace && P > 0, "field_train_forward: bad arguments");
   int rc = check_train_params(p, true);
   if (rc) return rc;
-  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, stream, nullptr);
+  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, scratch, stream, nullptr);
+}
+extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
+                                             const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
+  return diner_field_train_forward_s_f32(scene, p, xyz, viewdirs, P, out, workspace, nullptr, stream);
+}
+
+// bytes of the two parts of the training workspace: what the forward keeps for the backward (per object) and the work buffers of either call
+// (may be one buffer shared by the objects of a step: calls on one stream use it one after the other)
+extern "C" int diner_field_train_workspace_split(long long P, int nv, size_t* saved_bytes, size_t* scratch_bytes) {
+  DINER_CHECK_ARG(P > 0 && nv > 0 && saved_bytes && scratch_bytes, "field_train_workspace_split: bad arguments");
+  const TrainWs w = train_ws(P, nv);
+  *saved_bytes = w.saved_total * sizeof(float);
+  *scratch_bytes = (w.total - w.saved_total) * sizeof(float);
+  return 0;
 }
 
 // ---- training forward on the INFERENCE kernels (round 5, experiment behind DINER_TRAIN_FUSED_FWD=1 of the Python host) ------------------
@@ -1409,8 +1429,8 @@ enum { kFlagFusedOvf = 14 };
 }  // namespace
 
 extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
-                                                   const float* viewdirs, long long P, float* out, void* workspace, float* latent_proj_out,
-                                                   void* stream) {
+                                                   const float* viewdirs, long long P, float* out, void* workspace, void* scratch,
+                                                   float* latent_proj_out, void* stream) {
   DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && out && workspace && P > 0, "field_train_forward_fused: bad arguments");
   int rc = check_train_params(p, true);
   if (rc) return rc;
@@ -1458,11 +1478,11 @@ extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, cons
   for (int b = 0; b < 5; ++b) { sv.bX[b] = reinterpret_cast<unsigned*>(ws + w.bX[b]); sv.bH[b] = reinterpret_cast<unsigned*>(ws + w.bH[b]); }
   int* ovf = nullptr;
   // hand-over + tile counters of the two kernels: the backward's dx buffer is free in the forward (8 KB per point; 2 KB + flags needed)
-  if ((rc = field_forward_save(&own, mlp, xyz, viewdirs, P, out, ws + w.dx, sv, &ovf, st))) return rc;
+  if ((rc = field_forward_save(&own, mlp, xyz, viewdirs, P, out, scratch_base(ws, scratch, w) + w.dx, sv, &ovf, st))) return rc;
   hipLaunchKernelGGL(k_copy_flag, dim3(1), dim3(1), 0, st, ovf, reinterpret_cast<int*>(ws + w.flags) + kFlagFusedOvf);
   DINER_LAUNCH_OK();
   // the exact repeat, on the device: the layer-wise forward behind the flag (its ~25 launches return at once when it stayed down)
-  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, stream, reinterpret_cast<const int*>(ws + w.flags) + kFlagFusedOvf);
+  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, scratch, stream, reinterpret_cast<const int*>(ws + w.flags) + kFlagFusedOvf);
 }
 
 // 1 when the fused forward that filled `workspace` met an activation beyond the fp16 range (its saved activations are not usable), else 0;
@@ -1478,9 +1498,15 @@ extern "C" int diner_field_train_fused_overflowed(const void* workspace, long lo
 
 // grads: the same structure as the parameters, device buffers of the parameters' shapes (overwritten);
 // d_latent_cl (nv, Hf, Wf, 512) or NULL: overwritten with the gradient of the channels-last feature map
+extern "C" int diner_field_train_backward_s_f32(const DinerScene* scene, const DinerMlpParams* p, const DinerMlpParams* grads, long long P,
+                                                const float* d_out, void* workspace, void* scratch, float* d_latent_cl, void* stream);
 extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* p, const DinerMlpParams* grads,
                                               long long P, const float* d_out, void* workspace, float* d_latent_cl,
                                               void* stream) {
+  return diner_field_train_backward_s_f32(scene, p, grads, P, d_out, workspace, nullptr, d_latent_cl, stream);
+}
+extern "C" int diner_field_train_backward_s_f32(const DinerScene* scene, const DinerMlpParams* p, const DinerMlpParams* grads, long long P,
+                                                const float* d_out, void* workspace, void* scratch, float* d_latent_cl, void* stream) {
   DINER_CHECK_ARG(scene && d_out && workspace && P > 0, "field_train_backward: bad arguments");
   int rc = check_train_params(p, false);
   if (rc) return rc;
@@ -1490,13 +1516,14 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   float* ws = (float*)workspace;
   const TrainWs w = train_ws(P, scene->nv);
   const long long cols = P * scene->nv;
-  float* dx = ws + w.dx;
-  float* dH = ws + w.dH;
+  float* sc = scratch_base(ws, scratch, w);
+  float* dx = sc + w.dx;
+  float* dH = sc + w.dH;
   // weight gradients of the 512 x 512 layers: every layer keeps its partial tiles in its own slot, one launch sums them all at the end
   WgReduceJobs jobs;
   int n_jobs = 0;
   const size_t part_floats = wgrad512_part_bytes() / sizeof(float);
-  auto part = [&](int slot) { return ws + w.wgpart + (size_t)slot * part_floats; };
+  auto part = [&](int slot) { return sc + w.wgpart + (size_t)slot * part_floats; };
   auto job = [&]() -> WgReduceJob* {
     jobs.job[n_jobs] = WgReduceJob{nullptr, nullptr, nullptr, 0};
     return &jobs.job[n_jobs++];
@@ -1507,7 +1534,7 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   // f16x3 backward (use_bwd_f16): every dy operand carries the maximum of its magnitudes in an amax slot, written by its producer
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   unsigned* amax = reinterpret_cast<unsigned*>(flags) + kAmax0;
-  const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, ws + w.d_lat, kHidden, nullptr, nullptr);   // as the forward decided
+  const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, sc + w.d_lat, kHidden, nullptr, nullptr);   // as the forward decided
   const bool bwd16 = use_bwd_f16() && use_fwd_f16() && use_lin512() && use_wgrad512() && z_sep && (reinterpret_cast<size_t>(workspace) & 15) == 0;
   if (bwd16) DINER_HIP_OK(hipMemsetAsync(amax, 0, 64 * sizeof(unsigned), st));
   int a_cur = 0, a_next = 1;                                  // slot of the current dx; next free slot
@@ -1523,8 +1550,8 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
     hipLaunchKernelGGL(k_lin_out_bwd, dim3(grid1d(P, 4, 256)), dim3(256), 0, st, ws + w.x_last, ws + w.raw, d_out, p->lin_out_w, P, dx,
                        (float*)grads->lin_out_w, (float*)grads->lin_out_b, bwd16 ? amax + 0 : nullptr);
   } else {
-    hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, ws + w.d_raw);
-    if ((rc = linear_bwd(ws + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
+    hipLaunchKernelGGL(k_field_act_bwd, dim3(grid1d(P)), dim3(256), 0, st, ws + w.raw, d_out, P, 4, sc + w.d_raw);
+    if ((rc = linear_bwd(sc + w.d_raw, 4, ws + w.x_last, kHidden, true, p->lin_out_w, (float*)grads->lin_out_w,
                          (float*)grads->lin_out_b, P, 4, kHidden, dx, ws + w.x_last, false, st))) return rc;
     // (lin_out off its skinny kernel -- a weight or d_out that is not 16-byte aligned: the general path keeps no maximum of dx)
     if (bwd16) hipLaunchKernelGGL(k_absmax, dim3(grid1d(P * (long long)kHidden)), dim3(256), 0, st, dx, P * (long long)kHidden, amax + 0);
@@ -1547,7 +1574,7 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
                          arith(kSlotFc0 + b, a_h, a_x), bits(w.bX[b])))) return rc;
     a_cur = a_x;
     if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
-                                  (float*)grads->lin_z_b[b], M, kHidden, kLatent, ws + w.d_lat, nullptr, b < 2, st,
+                                  (float*)grads->lin_z_b[b], M, kHidden, kLatent, sc + w.d_lat, nullptr, b < 2, st,
                                   wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job(), arith(kSlotLinZ + b, a_cur, -1)))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
       const int a_b = a_next++;
@@ -1567,7 +1594,7 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
   }
   if (d_latent_cl) {
     DINER_HIP_OK(hipMemsetAsync(d_latent_cl, 0, (size_t)scene->nv * scene->Hf * scene->Wf * kLatent * sizeof(float), st));
-    if ((rc = scatter_latent_launch(ws + w.d_lat, (const int*)(ws + w.tap_row), ws + w.tap_w, cols, d_latent_cl, st))) return rc;
+    if ((rc = scatter_latent_launch(sc + w.d_lat, (const int*)(ws + w.tap_row), ws + w.tap_w, cols, d_latent_cl, st))) return rc;
   }
   DINER_LAUNCH_OK();
   return 0;

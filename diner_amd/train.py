@@ -20,7 +20,8 @@ once; an activation beyond the fp16 range raises a flag and the layer-wise forwa
 no host synchronisation) redoes the object; weights outside the fp16 split go to the layer-wise forward at once
 (diner_field_train_forward_f32: one product per launch; DINER_TRAIN_FUSED_FWD=0 makes it the only one).  Sizes: the shipped configs train SB = 4 objects x 4096 rays (a 64 x 64 patch: w_vgg != 0, diner.py:57) x 40 samples x
 4 views = 655 k columns per object and step (configs/train_dtu.yaml:16,52-63); the workspace of saved activations is 94 KB per sample
-point = 14.7 GiB per object at that size (diner_field_train_workspace_bytes), four of them alive between forward and backward.
+point = 15.4 GiB per object at that size (diner_field_train_workspace_bytes); round 5: 10.8 GiB of it are what the backward reads (kept per
+object by autograd, four alive between forward and backward), the other 4.6 GiB are work buffers shared by the objects of a step.
 """
 import os
 
@@ -133,14 +134,31 @@ def fused_forward_enabled(P=None, scene=None):
 _PROJ = {}
 
 
-def _proj_buffer(scene, dev):
-    """The latent map projected through lin_z[0..2] with the step's weights: written and read inside the forward call only, so the objects
-    of a step (and the steps) share one buffer per device (stream order keeps them apart)."""
-    n = int(lib.diner_scene_proj_bytes(scene.ref)) // 4
-    buf = _PROJ.get(dev)
-    if buf is None or buf.numel() < n:
-        buf = _PROJ[dev] = torch.empty(n, dtype=torch.float32, device=dev)
+def _shared(pool, dev, nbytes):
+    """A buffer that lives inside one library call only, shared by the objects of a step (and the steps): one per device AND stream -- calls
+    on a stream run one after the other; it only grows (the caching allocator keeps a replaced one alive for the work already enqueued)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = pool.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = pool[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     return buf
+
+
+def _proj_buffer(scene, dev):
+    """The latent map projected through lin_z[0..2] with the step's weights: written and read inside the forward call only."""
+    return _shared(_PROJ, dev, int(lib.diner_scene_proj_bytes(scene.ref)))
+
+
+_SCRATCH = {}
+
+
+def workspace_split(P, nv):
+    """(saved bytes, scratch bytes) of the training workspace (diner_field_train_workspace_split): the saved part is what autograd keeps per
+    object between forward and backward, the scratch part is shared (`_SCRATCH`)."""
+    import ctypes as C
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    _lib.check(lib.diner_field_train_workspace_split(P, nv, C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
 
 
 _STEP_MLP = [None, None]
@@ -176,7 +194,11 @@ class FieldFunction(torch.autograd.Function):
         P, NV = xyz.shape[0], scene.nv
         dev = xyz.device
         with torch.cuda.device(dev):
-            ws = torch.empty(int(lib.diner_field_train_workspace_bytes(P, NV)), dtype=torch.uint8, device=dev)
+            # round 5: autograd keeps the SAVED part of the workspace only (10.8 of 15.4 GiB per object at 4096 rays x 40 samples); the work
+            # buffers of the two calls are one shared buffer per device and stream
+            saved_bytes, scratch_bytes = workspace_split(P, NV)
+            ws = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            scratch = _shared(_SCRATCH, dev, scratch_bytes)
             out = torch.empty(P, 4, device=dev)
             ps, keep = _param_struct(params, freq_factor)
             done = False
@@ -185,13 +207,13 @@ class FieldFunction(torch.autograd.Function):
                 # backward's operands are written once); needs this step's packed weights and the latent projected with them
                 mlp = _step_mlp(params, freq_factor)
                 rc = lib.diner_field_train_forward_fused_f32(scene.ref, mlp.handle, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P,
-                                                             _ptr(out), _ptr(ws), _ptr(_proj_buffer(scene, dev)), _stream())
+                                                             _ptr(out), _ptr(ws), _ptr(scratch), _ptr(_proj_buffer(scene, dev)), _stream())
                 if rc != _lib.E_UNSUPPORTED:         # (weights outside the fp16 split, maps beyond 4 GiB: the layer-wise forward below)
                     _lib.check(rc)                   # (an activation beyond the fp16 range: the library's gated layer-wise repeat, on the device)
                     done = True
             if not done:
-                _lib.check(lib.diner_field_train_forward_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
-                                                             _ptr(ws), _stream()))
+                _lib.check(lib.diner_field_train_forward_s_f32(scene.ref, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out),
+                                                               _ptr(ws), _ptr(scratch), _stream()))
             # the backward's outputs are allocated here, while the device works on the forward: the host is idle now and is the one the
             # device waits for at the start of the backward (64 us of the reference batch's 3.9 ms step)
             ctx.ps = (ps, keep)
@@ -213,8 +235,9 @@ class FieldFunction(torch.autograd.Function):
                 d_cl = None
             ps, keep = ctx.ps
             d_out = _f32c(d_out)
-            _lib.check(lib.diner_field_train_backward_f32(ctx.scene.ref, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out),
-                                                          _ptr(ws), _ptr(d_cl), _stream()))
+            scratch = _shared(_SCRATCH, d_out.device, workspace_split(ctx.P, ctx.scene.nv)[1])
+            _lib.check(lib.diner_field_train_backward_s_f32(ctx.scene.ref, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out),
+                                                            _ptr(ws), _ptr(scratch), _ptr(d_cl), _stream()))
             d_lat = None
             if d_cl is not None:             # channels-last -> the encoder's (nv, C, Hf, Wf), contiguous: autograd takes it as it is
                 nv, Cc, Hf, Wf = ctx.latent_shape

@@ -298,7 +298,17 @@ int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams*
                                   const float* viewdirs, long long P, float* out, void* workspace, void* stream);
 int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams* params, const DinerMlpParams* grads,
                                    long long P, const float* d_out, void* workspace, float* d_latent_cl, void* stream);
-/* Round 5 (experiment; the Python host uses it when DINER_TRAIN_FUSED_FWD=1): the training forward on the INFERENCE kernels -- the f16x3
+/* Round 5: the workspace in two parts.  `saved_bytes`: what the forward leaves for the backward (per object: 10.8 GiB of the 15.4 at 4096
+ * rays x 40 samples); `scratch_bytes`: the work buffers of either call (the backward's dx / dH / d_lat, partial weight-gradient tiles; the
+ * forward's hand-over buffers) -- nothing in them lives from the forward to the backward, so the objects of a step, whose calls run one
+ * after the other on a stream, can share ONE scratch buffer.  The _s entry points take the two parts separately (scratch NULL: the work
+ * buffers follow the saved part in `workspace`, which then holds diner_field_train_workspace_bytes = saved + scratch bytes). */
+int diner_field_train_workspace_split(long long P, int nv, size_t* saved_bytes, size_t* scratch_bytes);
+int diner_field_train_forward_s_f32(const DinerScene* scene, const DinerMlpParams* params, const float* xyz, const float* viewdirs,
+                                    long long P, float* out, void* workspace, void* scratch, void* stream);
+int diner_field_train_backward_s_f32(const DinerScene* scene, const DinerMlpParams* params, const DinerMlpParams* grads, long long P,
+                                     const float* d_out, void* workspace, void* scratch, float* d_latent_cl, void* stream);
+/* Round 5 (the Python host uses it for objects with at least half a feature map of sample points; DINER_TRAIN_FUSED_FWD=1 / 0 forces it): the training forward on the INFERENCE kernels -- the f16x3
  * per-view and post kernels of diner_field_from_points_f32 in variants that store the pre-activations into the places of `workspace`
  * the layer-wise forward uses (diner_field_train_ws_layout), so that diner_field_train_backward_f32 follows unchanged.  `mlp`: the
  * packed-weights handle of THIS step's parameters.  latent_proj_out (diner_scene_proj_bytes; free again when the call's work is done):
@@ -308,8 +318,8 @@ int diner_field_train_backward_f32(const DinerScene* scene, const DinerMlpParams
  * diner_field_train_fused_overflowed reads that flag back after a stream wait (a test aid).  DINER_E_UNSUPPORTED (weights outside the fp16
  * split, a projected map of 4 GiB or more): call diner_field_train_forward_f32 (pixelnerf.py:55-145, resnetfc.py:129-159). */
 int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
-                                        const float* viewdirs, long long P, float* out, void* workspace, float* latent_proj_out,
-                                        void* stream);
+                                        const float* viewdirs, long long P, float* out, void* workspace, void* scratch,
+                                        float* latent_proj_out, void* stream);
 int diner_field_train_fused_overflowed(const void* workspace, long long P, int nv, int* overflowed, void* stream);
 /* Test aid: float offsets into the training workspace of the pre-activations the forward saved -- [0..4] X_b, the residual stream
  * entering block b (P*nv rows of 512 for b < 3, P rows behind the view mean), [5..9] H_b, the fc_0 outputs of block b, [10] the

@@ -74,8 +74,9 @@ for NR in args.rays:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
     flop = 3 * 2 * SB * NR * K * (4 * (55 * 512 + 9 * 512 * 512) + 4 * 512 * 512 + 4 * 512)      # fwd + dgrad + wgrad
-    ws = lib.diner_field_train_workspace_bytes(NR * K, 4)
+    from diner_amd import train as _train
+    ws, scratch_b = _train.workspace_split(NR * K, 4)
     print(f"{SB} object(s) x {NR} rays x {K} samples: {dt * 1e3:.2f} ms per forward+backward step = {SB * NR / dt:.0f} rays/s, "
-          f"{flop / dt / 1e12:.1f} TFLOP/s fp32-equivalent; host enqueue {host * 1e3:.2f} ms per step; workspace {ws / 2 ** 30:.2f} GiB per object "
-          f"({SB * ws / 2 ** 30:.1f} GiB alive between forward and backward), peak device memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB",
+          f"{flop / dt / 1e12:.1f} TFLOP/s fp32-equivalent; host enqueue {host * 1e3:.2f} ms per step; saved activations {ws / 2 ** 30:.2f} GiB per object "
+          f"({SB * ws / 2 ** 30:.1f} GiB alive between forward and backward) + {scratch_b / 2 ** 30:.2f} GiB of shared work buffers, peak device memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB",
           flush=True)
