@@ -1081,7 +1081,7 @@ enum { kFlagWBad = 13, kAmax0 = 32, kFlagInts = 128 };
 enum { kSlotFc0 = 0, kSlotFc1 = 5, kSlotLinZ = 10 };
 struct TrainWs {               // float offsets into the workspace
   size_t feat, tap_row, tap_w, lat, X[5], H[5], x_last, raw, wpack, flags, bX[5], bH[5], saved_total, d_raw, dx, dH, d_lat, wgpart, total;
-};      // [0, saved_total): what the forward leaves for the backward; [saved_total, total): work buffers of either call, nothing in them lives
+};      // [0, saved_total): what the forward leaves for the backward; d_raw .. wgpart (offsets from scratch_base): work buffers of either call, nothing in them lives
         // from the forward to the backward (round 5: they may sit in a buffer of their own that the objects of a step share -- `scratch` of
         // the _s entry points; one workspace: they follow the saved part).  bX / bH (round 5): the relu decisions of X[b] / H[b] as bits, 16 dwords per row (Lin512Args.maskbits): what the data gradients read
 TrainWs train_ws(long long P, int nv) {
@@ -1108,16 +1108,17 @@ TrainWs train_ws(long long P, int nv) {
     w.bH[b] = take(m * 16);
   }
   w.saved_total = o;
+  o = 0;                                                           // the work buffers: offsets from THEIR base (scratch_base)
   w.d_raw = take((size_t)P * 4);
   w.dx = take(cols * kHidden);
   w.dH = take(cols * kHidden);
   w.d_lat = take(cols * kLatent);
   w.wgpart = take(13 * (wgrad512_part_bytes() / sizeof(float)));     // per-chunk partial weight gradients of the 13 512 x 512 layers (train_wgrad512.hip)
-  w.total = o;
+  w.total = w.saved_total + o;
   return w;
 }
 // base pointer for the work buffers' offsets: `scratch` (a buffer of its own, diner_field_train_workspace_split) or the workspace itself
-float* scratch_base(float* ws, void* scratch, const TrainWs& w) { return scratch ? (float*)scratch - w.saved_total : ws; }
+float* scratch_base(float* ws, void* scratch, const TrainWs& w) { return scratch ? (float*)scratch : ws + w.saved_total; }
 int check_train_params(const DinerMlpParams* p, bool poscode) { return check_mlp_config(p, "field_train", poscode); }
 // DINER_TRAIN_LIN512=0 routes the 512 x 512 layer products back to the general kernel (A/B measurement)
 bool use_lin512() {

@@ -125,6 +125,8 @@ def fused_forward_enabled(P=None, scene=None):
     (the inference path's hoist) where the layer-wise forward projects the P x NV gathered rows: it pays from about half a map of sample
     points per object (the shipped 4096 rays x 40 samples: 3 maps' worth -- 157.0 -> 143.0 ms per four-object step; a 128-ray batch: a
     tenth of a map: profiles/r05_train_fused_forward.txt)."""
+    if scene is not None and scene.nv != 4:          # the fused kernels are built for four source views (the layer-wise forward: any)
+        return False
     e = os.environ.get("DINER_TRAIN_FUSED_FWD", "")
     if e in ("0", "1"):
         return e == "1"
