@@ -222,7 +222,14 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
     r.wg.skip = ar->wg_skip;
     r.wg.gate = ar->wg_gate;
   }
-  if (ar && ar->arith == 1) hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1] + n_wg), dim3(256), kLdsBytesRun, stream, r);
+  // DINER_TRAIN_BWD_SPLIT=1 (measurement aid): the data-gradient parts and the weight-gradient part as two launches of the same kernel
+  static const bool split = [] { const char* e = getenv("DINER_TRAIN_BWD_SPLIT"); return e && *e == '1'; }();
+  if (split && ar && ar->arith == 1 && r.n[0] + r.n[1] > 0 && n_wg > 0) {
+    hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
+    Run512 w2 = r;
+    w2.n[0] = w2.n[1] = 0;
+    hipLaunchKernelGGL(k_run512_f16x3, dim3(n_wg), dim3(256), kLdsBytesRun, stream, w2);
+  } else if (ar && ar->arith == 1) hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1] + n_wg), dim3(256), kLdsBytesRun, stream, r);
   else hipLaunchKernelGGL(k_run512, dim3(r.n[0] + r.n[1] + n_wg), dim3(256), kLdsBytesRun, stream, r);
   if (part) {
     // chunks that start past M wrote nothing: only the chunks with rows are summed
