@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
   wgrad512_body<0>(r.wg, b - r.n[1]);
 }
 
+// round 5: the weight gradient of an f16x3 launch on eight waves (wgrad512_body_w8), a launch of its own behind the data gradient's
+__global__ __launch_bounds__(512, 1) void k_wgrad512_w8(Wgrad512Args a) { wgrad512_body_w8(a, blockIdx.x); }
+
 namespace {
 constexpr size_t kLdsBytesRun = kLdsBytesWgrad > kLdsBytes512 ? kLdsBytesWgrad : kLdsBytes512;
 static_assert(kLdsBytesRun >= kLdsBytes512F16, "the f16x3 128-row shape needs 128 KB");
@@ -83,6 +86,7 @@ int device_cus(int* cus) {                                   // per device: dyna
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512F16));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3_w2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512F16W2));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad512_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(c > 1 ? c & ~1 : 256);
@@ -224,7 +228,12 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
   }
   // DINER_TRAIN_BWD_SPLIT=1 (measurement aid): the data-gradient parts and the weight-gradient part as two launches of the same kernel
   static const bool split = [] { const char* e = getenv("DINER_TRAIN_BWD_SPLIT"); return e && *e == '1'; }();
-  if (split && ar && ar->arith == 1 && r.n[0] + r.n[1] > 0 && n_wg > 0) {
+  // DINER_WGRAD_W8=0: the four-wave weight gradient inside the data gradient's launch (round 4; A/B measurement)
+  static const bool w8 = [] { const char* e = getenv("DINER_WGRAD_W8"); return !(e && *e == '0'); }();
+  if (w8 && wide && n_wg > 0) {
+    if (r.n[0] + r.n[1] > 0) hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
+    hipLaunchKernelGGL(k_wgrad512_w8, dim3(n_wg), dim3(512), kLdsBytesRun, stream, r.wg);
+  } else if (split && ar && ar->arith == 1 && r.n[0] + r.n[1] > 0 && n_wg > 0) {
     hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
     Run512 w2 = r;
     w2.n[0] = w2.n[1] = 0;

@@ -462,6 +462,172 @@ __device__ __forceinline__ void wgrad512_body_wide(const Wgrad512Args& a, const 
   }
 }
 
+// ---- round 5: the same 256 x 256 tiles on EIGHT waves (512 threads, two waves per SIMD, 256 registers each).  One wave per SIMD leaves the
+// matrix pipe idle whenever that wave converts, waits at the slab barrier or for a fragment (both 512-layer bodies run at ~0.47 of the
+// pipe, profiles/r05_train_bwd_split.txt); two waves fill each other's gaps (the micro-benchmark of the inference kernels: 0.98 of the pipe
+// against 0.8).  Waves 2 (f) x 4 (k): 128 f x 64 k each = 4 x 2 accumulator tiles = 128 registers.  Staging: waves 0..3 convert the x
+// operand (columns [64 w, +64) of the tile's k range), waves 4..7 the dy operand (columns [64 (w - 4), +64) of its f range) -- the lane
+// mapping, the LDS layout (64 KB slabs, two buffers) and the partial-tile layout of wgrad512_body_wide; 32 values per thread and slab for
+// 48 MFMAs.  Its own kernel (k_wgrad512_w8: 512 threads); the data gradient of the layer is the launch in front of it.
+__device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const int bid) {
+  constexpr int NP = 2, kFrags = 16 * NP, kSlab = 2 * kFrags * 1024;
+  if (a.gate && *a.gate == 0) return;
+  if (a.skip && *a.skip != 0) return;
+  float sy = 1.0f, inv_sy = 1.0f;
+  if (a.amax_dy) {
+    const unsigned e = (*a.amax_dy >> 23) & 0xffu;
+    if (e >= 32u && e < 255u) {
+      sy = __uint_as_float((268u - e) << 23);
+      inv_sy = __uint_as_float((e - 14u) << 23);
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  typedef __attribute__((address_space(3))) bf8w* lds_bf8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int tile = (bid >> 3) & 3, chunk = (bid & 7) + 8 * (bid >> 5);      // as wgrad512_body_wide
+  const int ft = tile >> 1, kt2 = tile & 1;
+  const long long m_begin = (long long)chunk * a.rows_per_chunk;
+  long long m_end = m_begin + a.rows_per_chunk;
+  if (m_end > a.M) m_end = a.M;
+  if (m_begin >= a.M) return;
+  const int n_slabs = (int)((m_end - m_begin + 31) / 32);
+  const bool is_y = wave >= 4;                               // this wave stages dy (else x)
+  const int ws = wave & 3;                                   // its 64-column block of that operand
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 vr[8];                                               // rows 8 g .. 8 g + 7 of the lane's 4 columns
+  const int ld = is_y ? a.ldy : a.ldx;
+  const float* src = is_y ? a.dY : a.X;
+  const unsigned s_bytes = (unsigned)((m_end - m_begin) * (long long)ld * 4);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)m_begin * ld), 0, (int)s_bytes, 0x00020000);
+  const unsigned voff = (unsigned)(8 * g) * (unsigned)ld * 4u + (unsigned)(256 * (is_y ? ft : kt2) + 64 * ws + 4 * li) * 4u;
+  auto request = [&](int j, long long m0) {
+    const unsigned row = (unsigned)(m0 - m_begin) + (unsigned)j;
+    vr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, row * (unsigned)ld * 4u, 0));
+  };
+  lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kFrags * 1024) + (32 * (g & 1)) * 16;
+  const int slot = (((is_y ? 0 : 8) + 2 * ws + (li >> 3)) * NP) * 1024 + (4 * (li & 7)) * 16;
+  const int relu_floor = (!is_y && a.relu_x) ? 0 : (int)0x80000000;
+  const float scale = is_y ? sy : 1.0f;
+  float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};                   // dy waves: row sums of the lane's four columns (bias gradient, unscaled)
+  typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+  u32x4w sp0, sp1;
+  auto stash_half = [&](int buf, int i, int half) {          // column i (0..3) of the lane's block, rows 0..3 / 4..7 (+ the store)
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __int_as_float(max(__float_as_int(vr[4 * half + j][i]), relu_floor));
+    rs[i] += (v[0] + v[1]) + (v[2] + v[3]);                  // (x waves: never read)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= scale;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned h = cvt_pk_f16_w(v[2 * j], v[2 * j + 1]);
+      sp0[2 * half + j] = h;
+      sp1[2 * half + j] = cvt_pk_f16_w(resid_lo_w(h, v[2 * j]), resid_hi_w(h, v[2 * j + 1]));
+    }
+    if (half == 1) {
+      lds_ptr d = sbase + buf * kSlab + slot + i * 16;
+      *(lds_bf8)(d) = __builtin_bit_cast(bf8w, sp0);
+      *(lds_bf8)(d + 1024) = __builtin_bit_cast(bf8w, sp1);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j) request(j, m_begin);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    stash_half(0, i, 0);
+    stash_half(0, i, 1);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) request(j, m_begin + 32);      // (past the chunk: zeros)
+  __syncthreads();
+
+  const int wf = wave >> 2, wk = wave & 3;                    // this wave's 128 f x 64 k part of the tile
+  f32x16w acc[4][2];
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[fi][kt][e] = 0.0f;
+  lds_ptr lbase = (lds_ptr)smem + lane * 16;
+#pragma nounroll
+  for (int slab = 0; slab < n_slabs; ++slab) {
+    const int buf = slab & 1;
+    const long long m_next2 = m_begin + 32ll * (slab + 2);
+    lds_ptr rb = lbase + buf * kSlab;
+    asm volatile("" : "+v"(rb));
+    wfor<2>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      bf8w af[4][NP], bfr[2][NP];
+#pragma unroll
+      for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) af[fi][pl] = *(lds_bf8)(rb + (s * kFrags + (4 * wf + fi) * NP + pl) * 1024);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) bfr[kt][pl] = *(lds_bf8)(rb + (s * kFrags + (8 + 2 * wk + kt) * NP + pl) * 1024);
+      wfor<8>([&](auto G) {
+        constexpr int gi = decltype(G)::value, kt = gi >> 2, fi = gi & 3;
+        constexpr int u = s * 8 + gi;                        // 16 groups of 3 MFMAs per slab
+        __builtin_amdgcn_sched_barrier(0);
+        // staging side task: the next slab's four lane-fragment columns, each in two halves, groups 1..8; requests re-armed in group 9
+        if constexpr (u >= 1 && u <= 8) stash_half(buf ^ 1, (u - 1) >> 1, (u - 1) & 1);
+        if constexpr (u == 9) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) request(j, m_next2);
+        }
+        const bf8w b0 = bfr[kt][0], b1 = bfr[kt][1];
+        DINER_WG_MFMA_F16(acc[fi][kt], af[fi][1], b0);       // smallest terms first
+        DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], b1);
+        DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], b0);
+        if constexpr (u >= 1 && u <= 8) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        }
+        asm volatile("" : "+a"(acc[fi][kt]));
+      });
+    });
+    __syncthreads();
+  }
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int k = 256 * kt2 + 32 * (2 * wk + kt) + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int f = 256 * ft + 32 * (4 * wf + fi) + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        const float val = acc[fi][kt][e] * inv_sy;
+        if (a.part) a.part[((size_t)chunk * 512 + f) * 512 + k] = val;
+        else atomicAdd(a.dW + (size_t)f * 512 + k, val);
+      }
+    }
+  if (a.db && kt2 == 0 && is_y) {
+    const int f = 256 * ft + 64 * ws + 4 * li;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      rs[c] += __shfl_xor(rs[c], 16);
+      rs[c] += __shfl_xor(rs[c], 32);
+    }
+    if (lane < 16) {
+      if (a.part) {
+        float* pdb = a.part + (size_t)kWgMaxChunks * 512 * 512 + (size_t)chunk * 512;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pdb[f + c] = rs[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(a.db + f + c, rs[c]);
+      }
+    }
+  }
+}
+
 // dW[i] (+)= sum over the chunks of part[c][i]; db likewise from the partial row sums behind the tiles.  Four independent running sums:
 // the 32 loads of a thread must not wait for each other (the pass read its 32 MB at 2 TB/s with one)
 __global__ __launch_bounds__(256) void k_wgrad512_reduce(const float* __restrict__ part, int n_chunks, int overwrite, float* __restrict__ dW,

@@ -289,6 +289,15 @@ def test_no_spill_code_in_the_training_kernels(tmp_path):
                     after = any("v_mfma" in x for x in body[i + 1:i + 26])
                     assert not (before and after), f"{name}: scratch access among MFMAs: {l.strip()}"
         found[name] = body
+    # round 5: the eight-wave weight gradient (two waves per SIMD: 256 registers, 128 of them accumulators) -- no scratch access inside its slab loop
+    m = re.search(r"^(\w*\dk_wgrad512_w8E\w*):.*?\n(.*?)\.Lfunc_end", txt, re.S | re.M)
+    assert m, "k_wgrad512_w8"
+    body = m.group(2).split("\n")
+    idx = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_f16" in l]
+    assert len(idx) == 48, len(idx)
+    assert not [l for l in body[idx[0]:idx[-1] + 1] if "scratch_" in l]
+    assert len([l for l in body if "scratch_" in l]) <= 14
+    assert re.search(r"\.amdhsa_kernel \S*k_wgrad512_w8\S*\n.*?\.amdhsa_next_free_vgpr (\d+)", txt, re.S).group(1) == "256"
     assert sum("v_mfma_f32_32x32x16_bf16" in l for l in found["k_run512"]) > 1000
     assert sum("v_mfma_f32_32x32x16_f16" in l for l in found["k_fwd512_f16x3"]) > 500
     assert not any("v_mfma_f32_32x32x16_bf16" in l for l in found["k_fwd512_f16x3"])
