@@ -508,6 +508,13 @@ __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const in
   };
   lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kFrags * 1024) + (32 * (g & 1)) * 16;
   const int slot = (((is_y ? 0 : 8) + 2 * ws + (li >> 3)) * NP) * 1024 + (4 * (li & 7)) * 16;
+  // Bank conflicts of the staging writes: one store instruction puts column i of every lane's 4-column block into its fragment -- 16-byte
+  // slots 4 (li & 7) + i, a stride of 64 bytes: the 64 lanes hit a quarter of the banks (the round-4 counters: 64-70 % of the LDS-active
+  // cycles were conflict cycles), and with eight waves reading 96 KB of fragments per k16 step on top of 4 x 32 KB-equivalents of
+  // conflicted writes the LDS, not the matrix pipe, sets the pace.  Slots are swizzled inside every 1 KB fragment: slot L lives at
+  // L ^ ((L >> 3) & 3) -- the eight lanes of a row group then cover all eight 16-byte bank groups, and a reader's 64 lanes still read 64
+  // distinct slots.  For the writer (L >> 3) & 3 = (li >> 1) & 3 whatever i: the slot offset of column i is (16 i) ^ sw16.
+  const int sw16 = ((li >> 1) & 3) * 16;
   const int relu_floor = (!is_y && a.relu_x) ? 0 : (int)0x80000000;
   const float scale = is_y ? sy : 1.0f;
   float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};                   // dy waves: row sums of the lane's four columns (bias gradient, unscaled)
@@ -527,7 +534,7 @@ __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const in
       sp1[2 * half + j] = cvt_pk_f16_w(resid_lo_w(h, v[2 * j]), resid_hi_w(h, v[2 * j + 1]));
     }
     if (half == 1) {
-      lds_ptr d = sbase + buf * kSlab + slot + i * 16;
+      lds_ptr d = sbase + buf * kSlab + slot + ((i * 16) ^ sw16);
       *(lds_bf8)(d) = __builtin_bit_cast(bf8w, sp0);
       *(lds_bf8)(d + 1024) = __builtin_bit_cast(bf8w, sp1);
     }
@@ -551,7 +558,7 @@ __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const in
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[fi][kt][e] = 0.0f;
-  lds_ptr lbase = (lds_ptr)smem + lane * 16;
+  lds_ptr lbase = (lds_ptr)smem + (lane ^ ((lane >> 3) & 3)) * 16;      // (the swizzled slot of fragment lane `lane`)
 #pragma nounroll
   for (int slab = 0; slab < n_slabs; ++slab) {
     const int buf = slab & 1;
