@@ -69,6 +69,18 @@ __global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
   wgrad512_body<0>(r.wg, b - r.n[1]);
 }
 
+// round 5: the data gradient of an f16x3 launch on eight waves (lin512_body<.., NW = 8>: two waves per SIMD, 64 features and half the staging
+// rows per wave; the shared 32-row shape of a plan runs as plain 32-row tiles -- its second workgroups find no tile)
+__global__ __launch_bounds__(512, 1) void k_dgrad512_w8(Run512 r) {
+  int b = blockIdx.x;
+  const int i = b < r.n[0] ? 0 : 1;
+  if (i) b -= r.n[0];
+  const Lin512Args& a = r.part[i];
+  const int shape = r.shape[i], nblk = r.n[i];
+  if (shape == kShape128) lin512_body<DINER_L512_RING, 4, 1, 1, 8>(a, b, nblk);
+  else if (shape == kShape64) lin512_body<DINER_L512_RING, 2, 1, 1, 8>(a, b, nblk);
+  else lin512_body<DINER_L512_RING, 1, 1, 1, 8>(a, b, nblk);
+}
 // round 5: the weight gradient of an f16x3 launch on eight waves (wgrad512_body_w8), a launch of its own behind the data gradient's
 __global__ __launch_bounds__(512, 1) void k_wgrad512_w8(Wgrad512Args a) { wgrad512_body_w8(a, blockIdx.x); }
 
@@ -87,6 +99,7 @@ int device_cus(int* cus) {                                   // per device: dyna
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_fwd512_f16x3_w2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes512F16W2));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad512_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_dgrad512_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(c > 1 ? c & ~1 : 256);
@@ -231,7 +244,12 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
   // DINER_WGRAD_W8=0: the four-wave weight gradient inside the data gradient's launch (round 4; A/B measurement)
   static const bool w8 = [] { const char* e = getenv("DINER_WGRAD_W8"); return !(e && *e == '0'); }();
   if (w8 && wide && n_wg > 0) {
-    if (r.n[0] + r.n[1] > 0) hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
+    // DINER_DGRAD_W8=1: the data gradient on eight waves too (round 5 experiment)
+    static const bool d8 = [] { const char* e = getenv("DINER_DGRAD_W8"); return e && *e == '1'; }();
+    if (r.n[0] + r.n[1] > 0) {
+      if (d8) hipLaunchKernelGGL(k_dgrad512_w8, dim3(r.n[0] + r.n[1]), dim3(512), kLdsBytesRun, stream, r);
+      else hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);
+    }
     hipLaunchKernelGGL(k_wgrad512_w8, dim3(n_wg), dim3(512), kLdsBytesRun, stream, r.wg);
   } else if (split && ar && ar->arith == 1 && r.n[0] + r.n[1] > 0 && n_wg > 0) {
     hipLaunchKernelGGL(k_run512_f16x3, dim3(r.n[0] + r.n[1]), dim3(256), kLdsBytesRun, stream, r);

@@ -143,16 +143,20 @@ __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base, int* __res
 // AR: arithmetic -- 0 = bf16x6 (three bf16 planes per operand, six product terms: no range limit), 1 = f16x3 (two fp16 planes, three
 // terms, weights x16: the inference kernels' arithmetic; half the MFMAs; an operand beyond the fp16 range raises a.ovf and the caller
 // recomputes the product with AR = 0 -- the training FORWARD only, whose operands are activations)
-template <int R, int CT, int FH, int AR = 0>
+// NW (round 5): waves per workgroup.  8 = two waves per SIMD (512 threads, 256 registers per wave): wave w owns 64 features (the second half
+// of the wave slice w / 2 for odd w: the addressing of the shared 32-row shape, FH = 2, inside ONE workgroup) and stages half as many rows.
+template <int R, int CT, int FH, int AR = 0, int NW = 4>
 __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, const int nblk) {
+  static_assert(NW == 4 || (NW == 8 && FH == 1), "eight waves: whole tiles only");
   constexpr int NP = AR == 1 ? 2 : 3, NT = AR == 1 ? 3 : 6;  // planes per operand, product terms
-  constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * NP, NQ = 4 * CT;      // NQ: staging requests per wave and slab
+  constexpr int kRows = 32 * CT, kSlabFrags = kStepsPerSlab * CT * NP, NQ = 16 * CT / NW;      // NQ: staging requests per wave and slab
+  constexpr int kStageRows = 32 * CT / NW;                   // rows of the tile this wave stages
   // A staging write puts 8 bytes per lane into the fragments of EIGHT k16 steps at once (a lane holds 4 consecutive k of one row); with the
   // steps a multiple of 1 KB apart those are 8 lanes per LDS bank (PMC, round 4: 70 % of the kernel's LDS-active cycles were bank-conflict
   // cycles).  kStepPad = 32 bytes between the steps spreads them over the banks (2 lanes per bank are left: the two 8-row halves of a
   // fragment are 512 bytes apart by the MFMA layout); the fragment reads stay 1 KB contiguous per instruction.
   constexpr int kStepBytes = CT * NP * 1024 + kStepPad, kSlabBytes = kStepsPerSlab * kStepBytes;
-  constexpr int NRT = 4 / FH, NF = NP * NRT;                 // MFMA row (= feature) tiles per wave, weight fragments per k16 step
+  constexpr int NRT = 16 / (FH * NW), NF = NP * NRT;         // MFMA row (= feature) tiles per wave, weight fragments per k16 step
   if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
   if (a.gate2 && *a.gate2 == 0) return;
   if (a.skip && *a.skip != 0) {                              // f16x3 launch of a step whose weights do not fit: the bf16x6 twin works
@@ -191,7 +195,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   // Buffer loads (as in wgrad512_body): a descriptor over the tile's rows made from scalars, the lane's part of the offset in one register
   // for the whole kernel, request and slab as the scalar offset; rows past M read as zeros (their results are never stored).
   f32x4 xst[NQ];
-  const unsigned xvoff = ((unsigned)(8 * CT * wave + (lane >> 5)) * (unsigned)a.ldx + 4u * (lane & 31)) * 4u;
+  const unsigned xvoff = ((unsigned)(kStageRows * wave + (lane >> 5)) * (unsigned)a.ldx + 4u * (lane & 31)) * 4u;
   auto request_one = [&](int i, long long tile, int slab) {
     const long long row0 = tile * kRows;
     long long left = a.M - row0;
@@ -242,7 +246,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
     }
   };
   auto stash_write = [&](int buf, int i) {
-    const int r = 8 * CT * wave + 2 * i + (lane >> 5);       // row within the tile
+    const int r = kStageRows * wave + 2 * i + (lane >> 5);   // row within the tile
     lds_ptr d = (lds_ptr)smem + buf * kSlabBytes + st_off + ((r >> 5) * NP) * 1024 + (r & 31) * 16;
     *(lds_bf4)(d) = sp0;
     *(lds_bf4)(d + 1024) = sp1;
@@ -256,8 +260,8 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   // ---- weights: wave-private stream, NF fragments (NRT row tiles x 3 planes) per k16 step out of the 12 of the packed wave slice
   typedef const __attribute__((address_space(1))) char* gptr;
   const int half = FH == 2 ? (bid & 1) : 0;
-  const int wslice = FH == 2 ? 2 * half + (wave >> 1) : wave;                // 128-feature slice of the packed weights
-  const int rt0 = FH == 2 ? 2 * (wave & 1) : 0;                              // first of this wave's row tiles inside the slice
+  const int wslice = NW == 8 ? (wave >> 1) : FH == 2 ? 2 * half + (wave >> 1) : wave;      // 128-feature slice of the packed weights
+  const int rt0 = (FH == 2 || NW == 8) ? 2 * (wave & 1) : 0;                 // first of this wave's row tiles inside the slice
   const gptr wbase = (gptr)(reinterpret_cast<const char*>(a.Wp)) + ((size_t)wslice * 32 * (4 * NP) + NP * rt0) * 1024;
   const gptr wbase2 = (gptr)(reinterpret_cast<const char*>(a.Wp2 ? a.Wp2 : a.Wp)) + ((size_t)wslice * 32 * (4 * NP) + NP * rt0) * 1024;
   const int step_mask = 8 * n_slabs - 1;                     // k16 steps of a tile - 1 (the weight stream repeats per tile)
