@@ -122,7 +122,7 @@ def _param_struct(tensors, freq_factor=6.28):
 
 def fused_forward_enabled(P=None, scene=None):
     """DINER_TRAIN_FUSED_FWD: 1 = always, 0 = never, unset = by size.  The fused forward projects the WHOLE latent map through lin_z[0..2]
-    (the inference path's hoist) where the layer-wise forward projects the P x NV gathered rows: it pays from about half a map of sample
+    (the inference path's hoist) where the layer-wise forward projects the P x NV gathered rows: it pays from about 0.7 of a map of sample
     points per object (the shipped 4096 rays x 40 samples: 3 maps' worth -- 157.0 -> 143.0 ms per four-object step; a 128-ray batch: a
     tenth of a map: profiles/r05_train_fused_forward.txt)."""
     if scene is not None and scene.nv != 4:          # the fused kernels are built for four source views (the layer-wise forward: any)
@@ -130,7 +130,9 @@ def fused_forward_enabled(P=None, scene=None):
     e = os.environ.get("DINER_TRAIN_FUSED_FWD", "")
     if e in ("0", "1"):
         return e == "1"
-    return P is None or scene is None or 2 * P >= scene.Hf * scene.Wf
+    # break-even from the measured parts at 400 x 300 / 4096 rays x 40 samples (fused 7.1 + 1.1 + 0.4 ms + 5.2 us per 1000 map rows projected,
+    # layer-wise 13.3 ms; everything but the projection scales with P): maps up to ~1.4 x the sample points per view
+    return P is None or scene is None or 7 * P >= 5 * scene.Hf * scene.Wf
 
 
 _PROJ = {}

@@ -308,7 +308,7 @@ int diner_field_train_forward_s_f32(const DinerScene* scene, const DinerMlpParam
                                     long long P, float* out, void* workspace, void* scratch, void* stream);
 int diner_field_train_backward_s_f32(const DinerScene* scene, const DinerMlpParams* params, const DinerMlpParams* grads, long long P,
                                      const float* d_out, void* workspace, void* scratch, float* d_latent_cl, void* stream);
-/* Round 5 (the Python host uses it for objects with at least half a feature map of sample points; DINER_TRAIN_FUSED_FWD=1 / 0 forces it): the training forward on the INFERENCE kernels -- the f16x3
+/* Round 5 (the Python host uses it for objects with at least ~0.7 of a feature map of sample points; DINER_TRAIN_FUSED_FWD=1 / 0 forces it): the training forward on the INFERENCE kernels -- the f16x3
  * per-view and post kernels of diner_field_from_points_f32 in variants that store the pre-activations into the places of `workspace`
  * the layer-wise forward uses (diner_field_train_ws_layout), so that diner_field_train_backward_f32 follows unchanged.  `mlp`: the
  * packed-weights handle of THIS step's parameters.  latent_proj_out (diner_scene_proj_bytes; free again when the call's work is done):
