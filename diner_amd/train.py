@@ -131,7 +131,8 @@ def fused_forward_enabled(P=None, scene=None):
     if e in ("0", "1"):
         return e == "1"
     # break-even from the measured parts at 400 x 300 / 4096 rays x 40 samples (fused 7.1 + 1.1 + 0.4 ms + 5.2 us per 1000 map rows projected,
-    # layer-wise 13.3 ms; everything but the projection scales with P): maps up to ~1.4 x the sample points per view
+    # layer-wise 13.3 ms; everything but the projection scales with P): maps up to ~1.4 x the sample points per view.  Checked on either side:
+    # 800 x 600 maps (1.03 x) fused 38.75 / layer-wise 39.97 ms per object, 1024 x 1024 (2.0 x) 43.93 / 41.49 (profiles/r05_train_fused_forward.txt)
     return P is None or scene is None or 7 * P >= 5 * scene.Hf * scene.Wf
 
 
