@@ -2,6 +2,8 @@
 compositor against torch autograd on the CPU oracle (the form in which the reference itself differentiates them,
 diner.py:217-290).  Tolerance: 1e-4 max-norm relative per gradient tensor, as for the forward path."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -607,16 +609,21 @@ def test_training_step_two_objects_patch_of_rays(ops):
     assert not torch.equal(nerf.encoder.latent.grad[0], nerf.encoder.latent.grad[1])
 
 
-def test_shipped_ray_batch_equals_the_sum_of_reference_sized_batches(ops):
+def test_shipped_ray_batch_equals_the_sum_of_reference_sized_batches(ops, monkeypatch):
     """The ray batch the shipped configs train on (4096 rays per object = a 64 x 64 patch, diner.py:57 with configs/train_dtu.yaml:63; 163,840
     sample points, 655,360 per-view rows) takes launch plans no oracle comparison reaches -- 128-row tiles of the forward / data-gradient
     products, 256 x 256 weight-gradient tiles over 64 row chunks, the two-segment fc_1 + lin_z product -- and a CPU autograd of that size needs
     40 GB.  Size-independent property instead: rays are independent and the loss is a sum over rays, so the gradients of the 4096-ray step
     are the SUM of the gradients of its 32 sub-batches of 128 rays -- the size whose gradients are pinned against the oracle's autograd at 1e-4
     (test_field_forward_and_backward_against_oracle_autograd[5120]).  Per row the arithmetic is the same whatever the tile shape, so the relu
-    decisions are the same and only the summation order of the weight gradients differs: 1e-4 max-norm per tensor, rgb bit for bit."""
+    decisions are the same and only the summation order of the weight gradients differs: 1e-4 max-norm per tensor, rgb bit for bit.
+    (Round 5: "the same arithmetic per row" holds within ONE forward -- by its size rule the host would take the fused forward for the
+    4096-ray batch and the layer-wise one for a 128-ray batch on this scene; the fused forward, what the shipped step runs, is forced for both.
+    The layer-wise forward against the same sums: DINER_TRAIN_FUSED_FWD=0 in the environment of the whole file, tools/README.md.)"""
     from tests.test_boundary_gpu import setup_model
     from diner_amd import noise
+    if os.environ.get("DINER_TRAIN_FUSED_FWD", "") != "0":
+        monkeypatch.setenv("DINER_TRAIN_FUSED_FWD", "1")
     sc, nerf, R, rays = setup_model(64, 64, 8)
     nerf.train()
     NR, K, G, n_cand, CH = 4096, 40, 15, 1000, 128
