@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 5, diagnostic for the next round (NOT completed: the TCP_*_LATENCY group of the third pass hung the profiler for 25 min -- now every pass runs under `timeout 120`): counters of the per-view training kernel with and without its stores (DINER_TRAIN_NOSAVE=1)
+# round 5, diagnostic for the next round (the TCP_*_LATENCY counters hung the profiler for 25 min at the first try: dropped, every pass under `timeout 60`; result: profiles/r05_train_fwd_pre_store_counters.txt): counters of the per-view training kernel with and without its stores (DINER_TRAIN_NOSAVE=1)
 O=gpurun_out/r05aq; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/tools/time_train.py --objects 1 --rays 4096 --steps 1"
 for v in 0 1; do
-  for grp in "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_HIT_sum TCC_MISS_sum TCC_WRITEBACK_sum" "TA_TA_BUSY_sum TA_BUFFER_WRITE_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TCP_TA_TCP_STATE_READ_sum"; do
+  for grp in "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_HIT_sum TCC_MISS_sum TCC_WRITEBACK_sum" "TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum"; do
     n=$(echo $grp | cut -d' ' -f1)
-    DINER_TRAIN_NOSAVE=$v timeout 120 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$O/p${v}_$n -o pmc -- $CMD > $R/$O/p${v}_$n.log 2>&1
+    DINER_TRAIN_NOSAVE=$v timeout 60 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$O/p${v}_$n -o pmc -- $CMD > $R/$O/p${v}_$n.log 2>&1
   done
 done
 cd $R
