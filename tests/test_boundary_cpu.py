@@ -24,6 +24,23 @@ def build_nerf():
                                                                  combine_type="average")))
 
 
+def test_training_workspace_split_is_consistent():
+    """Host arithmetic only (no device work): the two parts of the training workspace (round 5: what the forward keeps for the backward, per
+    object / the work buffers the objects of a step share) add up to the one-buffer size of the older entry points, for the shipped step, the
+    reference batch and ragged sizes; the saved part is what autograd holds per object (10.84 GiB at 4096 rays x 40 samples x 4 views)."""
+    import ctypes as C
+    from diner_amd import _lib
+    lib = _lib.load()
+    for P, nv in ((163840, 4), (5120, 4), (200, 4), (1, 4), (4097, 3)):
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        assert lib.diner_field_train_workspace_split(P, nv, C.byref(a), C.byref(b)) == 0
+        assert a.value > 0 and b.value > 0 and a.value % 256 == 0 and b.value % 256 == 0
+        assert a.value + b.value == lib.diner_field_train_workspace_bytes(P, nv)
+    lib.diner_field_train_workspace_split(163840, 4, C.byref(a), C.byref(b))
+    assert 10.5 < a.value / 2 ** 30 < 11.0 and 4.4 < b.value / 2 ** 30 < 4.7
+    assert lib.diner_field_train_workspace_split(0, 4, C.byref(a), C.byref(b)) != 0      # bad sizes are an error, not a zero
+
+
 def test_library_exports_every_declared_symbol():
     import ctypes
     from diner_amd import _lib
