@@ -1,0 +1,81 @@
+// Micro-benchmark (round 5, for the stores of k_train_fwd_pre): what one 1 KB global_store_dwordx4 costs on the CU's vector-memory path as a
+// function of how many cache lines it covers.  A persistent workgroup per CU (4 waves) writes "saved activation" tiles of 64 rows x 512 floats
+// in one of three lane -> address maps, all 16 bytes per lane:
+//   PAT 0  the accumulator layout of save_block (mlp_h3n.hip): lane (q = lane / 16, n = lane % 16) writes row n, bytes [64 mo + 16 q, +16) of
+//          the wave's 512-byte slice: 16 rows x 64 bytes per instruction = 16 cache lines
+//   PAT 1  two rows x 512 contiguous bytes per instruction (lane / 32 = row, lane % 32 = 16-byte chunk): 8 cache lines
+//   PAT 2  one fully contiguous KB per instruction (a tile-blocked layout): 8 cache lines, one row-block
+// Every wave writes the same number of bytes in all patterns (8 instructions per 16-row group and wave slice).  Reports GB/s and shader
+// clocks per store instruction.    hipcc --offload-arch=gfx950 -O3 store_pattern.hip -o bin/store_pattern && bin/store_pattern
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int PAT>
+__global__ __launch_bounds__(256, 1) void k_store(float* __restrict__ dst, long long rows, int iters, unsigned long long* clk) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long n_tiles = rows / 64;
+  f32x4 v = {(float)lane, (float)wave, 1.0f, 2.0f};
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it)
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      float* base = dst + (size_t)tile * 64 * 512;                    // 64 rows x 512 floats
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                                    // four 16-row groups
+#pragma unroll
+        for (int mo = 0; mo < 8; ++mo) {                               // eight stores per group: the wave's 16 rows x 128 features
+          float* p;
+          if (PAT == 0) p = base + (size_t)(16 * g + (lane & 15)) * 512 + 128 * wave + 16 * mo + 4 * (lane >> 4);
+          else if (PAT == 1) p = base + (size_t)(16 * g + 2 * mo + (lane >> 5)) * 512 + 128 * wave + 4 * (lane & 31);
+          else p = base + (size_t)(16 * g) * 512 + (size_t)wave * (16 * 128) + 256 * mo + 4 * lane;      // tile-blocked: 1 KB contiguous
+          v[0] += 1.0f;
+          *reinterpret_cast<f32x4*>(p) = v;
+        }
+      }
+    }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+}
+
+template <int PAT>
+static void run(float* d, long long rows, int cus, unsigned long long* dclk) {
+  const int iters = 4;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_store<PAT>, dim3(cus), dim3(256), 0, 0, d, rows, 1, dclk);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k_store<PAT>, dim3(cus), dim3(256), 0, 0, d, rows, iters, dclk);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long h[1024];
+  hipMemcpy(h, dclk, cus * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (int i = 0; i < cus; ++i) mean += (double)h[i];
+  mean /= cus;
+  const double bytes = (double)rows * 2048.0 * iters;
+  const double stores_per_wave = (double)(rows / 64) / cus * 32.0 * iters;
+  printf("pattern %d: %.3f ms, %.0f GB/s, %.0f shader clocks per store instruction and wave (%.0f per CU-store with 4 waves in flight)\n", PAT, ms,
+         bytes / ms * 1e-6, mean / stores_per_wave, mean / stores_per_wave / 4.0);
+}
+
+int main() {
+  int cus = 256;
+  hipDeviceProp_t pr;
+  hipGetDeviceProperties(&pr, 0);
+  cus = pr.multiProcessorCount;
+  const long long rows = 655360;                                      // one saved tensor of the shipped training step: 1.34 GB
+  float* d;
+  unsigned long long* dclk;
+  hipMalloc(&d, (size_t)rows * 2048);
+  hipMalloc(&dclk, 1024 * sizeof(unsigned long long));
+  printf("%d CUs, %lld rows x 2 KB per pass, 4 passes\n", cus, rows);
+  run<0>(d, rows, cus, dclk);
+  run<1>(d, rows, cus, dclk);
+  run<2>(d, rows, cus, dclk);
+  run<0>(d, rows, cus, dclk);
+  return 0;
+}
