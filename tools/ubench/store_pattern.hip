@@ -38,6 +38,61 @@ __global__ __launch_bounds__(256, 1) void k_store(float* __restrict__ dst, long 
   if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
 
+// Part 2: the same stores next to matrix work, at the per-view training kernel's ratio (32 stores of 1 KB per wave for ~49 k clocks of MFMAs):
+// SPREAD = 0: the 32 stores in one burst in front of the MFMAs (save_block); 1: one store every 96 MFMAs; 2: no stores (the floor).
+template <int SPREAD>
+__global__ __launch_bounds__(256, 1) void k_mix(float* __restrict__ dst, long long rows, const float* __restrict__ in, float* __restrict__ out,
+                                                unsigned long long* clk) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long n_tiles = rows / 64;
+  f32x4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  h8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)in[lane + i]; b[i] = (_Float16)in[lane + 8 + i]; }
+  f32x4 v = {(float)lane, (float)wave, 1.0f, 2.0f};
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    float* base = dst + (size_t)tile * 64 * 512;
+    auto store = [&](int j) {                                          // store j of the tile's 32 (pattern 0)
+      const int g = j >> 3, mo = j & 7;
+      v[0] += 1.0f;
+      *reinterpret_cast<f32x4*>(base + (size_t)(16 * g + (lane & 15)) * 512 + 128 * wave + 16 * mo + 4 * (lane >> 4)) = v;
+    };
+    if (SPREAD == 0) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) store(j);
+    }
+#pragma unroll 1
+    for (int j = 0; j < 32; ++j) {
+      if (SPREAD == 1) store(j);
+#pragma unroll
+      for (int r = 0; r < 96; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(a), "v"(b));
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+  f32x4 sum = acc[0];
+  for (int i = 1; i < 8; ++i) sum += acc[i];
+  if (sum[0] == 12345.678f) out[threadIdx.x] = sum[1];                // (keeps the accumulators alive)
+}
+
+template <int SPREAD>
+static void run_mix(float* d, long long rows, int cus, unsigned long long* dclk, const float* din, float* dout) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_mix<SPREAD>, dim3(cus), dim3(256), 0, 0, d, rows / 4, din, dout, dclk);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k_mix<SPREAD>, dim3(cus), dim3(256), 0, 0, d, rows, din, dout, dclk);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double mfma_ms = (double)(rows / 64) / cus * 32 * 96 * 16 / 2.1e6;      // at 2.1 GHz, 16 clocks per MFMA
+  printf("mix, %s: %.3f ms (the MFMAs alone at 2.1 GHz: %.3f ms)\n", SPREAD == 0 ? "32-store burst in front of 3072 MFMAs" : SPREAD == 1 ? "one store every 96 MFMAs" : "no stores", ms, mfma_ms);
+}
+
 template <int PAT>
 static void run(float* d, long long rows, int cus, unsigned long long* dclk) {
   const int iters = 4;
@@ -77,5 +132,13 @@ int main() {
   run<1>(d, rows, cus, dclk);
   run<2>(d, rows, cus, dclk);
   run<0>(d, rows, cus, dclk);
+  float *din, *dout;
+  hipMalloc(&din, 4096); hipMalloc(&dout, 4096);
+  hipMemset(din, 0, 4096);
+  run_mix<2>(d, rows, cus, dclk, din, dout);
+  run_mix<0>(d, rows, cus, dclk, din, dout);
+  run_mix<1>(d, rows, cus, dclk, din, dout);
+  run_mix<0>(d, rows, cus, dclk, din, dout);
+  run_mix<1>(d, rows, cus, dclk, din, dout);
   return 0;
 }
