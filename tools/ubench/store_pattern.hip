@@ -93,6 +93,78 @@ static void run_mix(float* d, long long rows, int cus, unsigned long long* dclk,
   printf("mix, %s: %.3f ms (the MFMAs alone at 2.1 GHz: %.3f ms)\n", SPREAD == 0 ? "32-store burst in front of 3072 MFMAs" : SPREAD == 1 ? "one store every 96 MFMAs" : "no stores", ms, mfma_ms);
 }
 
+// Part 3: as part 2, but the MFMAs CONSUME A STREAM OF LOADS (a weight ring: every 12 MFMAs use a 1 KB fragment requested two steps earlier from
+// a 3 MB L2-resident buffer) -- the situation of the per-view kernel: loads queue behind the stores on the in-order vector-memory path.
+template <int SPREAD>
+__global__ __launch_bounds__(256, 1) void k_ring(float* __restrict__ dst, long long rows, const float* __restrict__ wbuf, float* __restrict__ out,
+                                                 unsigned long long* clk) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long n_tiles = rows / 64;
+  f32x4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const h8* wp = reinterpret_cast<const h8*>(wbuf) + (size_t)wave * 768 * 64 + lane;      // 768 fragments of 1 KB per wave: 3 MB per workgroup
+  h8 b;
+  for (int i = 0; i < 8; ++i) b[i] = (_Float16)1.0f;
+  f32x4 v = {(float)lane, (float)wave, 1.0f, 2.0f};
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  if (SPREAD == 3) {                                                   // bursts, the workgroups started an eighth of a tile apart (8 phase groups)
+#pragma unroll 1
+    for (int k = 0; k < (int)((blockIdx.x >> 3) & 7) * 32; ++k)
+#pragma unroll
+      for (int r = 0; r < 12; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(b), "v"(b));
+  }
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    float* base = dst + (size_t)tile * 64 * 512;
+    auto store = [&](int j) {
+      const int g = j >> 3, mo = j & 7;
+      v[0] += 1.0f;
+      if (SPREAD == 4) *reinterpret_cast<f32x4*>(base + (size_t)(16 * g) * 512 + (size_t)wave * (16 * 128) + 256 * mo + 4 * lane) = v;      // 1 KB contiguous
+      else *reinterpret_cast<f32x4*>(base + (size_t)(16 * g + (lane & 15)) * 512 + 128 * wave + 16 * mo + 4 * (lane >> 4)) = v;
+    };
+    if (SPREAD == 0 || SPREAD == 3 || SPREAD == 4) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) store(j);
+    }
+    h8 w0 = wp[0], w1 = wp[64], w2;
+#pragma unroll 1
+    for (int st = 0; st < 255; st += 3) {                              // 255 steps of 12 MFMAs, the fragment of step st + 2 requested in step st
+      w2 = wp[(size_t)((st + 2) % 768) * 64];
+      if (SPREAD == 1 && (st % 24) == 0) store(st / 8);
+#pragma unroll
+      for (int r = 0; r < 12; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(w0), "v"(b));
+      w0 = wp[(size_t)((st + 3) % 768) * 64];
+      if (SPREAD == 1 && (st % 24) == 8 * 1 + 1) store(st / 8);
+#pragma unroll
+      for (int r = 0; r < 12; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(w1), "v"(b));
+      w1 = wp[(size_t)((st + 4) % 768) * 64];
+      if (SPREAD == 1 && (st % 24) == 8 * 2 + 2) store(st / 8);
+#pragma unroll
+      for (int r = 0; r < 12; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(w2), "v"(b));
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+  f32x4 sum = acc[0];
+  for (int i = 1; i < 8; ++i) sum += acc[i];
+  if (sum[0] == 12345.678f) out[threadIdx.x] = sum[1];
+}
+
+template <int SPREAD>
+static void run_ring(float* d, long long rows, int cus, unsigned long long* dclk, const float* wbuf, float* dout) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_ring<SPREAD>, dim3(cus), dim3(256), 0, 0, d, rows / 4, wbuf, dout, dclk);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k_ring<SPREAD>, dim3(cus), dim3(256), 0, 0, d, rows, wbuf, dout, dclk);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("ring, %s: %.3f ms\n", SPREAD == 0 ? "32-store burst in front of 255 x 12 MFMAs fed by loads" : SPREAD == 1 ? "the stores spread, one every ~8 steps" : SPREAD == 3 ? "bursts, workgroups in 8 phase groups an eighth of a tile apart" : SPREAD == 4 ? "32-store burst, every store one contiguous KB (tile-blocked layout)" : "no stores", ms);
+}
+
 template <int PAT>
 static void run(float* d, long long rows, int cus, unsigned long long* dclk) {
   const int iters = 4;
@@ -132,6 +204,11 @@ int main() {
   run<1>(d, rows, cus, dclk);
   run<2>(d, rows, cus, dclk);
   run<0>(d, rows, cus, dclk);
+  printf("the same stores from 32 and from 8 workgroups only (is ~90 clocks per store the chip's write rate or the CU's?):\n");
+  run<0>(d, rows / 8, 32, dclk);
+  run<0>(d, rows / 32, 8, dclk);
+  run<2>(d, rows / 32, 8, dclk);
+  run<1>(d, rows / 32, 8, dclk);
   float *din, *dout;
   hipMalloc(&din, 4096); hipMalloc(&dout, 4096);
   hipMemset(din, 0, 4096);
@@ -140,5 +217,16 @@ int main() {
   run_mix<1>(d, rows, cus, dclk, din, dout);
   run_mix<0>(d, rows, cus, dclk, din, dout);
   run_mix<1>(d, rows, cus, dclk, din, dout);
+  float* wbuf;
+  hipMalloc(&wbuf, (size_t)4 * 768 * 1024);
+  hipMemset(wbuf, 0, (size_t)4 * 768 * 1024);
+  run_ring<2>(d, rows, cus, dclk, wbuf, dout);
+  run_ring<0>(d, rows, cus, dclk, wbuf, dout);
+  run_ring<1>(d, rows, cus, dclk, wbuf, dout);
+  run_ring<0>(d, rows, cus, dclk, wbuf, dout);
+  run_ring<1>(d, rows, cus, dclk, wbuf, dout);
+  run_ring<3>(d, rows, cus, dclk, wbuf, dout);
+  run_ring<4>(d, rows, cus, dclk, wbuf, dout);
+  run_ring<4>(d, rows, cus, dclk, wbuf, dout);
   return 0;
 }
