@@ -150,6 +150,61 @@ __global__ __launch_bounds__(256, 1) void k_ring(float* __restrict__ dst, long l
   if (sum[0] == 12345.678f) out[threadIdx.x] = sum[1];
 }
 
+// Part 4: the stores of the four computing waves issued by a FIFTH wave (its vector-memory queue holds nothing else; the hand-over of the data
+// through LDS is not modelled), one barrier per tile; the computing waves as in part 3 without stores.
+__global__ __launch_bounds__(320, 1) void k_ring_store_wave(float* __restrict__ dst, long long rows, const float* __restrict__ wbuf, float* __restrict__ out) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long n_tiles = rows / 64;
+  f32x4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const h8* wp = reinterpret_cast<const h8*>(wbuf) + (size_t)(wave & 3) * 768 * 64 + lane;
+  h8 b;
+  for (int i = 0; i < 8; ++i) b[i] = (_Float16)1.0f;
+  f32x4 v = {(float)lane, (float)wave, 1.0f, 2.0f};
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    float* base = dst + (size_t)tile * 64 * 512;
+    __syncthreads();
+    if (wave == 4) {
+#pragma unroll 4
+      for (int j = 0; j < 128; ++j) {                                  // the four waves' 32 stores each, two rows x 512 bytes per instruction
+        v[0] += 1.0f;
+        *reinterpret_cast<f32x4*>(base + (size_t)(2 * (j >> 2) + (lane >> 5)) * 512 + 128 * (j & 3) + 4 * (lane & 31)) = v;
+      }
+      continue;
+    }
+    h8 w0 = wp[0], w1 = wp[64], w2;
+#pragma unroll 1
+    for (int st = 0; st < 255; st += 3) {
+      w2 = wp[(size_t)((st + 2) % 768) * 64];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(w0), "v"(b));
+      w0 = wp[(size_t)((st + 3) % 768) * 64];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(w1), "v"(b));
+      w1 = wp[(size_t)((st + 4) % 768) * 64];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[r & 7]) : "v"(w2), "v"(b));
+    }
+  }
+  f32x4 sum = acc[0];
+  for (int i = 1; i < 8; ++i) sum += acc[i];
+  if (sum[0] == 12345.678f) out[threadIdx.x] = sum[1];
+}
+static void run_store_wave(float* d, long long rows, int cus, const float* wbuf, float* dout) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_ring_store_wave, dim3(cus), dim3(320), 0, 0, d, rows / 4, wbuf, dout);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k_ring_store_wave, dim3(cus), dim3(320), 0, 0, d, rows, wbuf, dout);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("ring, the stores from a fifth wave (one barrier per tile): %.3f ms\n", ms);
+}
+
 template <int SPREAD>
 static void run_ring(float* d, long long rows, int cus, unsigned long long* dclk, const float* wbuf, float* dout) {
   hipEvent_t e0, e1;
@@ -228,5 +283,8 @@ int main() {
   run_ring<3>(d, rows, cus, dclk, wbuf, dout);
   run_ring<4>(d, rows, cus, dclk, wbuf, dout);
   run_ring<4>(d, rows, cus, dclk, wbuf, dout);
+  run_store_wave(d, rows, cus, wbuf, dout);
+  run_store_wave(d, rows, cus, wbuf, dout);
+  run_ring<2>(d, rows, cus, dclk, wbuf, dout);
   return 0;
 }
