@@ -101,6 +101,10 @@ def parse(argv=None):
                     help="after the timed region render one frame with a fixed seed sharded and once more on rank 0 alone; compare bit "
                          "for bit (default: on for N > 1; with one rank the shards are emulated as 8 ray ranges rendered in turn)")
     ap.add_argument("--no-check-frame", dest="check_frame", action="store_false")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step entry (row f1: SB 4 x 4096 rays x 40 samples, forward + backward)")
+    ap.add_argument("--train-steps", type=int, default=7, help="timed training steps (median; >= 5)")
+    ap.add_argument("--no-encode", action="store_true", help="skip the encode_ms entry (PixelNeRF.encode on 4 x 800x600 images, reported beside the metric)")
+    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (power / sclk) during the timed region")
     ap.add_argument("--precision", choices=["f16x3", "fp32", "f16"], default=None,
                     help="MLP GEMM arithmetic of the headline number (default: the library default, f16x3)")
     return ap.parse_args(argv)
@@ -113,6 +117,78 @@ def kernel_source_digest():
         with open(os.path.join(ROOT, "diner_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def train_source_digest():
+    """sha256 of the training-kernel sources (profiles/pmc_latest.json["train"] records the digest its PMC run was taken with)."""
+    h = hashlib.sha256()
+    for f in ("train.hip", "train_512.hip", "train_lin512.hip", "train_wgrad512.hip", "mlp_h3n.hip", "field_common.hpp", "common.hpp"):
+        with open(os.path.join(ROOT, "diner_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def host_physical_cores():
+    """Physical cores of this host (distinct thread-sibling sets), hardware threads -- north_star: 'core count stated'."""
+    sibs = set()
+    try:
+        base = "/sys/devices/system/cpu"
+        for d in os.listdir(base):
+            if d.startswith("cpu") and d[3:].isdigit():
+                fn = os.path.join(base, d, "topology", "thread_siblings_list")
+                if os.path.exists(fn):
+                    with open(fn) as f:
+                        sibs.add(f.read().strip())
+    except OSError:
+        pass
+    return (len(sibs) or None), os.cpu_count()
+
+
+class PowerSampler:
+    """rocm-smi (package power, sclk) sampled in a side process while a timed region runs: the headline runs AT the 1400 W package cap
+    (DESIGN.md section 4), so a kernel change shows up as energy per ray before it shows up as time -- the line carries the quantity.
+    A sample is one `rocm-smi --showpower --showclocks` call of device `index` (~0.3 s each); nothing is parsed -> the fields stay null."""
+
+    def __init__(self, index=0, enabled=True):
+        import shutil
+        self.index, self.samples, self.clocks, self._stop, self._thr = index, [], [], None, None
+        self.exe = (shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)) if enabled else None
+
+    def _loop(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run([self.exe, "-d", str(self.index), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                break
+            m = re.search(r"Power \(W\): ([\d.]+)", out)
+            if m:
+                self.samples.append(float(m.group(1)))
+            m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+            if m:
+                self.clocks.append(float(m.group(1)))
+            self._stop.wait(0.1)
+
+    def __enter__(self):
+        if self.exe:
+            import threading
+            self._stop = threading.Event()
+            self._thr = threading.Thread(target=self._loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=15)
+
+    def summary(self, elapsed_s, rays):
+        med = lambda v: sorted(v)[len(v) // 2] if v else None
+        pw, ck = med(self.samples), med(self.clocks)
+        return {"power_w": pw, "sclk_mhz": ck, "power_samples": len(self.samples),
+                "joule_per_mray": round(pw * elapsed_s / (rays / 1e6), 1) if pw and rays else None,
+                "power_source": "median of rocm-smi --showpower --showclocks samples taken by a side process during the timed region" if pw
+                                else "no rocm-smi sample parsed"}
 
 
 # ---- self-launch: `python bench.py --gpus N` starts its own N ranks -------------------------------------------------------------
@@ -171,6 +247,133 @@ def self_launch(n, argv):
         print("bench.py: rank 0 produced no JSON line", file=sys.stderr)
         rc = 1
     return rc
+
+
+def encode_entry(torch, ops, dev, msd, W, H, make_scene, build_modules, repeats=3):
+    """PixelNeRF.encode (pixelnerf.py:35-53, image_encoder.py:225-291) on 4 source images of the frame size through this repo's own modules:
+    normalisation + depth2normal (HIP) + the ResNet34 trunk (torch / MIOpen, random init) + feature pyramid, then what the renderer adds per
+    scene: channels-last relayout (HipScene) and the lin_z hoist (diner_scene_prepare_f32).  Not part of `value`: reported beside it."""
+    sc = make_scene(W, H, seed=0, latent=False)
+    nerf, _ = build_modules(dict(sc, latent=torch.zeros(4, 512, 2, 2)), msd, dev)
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.rand(1, 4, 3, H, W, generator=g).to(dev)
+    depths, stds = sc["depths"][None].to(dev), sc["depths_std"][None].to(dev)
+    E, Km = sc["src_extrinsics"][None].to(dev), sc["src_intrinsics"][None].to(dev)
+    mlp = nerf.hip_mlp()
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    rows = []
+    with torch.no_grad():
+        for i in range(repeats + 1):
+            e = [ev() for _ in range(4)]
+            e[0].record()
+            nerf.encode(imgs, depths, stds, E, Km)
+            e[1].record()
+            scene = nerf.hip_scene(0)
+            e[2].record()
+            scene.prepare(mlp, force=True)
+            e[3].record()
+            torch.cuda.synchronize()
+            if i:
+                rows.append([e[k].elapsed_time(e[k + 1]) for k in range(3)])
+    med = lambda k: round(sorted(r[k] for r in rows)[len(rows) // 2], 3)
+    lat = nerf.encoder.latent
+    return {"encode_ms": round(med(0) + med(1) + med(2), 3), "trunk_and_prep_ms": med(0), "relayout_ms": med(1), "hoist_ms": med(2),
+            "images": f"4 x {W}x{H} RGB + depth / std maps", "latent": list(lat.shape[1:]),
+            "note": "PixelNeRF.encode of src.models (normalise, depth2normal on the device, ResNet34 trunk through torch / MIOpen with random-init "
+                    "weights, pyramid upsampling) + channels-last relayout + lin_z hoist; median of %d after one warm-up; excluded from `value`, "
+                    "which re-runs only the hoist per frame" % repeats}
+
+
+def train_entry(torch, ops, dev, msd, make_scene, build_modules, n_steps, SB=4, NR=4096, K=40, size=(400, 300)):
+    """One optimiser step's rendering work as the shipped configs run it: SB 4 objects x a 64 x 64 ray patch x 40 samples (15 gaussian, 1000
+    candidates) through NeRFRendererDGS.forward in grad mode + MSE on fine.rgb + backward into the MLP parameters and encoder.latent
+    (diner.py:217-290, configs/train_dtu.yaml:16,52-63).  The parameters are written in place before every step (as an optimiser does), so
+    nothing cached per parameter version is left out.  Steps are enqueued back to back (no synchronisation inside the timed region); HIP events
+    on the stream give the per-step period and the forward / backward split."""
+    import time as _t
+    from diner_amd import train as T
+    Wt, Ht = size
+    G = int(15 * K / 40)
+    scs = [make_scene(Wt, Ht, seed=s) for s in range(SB)]
+    nerf, R = build_modules(scs, msd, dev)
+    nerf.train()
+    nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+    E = torch.stack([s["target_extrinsics"] for s in scs])
+    Km = torch.stack([s["target_intrinsics"] for s in scs])
+    rays_all = ops.gen_rays(E, Km, Wt, Ht, scs[0]["znear"], scs[0]["zfar"], dev)
+    side = int(round(NR ** 0.5))
+    ys, xs = torch.meshgrid(torch.arange(side) + (Ht - side) // 2, torch.arange(side) + (Wt - side) // 2, indexing="ij")
+    r = rays_all[:, (ys * Wt + xs).reshape(-1).to(dev)].contiguous()
+    del rays_all
+    gt = torch.rand(SB, NR, 3, device=dev)
+    ren = R(n_samples=K, n_depth_candidates=1000, n_gaussian=G, white_bkgd=True)
+    params = [p for p in nerf.parameters()]
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def step(e=None):
+        for p in params:
+            p.grad = None
+        nerf.encoder.latent.grad = None
+        with torch.no_grad():
+            torch._foreach_add_(params, 0.0)
+        if e:
+            e[0].record()
+        out = ren.forward(nerf, r)
+        loss = torch.nn.functional.mse_loss(out.fine.rgb, gt)
+        if e:
+            e[1].record()
+        loss.backward()
+        if e:
+            e[2].record()
+
+    torch.cuda.reset_peak_memory_stats()
+    step()
+    step()
+    torch.cuda.synchronize()
+    evs = [[ev() for _ in range(3)] for _ in range(n_steps + 1)]
+    host = []
+    t0 = _t.perf_counter()
+    for i in range(n_steps + 1):
+        h0 = _t.perf_counter()
+        step(evs[i])
+        host.append(_t.perf_counter() - h0)
+    enq = _t.perf_counter() - t0
+    torch.cuda.synchronize()
+    wall = _t.perf_counter() - t0
+    med = lambda v: sorted(v)[len(v) // 2]
+    period = [evs[i][0].elapsed_time(evs[i + 1][0]) for i in range(n_steps)]
+    fwd = [evs[i][0].elapsed_time(evs[i][1]) for i in range(n_steps)]
+    bwd = [evs[i][1].elapsed_time(evs[i][2]) for i in range(n_steps)]
+    ms = med(period)
+    P = NR * K
+    f_ref = 2 * P * (4 * (55 * 512 + 9 * 512 * 512) + 4 * 512 * 512 + 4 * 512)          # the reference's forward FLOPs per object
+    f_exec_fwd = 2 * P * (4 * (55 * 512 + 6 * 512 * 512) + 4 * 512 * 512 + 4 * 512) + 2 * 3 * 512 * 512 * 4 * scs[0]["latent"].shape[-1] * scs[0]["latent"].shape[-2]
+    ref_tf = 3 * SB * f_ref / (ms * 1e-3) / 1e12
+    issued = 3 * SB * (f_exec_fwd + 2 * f_ref) / (ms * 1e-3) / 1e12
+    hbm = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            ent = json.load(f).get("train")
+        if ent and ent.get("source_digest") == train_source_digest():
+            hbm = ent.get("hbm_gb_per_object_step")
+    except Exception:
+        pass
+    saved, scratch = T.workspace_split(P, 4)
+    return {"ms_per_step": round(ms, 2), "rays_per_s": round(SB * NR / (ms * 1e-3), 1), "steps": n_steps,
+            "ms_all": [round(t, 2) for t in period], "forward_ms": round(med(fwd), 2), "backward_ms": round(med(bwd), 2),
+            "ms_per_step_wall": round(wall / (n_steps + 1) * 1e3, 2), "host_enqueue_ms": round(med(host) * 1e3, 2),
+            "host_enqueue_total_ms": round(enq * 1e3, 1),
+            "tflops_fp32_equivalent": round(ref_tf, 1), "mfma_issued_tflops": round(issued, 1), "frac": round(issued / PEAK_F16_MFMA_TFLOPS, 4),
+            "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "saved_gib_per_object": round(saved / 2 ** 30, 2), "hbm_gb_per_object_step": hbm,
+            "batched": T.batch_enabled(P, [nerf.hip_scene(sb) for sb in range(SB)]),
+            "config": {"workload": f"row f1: SB {SB} objects x {NR} rays (a {side} x {side} patch) x {K} samples ({G} gaussian, 1000 candidates), 4 source views of "
+                                   f"{Wt}x{Ht}, NeRFRendererDGS.forward in grad mode + MSE + backward into the MLP parameters and encoder.latent; "
+                                   f"parameters written in place before every step", "objects": SB, "rays_per_object": NR, "samples_per_ray": K},
+            "note": "ms_per_step = median period between the steps' first HIP events (steps enqueued back to back, nothing synchronised in "
+                    "between); tflops_fp32_equivalent = 3 x the reference's forward FLOPs (forward + data gradient + weight gradient) / time; "
+                    "mfma_issued = 3 fp16 MFMA products per fp32 product of the EXECUTED work (forward with lin_z hoisted to the maps, backward as the "
+                    "reference's), frac against the dense fp16 peak"}
 
 
 def main():
@@ -274,7 +477,7 @@ def main():
                         frame[0] = torch.cat((rgb[0].permute(1, 2, 0).reshape(NRF, 3), depth[0].reshape(NRF, 1)), dim=1)
                 finally:
                     ops.set_precision(head)
-            res.update(step=step, out=None, scene=nerf.hip_scene(0), nerf=nerf)
+            res.update(step=step, out=None, scene=nerf.hip_scene(0), nerf=nerf, mlp=nerf.hip_mlp())
             return res
 
         scene = ops.HipScene(sc["latent"].to(dev), depths, sc["depths_std"].to(dev), normals,
@@ -326,7 +529,7 @@ def main():
                 dist.gather(src, gat, dst=0)
             else:
                 frame[0] = out
-        res.update(step=step, out=out, scene=scene, render_range=render_range)
+        res.update(step=step, out=out, scene=scene, render_range=render_range, mlp=mlp)
         return res
 
     W, H, K = args.width, args.height, args.samples
@@ -403,9 +606,12 @@ def main():
                 "points_per_launch": round(prof["points"] / max(prof["launches"], 1)), "traffic": tr,
                 "whole_path_achieved": round(path, 2), "whole_path_frac": round(path / peak, 4)}
 
-    def measure(stepf, m, rays, n, dims=None):
-        """median-of-n timed frames of `stepf` in mode m (each frame bracketed by barrier + synchronize) + roofline figures."""
+    def measure(stepf, m, rays, n, dims=None, handle=None):
+        """median-of-n timed frames of `stepf` in mode m (each frame bracketed by barrier + synchronize) + roofline figures;
+        fallback_launches: field launches of the timed frames that the gated exact-fp32 pass recomputed (must be 0: else the number is that pass's)."""
         sync()
+        handle = handle if handle is not None else mlp
+        handle.fallback_launches(reset=True)
         ops.profile_enable(True)
         ops.profile_collect()
         ts = []
@@ -416,12 +622,16 @@ def main():
         ops.profile_enable(False)
         med = sorted(ts)[len(ts) // 2]
         return {"rays_per_s": round(rays / med, 1), "ms_per_step": round(med * 1e3, 2), "steps": n,
-                "ms_all": [round(t * 1e3, 2) for t in ts], "mode": names[m], "roofline": roof(m, prof, sum(ts), dims)}
+                "ms_all": [round(t * 1e3, 2) for t in ts], "mode": names[m], "fallback_launches": handle.fallback_launches(reset=True),
+                "roofline": roof(m, prof, sum(ts), dims)}
 
     for i in range(args.warmup):
         step(i, head)
     wl_head["record_phases"] = bool(multi and not args.weak and not args.via_modules)
-    elapsed, prof = timed(args.steps, head, args.warmup, profile=True)
+    wl_head["mlp"].fallback_launches(reset=True)
+    with PowerSampler(dev.index or 0, enabled=not args.no_power and rank == 0) as psamp:
+        elapsed, prof = timed(args.steps, head, args.warmup, profile=True)
+    head_fallbacks = wl_head["mlp"].fallback_launches(reset=True)
     wl_head["record_phases"] = False
     if not os.environ.get("DINER_AMD_LIB"):        # (timing experiments with ablated libraries produce garbage)
         if out is not None:
@@ -587,7 +797,10 @@ def main():
                          f"(restatement of the reference renderer, pinned bit-exact; 100,000-point MLP chunks) per repeat; "
                          f"1 warm-up (512 rays, after the thread sweep) + {len(times)} timed repeats, median {med:.1f} s (min {times[0]:.1f}, max "
                          f"{times[-1]:.1f}); {best} of {hw} hardware threads = fastest of the sweep {sweep} (rays/s on 256 rays)",
-               "repeats_s": [round(t, 2) for t in times], "thread_sweep_rays_per_s": sweep, "host_threads": hw}
+               "repeats_s": [round(t, 2) for t in times], "thread_sweep_rays_per_s": sweep, "host_threads": hw,
+               "host_cores": host_physical_cores()[0], "torch_threads_used": best,
+               "cores_note": "`cores` = torch intra-op threads of the fastest setting of the sweep (what was actually used); `host_cores` = physical "
+                             "cores of the box (distinct thread-sibling sets), `host_threads` = hardware threads"}
 
     # ---- the other single-GPU configurations of BASELINE.json + the module-level API (N = 1 only) ---------------------
     configs = {}
@@ -604,7 +817,7 @@ def main():
             wl = workload(cw, ch, ck, cfs, cfs, via_modules=via)
             for m in cmodes:
                 wl["step"](0, m, max_rays=2 * args.ray_batch)          # warm-up on the first two ray batches
-                e = measure(wl["step"], m, cw * ch, nx, (cw, ch, ck))
+                e = measure(wl["step"], m, cw * ch, nx, (cw, ch, ck), handle=wl["mlp"])
                 if wl["out"] is not None:
                     assert torch.isfinite(wl["out"]).all()
                 else:
@@ -617,6 +830,23 @@ def main():
                 configs[f"{key} [{names[m]}]"] = e
             del wl
             torch.cuda.empty_cache()
+
+    # ---- encode, reported beside the metric ("encode excluded, reported separately"; pixelnerf.py:35-53) ------------------------
+    encode = None
+    if world == 1 and not args.no_encode and not args.emulate_shard:
+        try:
+            encode = encode_entry(torch, ops, dev, msd, W, H, make_scene, build_modules)
+        except Exception as e:      # (a trunk that does not run on this box must not cost the headline)
+            encode = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
+    # ---- the training step, row f1 (N = 1 only; DINER.calc_losses, diner.py:217-290 at configs/train_dtu.yaml:16,52-63) -----------------
+    train_line = None
+    if world == 1 and not args.no_train and not args.emulate_shard:
+        del wl_head, step, out, frame, scene
+        torch.cuda.empty_cache()
+        train_line = train_entry(torch, ops, dev, msd, make_scene, build_modules, max(5, args.train_steps))
+        torch.cuda.empty_cache()
 
     if rank == 0:
         frame_name = f"{W}x{H}"
@@ -661,6 +891,10 @@ def main():
                        "rays_per_step": rays_per_step, "rays_per_gpu_per_step": hi - lo, "samples_per_ray": K, "src_views": 4,
                        "frame": frame_name, "parallelism": par},
             "backend": backend, "ranks_share_gpu": bool(shared and world > 1),
+            "fallback_launches": head_fallbacks,
+            "energy": psamp.summary(elapsed, rays_per_step * args.steps),
+            "encode": encode,
+            "train": train_line,
             "dist": dist_info, "frame_check": frame_check,
             "roofline": roofline,
             "modes": modes,

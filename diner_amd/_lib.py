@@ -33,6 +33,7 @@ SIGNATURES = {
     "diner_last_error": (C.c_char_p, []),
     "diner_mlp_create": (C.c_int, [C.POINTER(DinerMlpParams), C.c_void_p, C.POINTER(C.c_void_p)]),
     "diner_mlp_destroy": (C.c_int, [C.c_void_p]),
+    "diner_mlp_update": (C.c_int, [C.c_void_p, C.POINTER(DinerMlpParams), C.c_int, C.c_void_p]),
     "diner_mlp_weights_fit_f16x3": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "diner_mlp_stamp": (C.c_uint64, [C.c_void_p]),
     "diner_mlp_fallback_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.c_void_p]),
@@ -100,6 +101,11 @@ SIGNATURES = {
     "diner_field_train_backward_s_f32": (C.c_int, [C.POINTER(DinerScene), C.POINTER(DinerMlpParams), C.POINTER(DinerMlpParams),
                                                    C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_train_fused_overflowed": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "diner_field_train_batch_workspace_split": (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "diner_field_train_forward_batch_f32": (C.c_int, [C.POINTER(C.POINTER(DinerScene)), C.c_int, C.c_void_p, C.POINTER(DinerMlpParams), C.c_void_p,
+                                                      C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_train_backward_batch_f32": (C.c_int, [C.POINTER(C.POINTER(DinerScene)), C.c_int, C.POINTER(DinerMlpParams), C.POINTER(DinerMlpParams),
+                                                       C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "diner_quantize_rgb_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_minmax_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "diner_colormap_u8": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
@@ -108,7 +114,7 @@ SIGNATURES = {
                                      C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),
 }
 
-ABI_VERSION = 5          # DINER_ABI_VERSION of include/diner_hip.h
+ABI_VERSION = 6          # DINER_ABI_VERSION of include/diner_hip.h
 _lib = None
 
 
@@ -135,6 +141,7 @@ def load():
     return lib
 
 
+MLP_UPDATE_TRAIN_ONLY = 1      # DINER_MLP_UPDATE_TRAIN_ONLY
 E_INVALID, E_UNSUPPORTED, E_HIP = -1, -2, -3            # include/diner_hip.h:31-33
 
 

@@ -51,14 +51,41 @@ struct DinerMlpImpl {
   float* hn_b_pre; // 7 x 512, x16
   float* hn_b_post;// 4 x 512 x16, then lin_out bias (scale 1, padded to 16)
   float* wmax_dev; // max |parameter| (device scalar, reduced at pack time)
-  float wmax;      // ... read back at the end of diner_mlp_create
+  float wmax;      // ... read back at the end of diner_mlp_create; after diner_mlp_update: when first asked for (wmax_known)
+  int wmax_known;  // 0 after diner_mlp_update (packing enqueued, nothing read back): mlp_wmax() reads it back on demand
+  hipStream_t pack_stream;   // the stream the last packing was enqueued on (the lazy read back of wmax waits for it)
+  int train_only;  // diner_mlp_update(DINER_MLP_UPDATE_TRAIN_ONLY): only what the fused training forward reads is current
   float freq_factor;   // PositionalEncoding.freq_factor of the inputs this MLP was trained on
   unsigned int* fallback_dev;   // launches recomputed by the gated exact-fp32 pass (device counter)
   uint64_t stamp;      // identity of this handle (DinerScene.proj_stamp)
 };
 
+// max |weight| of the handle on the host: known after diner_mlp_create; after diner_mlp_update it is read back (one synchronisation
+// of the stream the packing was enqueued on) the first time somebody asks -- the inference entry points choose their kernels by it on the host, the fused training
+// forward never asks (it gates on the device scalar)
+static std::mutex g_wmax_mu;
+static int mlp_wmax(const DinerMlpImpl* m, float* out) {
+  std::lock_guard<std::mutex> lock(g_wmax_mu);
+  DinerMlpImpl* im = const_cast<DinerMlpImpl*>(m);
+  if (!im->wmax_known) {
+    DINER_HIP_OK(hipMemcpyAsync(&im->wmax, im->wmax_dev, sizeof(float), hipMemcpyDeviceToHost, im->pack_stream));
+    DINER_HIP_OK(hipStreamSynchronize(im->pack_stream));
+    im->wmax_known = 1;
+  }
+  *out = im->wmax;
+  return 0;
+}
+static int mlp_fits(const DinerMlpImpl* m, bool* fits) {
+  float w = 0.0f;
+  int rc = mlp_wmax(m, &w);
+  if (rc) return rc;
+  *fits = w == w && w < 1024.0f;
+  return 0;
+}
+
 // mlp_h3n.hip
-int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w, float** w_out, float** b_pre, float** b_post);
+int h3n_alloc(float** w, float** w_out, float** b_pre, float** b_post);
+int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float* w, float* w_out, float* b_pre, float* b_post, bool train_only);
 int h3n_set_attributes();
 void h3n_launch_pre(const SceneDev& sc, const FieldArgs& fa, const float* w, const float* b, int grid, bool split,
                     unsigned* tile_counter, hipStream_t stream, const SaveActs* sv = nullptr);
@@ -648,7 +675,13 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
   const int cus = prepare_device();
   if (cus < 0) return cus;
   // explicit matrices (diner_mlp_forward_f32) and weights outside the fp16 range always take the exact kernels
-  const bool fits = m->wmax == m->wmax && m->wmax < 1024.0f;
+  DINER_CHECK_ARG(!m->train_only, "field: this handle was last packed with diner_mlp_update(DINER_MLP_UPDATE_TRAIN_ONLY) -- only the "
+                  "layouts of the fused training forward are current; update it without the flag (or create one) for inference");
+  bool fits = false;
+  {
+    int rcf = mlp_fits(m, &fits);
+    if (rcf) return rcf;
+  }
   const bool use_hn = precision != DINER_PRECISION_FP32 && !fa.direct_feat && fits;
   if (use_hn && fa.tz_stride * sizeof(float) >= ((size_t)1 << 32)) {
     set_error("field: one projected feature map is %.1f GiB; the fp16-operand kernels address it with 32-bit offsets "
@@ -723,6 +756,7 @@ static int launch_field(const SceneDev* sc, const DinerMlpImpl* m, FieldArgs fa,
 }
 
 static int launch_hoist(const DinerMlpImpl* m, const float* src, long long rows, float* dst, hipStream_t stream) {
+  DINER_CHECK_ARG(!m->train_only, "scene_prepare: this handle was last packed with DINER_MLP_UPDATE_TRAIN_ONLY (its exact-fp32 lin_z pack is stale)");
   const int cus = prepare_device();
   if (cus < 0) return cus;
   HoistArgs ha{src, dst, rows, m->w_hoist, m->b_hoist};
@@ -740,7 +774,7 @@ struct DinerMlp {
   DinerMlpImpl impl;
 };
 
-static int mlp_pack(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& im) {
+static int mlp_alloc(DinerMlpImpl& im) {
   DINER_HIP_OK(hipMalloc(&im.w_hoist, (size_t)kHoistStages * kStageFloats * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&im.w_pre, (size_t)kPreStages * kStageFloats * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&im.w_post, (size_t)kPostStages * kStageFloats * sizeof(float)));
@@ -749,34 +783,43 @@ static int mlp_pack(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& i
   DINER_HIP_OK(hipMalloc(&im.b_post, (4 * kHidden + 16) * sizeof(float)));
   DINER_HIP_OK(hipMalloc(&im.wmax_dev, sizeof(float)));
   DINER_HIP_OK(hipMalloc(&im.fallback_dev, sizeof(unsigned int)));
-  DINER_HIP_OK(hipMemsetAsync(im.fallback_dev, 0, sizeof(unsigned int), stream));
+  return h3n_alloc(&im.hn_w, &im.hn_w_out, &im.hn_b_pre, &im.hn_b_post);
+}
+
+// Packs the parameters into the handle's buffers on `stream` (no allocation, no synchronisation).  train_only: only what the fused
+// training forward reads -- the four-wave f16x3 layouts, the lin_out packs, the biases of those kernels, the constants of the projected
+// maps (b_hoist) and the weight range; the exact-fp32 stage tiles and the eight-wave layouts keep their old contents.
+static int mlp_pack_into(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& im, bool train_only) {
+  im.pack_stream = stream;
+  im.wmax_known = 0;
   DINER_HIP_OK(hipMemsetAsync(im.wmax_dev, 0, sizeof(float), stream));
   auto pack = [&](const float* W, int rows, int cols, int n_kc, float* dst) {
-    hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, W, rows, cols, n_kc, dst);
+    if (!train_only) hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, W, rows, cols, n_kc, dst);
     hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, stream, W, (long long)rows * cols, im.wmax_dev);
   };
   auto bias = [&](const float* b, int n, int n_pad, float* dst) {
     hipLaunchKernelGGL(k_copy_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, dst);   // (biases stay fp32 in every mode)
   };
+  auto bias_x = [&](const float* b, int n, int n_pad, float* dst) { if (!train_only) bias(b, n, n_pad, dst); };   // (exact kernels only)
   for (int b = 0; b < 3; ++b) bias(p->lin_z_b[b], kHidden, kHidden, im.b_hoist + kHidden * b);
   float* wp = im.w_pre;
   pack(p->lin_in_w, kHidden, kDIn, 1, wp);
   wp += 4 * kStageFloats;
-  bias(p->lin_in_b, kHidden, kHidden, im.b_pre);
+  bias_x(p->lin_in_b, kHidden, kHidden, im.b_pre);
   for (int b = 0; b < 3; ++b) {
     pack(p->lin_z_w[b], kHidden, kLatent, 8, im.w_hoist + (size_t)b * kStagesPerLayer * kStageFloats);
     pack(p->fc0_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
     pack(p->fc1_w[b], kHidden, kHidden, 8, wp);   wp += kStagesPerLayer * kStageFloats;
     float* bb = im.b_pre + kHidden * (1 + 2 * b);
-    bias(p->fc0_b[b], kHidden, kHidden, bb);
+    bias_x(p->fc0_b[b], kHidden, kHidden, bb);
     // x_(b+1) = x_b + fc_1(..) + b1[b] + interp(lin_z[b+1](latent) + bz[b+1]): the two constants of blocks 0 and 1 travel together
     // in the projected map of the NEXT block (the interpolation weights sum to one), so the per-view kernels have no separate
     // fc_1 bias pass for those blocks -- a read-modify-write of a whole accumulator block per GEMM in the feature-sliced kernel
     if (b < 2) {
-      DINER_HIP_OK(hipMemsetAsync(bb + kHidden, 0, kHidden * sizeof(float), stream));
+      if (!train_only) DINER_HIP_OK(hipMemsetAsync(bb + kHidden, 0, kHidden * sizeof(float), stream));
       hipLaunchKernelGGL(k_add_vec, dim3(2), dim3(256), 0, stream, p->fc1_b[b], kHidden, im.b_hoist + kHidden * (b + 1));
     } else {
-      bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
+      bias_x(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
     }
   }
   wp = im.w_post;
@@ -784,22 +827,17 @@ static int mlp_pack(const DinerMlpParams* p, hipStream_t stream, DinerMlpImpl& i
     pack(p->fc0_w[b], kHidden, kHidden, 8, wp); wp += kStagesPerLayer * kStageFloats;
     pack(p->fc1_w[b], kHidden, kHidden, 8, wp); wp += kStagesPerLayer * kStageFloats;
     float* bb = im.b_post + 2 * kHidden * (b - 3);
-    bias(p->fc0_b[b], kHidden, kHidden, bb);
-    bias(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
+    bias_x(p->fc0_b[b], kHidden, kHidden, bb);
+    bias_x(p->fc1_b[b], kHidden, kHidden, bb + kHidden);
   }
-  hipLaunchKernelGGL(k_pack_lin_out, dim3(32), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, wp);
+  if (!train_only) hipLaunchKernelGGL(k_pack_lin_out, dim3(32), dim3(256), 0, stream, p->lin_out_w, 4, kHidden, wp);
   hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, stream, p->lin_out_w, (long long)4 * kHidden, im.wmax_dev);
-  bias(p->lin_out_b, 4, 16, im.b_post + 4 * kHidden);
+  bias_x(p->lin_out_b, 4, 16, im.b_post + 4 * kHidden);
   DINER_LAUNCH_OK();
-  int rc = h3n_pack(p, stream, &im.hn_w, &im.hn_w_out, &im.hn_b_pre, &im.hn_b_post);
-  if (rc) return rc;
-  // The call returns once packing has completed (the caller may free or overwrite the source tensors) and the weight
-  // range is known on the host: one 4-byte read back per parameter version.
-  DINER_HIP_OK(hipMemcpyAsync(&im.wmax, im.wmax_dev, sizeof(float), hipMemcpyDeviceToHost, stream));
-  DINER_HIP_OK(hipStreamSynchronize(stream));
-  return 0;
+  return h3n_pack(p, stream, im.hn_w, im.hn_w_out, im.hn_b_pre, im.hn_b_post, train_only);
 }
 
+static std::atomic<uint64_t> g_next_stamp{1};
 extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp** out) {
   DINER_CHECK_ARG(p && out, "mlp_create: null argument");
   int rc = check_mlp_config(p, "mlp_create", /*poscode=*/true);
@@ -807,15 +845,34 @@ extern "C" int diner_mlp_create(const DinerMlpParams* p, void* stream_, DinerMlp
   DinerMlp* m = new DinerMlp();
   memset(&m->impl, 0, sizeof(m->impl));
   m->impl.freq_factor = p->freq_factor;
-  static std::atomic<uint64_t> next_stamp{1};
-  m->impl.stamp = next_stamp.fetch_add(1);
-  rc = mlp_pack(p, (hipStream_t)stream_, m->impl);
+  m->impl.stamp = g_next_stamp.fetch_add(1);
+  rc = mlp_alloc(m->impl);
+  if (!rc) DINER_HIP_OK(hipMemsetAsync(m->impl.fallback_dev, 0, sizeof(unsigned int), (hipStream_t)stream_));
+  if (!rc) rc = mlp_pack_into(p, (hipStream_t)stream_, m->impl, false);
+  // The call returns once packing has completed (the caller may free or overwrite the source tensors) and the weight
+  // range is known on the host: one 4-byte read back per diner_mlp_create.
+  float w = 0.0f;
+  if (!rc) rc = mlp_wmax(&m->impl, &w);
   if (rc) {                       // nothing is left behind by a failed create
     diner_mlp_destroy(m);
     return rc;
   }
   *out = m;
   return 0;
+}
+
+// ABI v6: new parameter values into an existing handle -- no allocation, no synchronisation (the training step's packed weights: one
+// persistent handle per model, re-packed on the stream every step).  The handle gets a new stamp: maps projected with the old values are refused.
+extern "C" int diner_mlp_update(DinerMlp* m, const DinerMlpParams* p, int flags, void* stream_) {
+  DINER_CHECK_ARG(m && p, "mlp_update: null argument");
+  DINER_CHECK_ARG((flags & ~DINER_MLP_UPDATE_TRAIN_ONLY) == 0, "mlp_update: unknown flags 0x%x", flags);
+  int rc = check_mlp_config(p, "mlp_update", /*poscode=*/true);
+  if (rc) return rc;
+  m->impl.freq_factor = p->freq_factor;
+  m->impl.stamp = g_next_stamp.fetch_add(1);
+  m->impl.wmax_known = 0;
+  m->impl.train_only = (flags & DINER_MLP_UPDATE_TRAIN_ONLY) ? 1 : 0;
+  return mlp_pack_into(p, (hipStream_t)stream_, m->impl, m->impl.train_only != 0);
 }
 
 extern "C" int diner_mlp_destroy(DinerMlp* m) {
@@ -831,8 +888,11 @@ extern "C" int diner_mlp_destroy(DinerMlp* m) {
 
 extern "C" int diner_mlp_weights_fit_f16x3(const DinerMlp* mlp, float* max_abs) {
   DINER_CHECK_ARG(mlp, "mlp_weights_fit_f16x3: null handle");
-  if (max_abs) *max_abs = mlp->impl.wmax;
-  return (mlp->impl.wmax == mlp->impl.wmax && mlp->impl.wmax < 1024.0f) ? 1 : 0;
+  float w = 0.0f;
+  int rc = mlp_wmax(&mlp->impl, &w);      // (after diner_mlp_update: read back here, behind the packing's stream)
+  if (rc) return rc;
+  if (max_abs) *max_abs = w;
+  return (w == w && w < 1024.0f) ? 1 : 0;
 }
 
 extern "C" uint64_t diner_mlp_stamp(const DinerMlp* mlp) { return mlp ? mlp->impl.stamp : 0; }
@@ -962,6 +1022,25 @@ extern "C" int diner_field_from_points_f32(const DinerScene* scene, const DinerM
 // (diner_mlp_create folds them: the interpolation weights sum to one)
 const float* mlp_hoist_bias(const DinerMlp* mlp) { return mlp->impl.b_hoist; }
 
+// host-known reasons for which field_forward_save would return DINER_E_UNSUPPORTED, checked before the caller enqueues anything
+int field_forward_save_supported(const DinerScene* scene, const DinerMlp* mlp) {
+  const DinerMlpImpl* im = &mlp->impl;
+  if (im->wmax_known && !(im->wmax == im->wmax && im->wmax < 1024.0f)) {
+    set_error("field_forward_save: weights outside the fp16 split (max |w| %g)", (double)im->wmax);
+    return DINER_E_UNSUPPORTED;
+  }
+  if ((size_t)scene->nv * scene->Hf * scene->Wf * kLatent * sizeof(float) >= ((size_t)1 << 32)) {
+    set_error("field_forward_save: projected map beyond the 32-bit addressing of the fp16-operand kernels");
+    return DINER_E_UNSUPPORTED;
+  }
+  return 0;
+}
+
+__global__ void k_wmax_gate(const float* __restrict__ wmax, int* __restrict__ flag) {
+  const float w = *wmax;
+  if (!(w == w && w < 1024.0f)) *flag = 1;
+}
+
 int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float* xyz, const float* viewdirs, long long P, float* out,
                        void* workspace, const SaveActs& sv, int** overflow_flag, hipStream_t stream) {
   SceneDev sd;
@@ -970,7 +1049,10 @@ int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float
   const DinerMlpImpl* im = &mlp->impl;
   const int cus = prepare_device();
   if (cus < 0) return cus;
-  if (!(im->wmax == im->wmax && im->wmax < 1024.0f)) {
+  // weights outside the fp16 split (max |w| >= 1024): known on the host after diner_mlp_create -> DINER_E_UNSUPPORTED (the caller keeps the
+  // layer-wise forward); after diner_mlp_update (nothing read back) the launch's flag is raised ON THE DEVICE in front of the kernels --
+  // the caller's gated layer-wise repeat then redoes the object, no host synchronisation
+  if (im->wmax_known && !(im->wmax == im->wmax && im->wmax < 1024.0f)) {
     set_error("field_forward_save: weights outside the fp16 split (max |w| %g)", (double)im->wmax);
     return DINER_E_UNSUPPORTED;
   }
@@ -990,6 +1072,7 @@ int field_forward_save(const DinerScene* scene, const DinerMlp* mlp, const float
   fa.freq_factor = im->freq_factor;
   int* flag = reinterpret_cast<int*>((char*)workspace + xpre_bytes(P, sd.nv));
   DINER_HIP_OK(hipMemsetAsync(flag, 0, 24 * sizeof(int), stream));
+  if (!im->wmax_known) hipLaunchKernelGGL(k_wmax_gate, dim3(1), dim3(1), 0, stream, im->wmax_dev, flag);
   const long long n_t16 = (P + kPtsPerWave - 1) / kPtsPerWave;
   const int grid_pre = (int)(n_t16 < cus ? n_t16 : cus);
   const long long n_tiles = (n_t16 + 3) / 4;

@@ -2432,9 +2432,10 @@ __global__ void k_scale_pad(const float* __restrict__ src, int n, int n_pad, flo
 
 // w: lin_in + 6 per-view + 4 post layers (n-split fragments); w_out: lin_out fragments; b_pre: 7 x 512 (x16); b_post: 4 x 512
 // (x16) + the lin_out bias at scale 1 (padded to 16).  The caller frees whatever was allocated when this fails.
-int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float** w_lin_out, float** b_pre, float** b_post) {
+static size_t h3n_halfs4() { return (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192; }      // lin_in, 6 per-view layers, 4 post layers
+int h3n_alloc(float** w_out, float** w_lin_out, float** b_pre, float** b_post) {
   using namespace h3n;
-  const size_t halfs4 = (size_t)4 * 2 * 8192 + (size_t)(6 + 4) * 4 * 16 * 8192;      // lin_in, 6 per-view layers, 4 post layers
+  const size_t halfs4 = h3n_halfs4();
   const size_t halfs8 = w8::kLinInHalfs8 + 6 * w8::kLayerHalfs8;                    // the per-view layers in the 8-wave kernels' order: hi plane,
   const size_t halfs8x = w8::kLinInHalfs8x + 6 * w8::kLayerHalfs8x;                 // ... hi + lo planes,
   const size_t halfs = halfs4 + halfs8 + halfs8x + 4 * w8::kLayerHalfs8;             // and the four post layers (hi plane)
@@ -2442,6 +2443,19 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
   DINER_HIP_OK(hipMalloc(w_lin_out, (size_t)16384 * sizeof(_Float16) + kLinOutWBytes));      // MFMA fragments + the fp32 pack of the vector-ALU lin_out
   DINER_HIP_OK(hipMalloc(b_pre, 7 * kHidden * sizeof(float)));
   DINER_HIP_OK(hipMalloc(b_post, (5 * kHidden + 16) * sizeof(float)));
+  return 0;
+}
+// train_only: the four-wave layouts, the lin_out packs and the biases (what k_train_fwd_pre / k_train_fwd_post read); the eight-wave
+// layouts keep their old contents
+int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float* w_out_, float* w_lin_out_, float* b_pre_, float* b_post_, bool train_only) {
+  using namespace h3n;
+  float** w_out = &w_out_;
+  float** w_lin_out = &w_lin_out_;
+  float** b_pre = &b_pre_;
+  float** b_post = &b_post_;
+  const size_t halfs4 = h3n_halfs4();
+  const size_t halfs8 = w8::kLinInHalfs8 + 6 * w8::kLayerHalfs8;
+  const size_t halfs8x = w8::kLinInHalfs8x + 6 * w8::kLayerHalfs8x;
   auto bias = [&](const float* b, int n, int n_pad, float scale, float* dst) {
     hipLaunchKernelGGL(k_scale_pad, dim3(4), dim3(256), 0, stream, b, n, n_pad, scale, dst);
   };
@@ -2476,6 +2490,10 @@ int h3n_pack(const DinerMlpParams* p, hipStream_t stream, float** w_out, float**
     wp += (size_t)4 * 16 * 8192;
     hipLaunchKernelGGL(k_pack_layer_h3n, dim3(512), dim3(256), 0, stream, p->fc1_w[b], kHidden, kHidden, 16, kScale, wp);
     wp += (size_t)4 * 16 * 8192;
+  }
+  if (train_only) {
+    DINER_LAUNCH_OK();
+    return 0;
   }
   {
     _Float16* w8p = (_Float16*)*w_out + halfs4;

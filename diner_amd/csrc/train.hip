@@ -1275,13 +1275,13 @@ extern "C" int diner_field_train_ws_layout(long long P, int nv, long long* float
 
 // The layer-wise forward.  gate != null: the repeat behind the fused forward (below) -- inputs, packed weights and the flag block are in
 // place, every launch returns at once unless *gate != 0 (the fused kernels met an activation beyond the fp16 range).
+// ws / sc / w: the saved part, the work buffers and the offsets into them -- of one object's workspace, or (ABI v6, the batched step) one
+// object's view of the step's workspace (obj_view below; wpack and flags are the step's).  pack: pack the step's weights and clear the flag block
+// (the first object of a step; gate == null only).
 static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, const float* xyz, const float* viewdirs, long long P,
-                             float* out, void* workspace, void* scratch, void* stream, const int* gate) {
+                             float* out, float* ws, float* sc, const TrainWs& w, void* stream, const int* gate, bool pack = true) {
   int rc = 0;
   hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
-  const TrainWs w = train_ws(P, scene->nv);
-  float* sc = scratch_base(ws, scratch, w);
   const long long cols = P * scene->nv;
   if (!gate) {
     rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
@@ -1289,7 +1289,7 @@ static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, c
   }
   // the 512 x 512 layers: weights packed once per step (three bf16 planes in the consuming wave's order; one launch for the 13 matrices
   // in both orientations -- the backward call of the step reads the transposed ones from the workspace), products on k_lin512
-  if (use_lin512() && !gate) {
+  if (use_lin512() && !gate && pack) {
     PackMany pm;
     for (int b = 0; b < 5; ++b) { pm.W[kSlotFc0 + b] = p->fc0_w[b]; pm.W[kSlotFc1 + b] = p->fc1_w[b]; }
     for (int b = 0; b < 3; ++b) pm.W[kSlotLinZ + b] = p->lin_z_w[b];
@@ -1394,7 +1394,8 @@ extern "C" int diner_field_train_forward_s_f32(const DinerScene* scene, const Di
   DINER_CHECK_ARG(scene && xyz && viewdirs && out && workspace && P > 0, "field_train_forward: bad arguments");
   int rc = check_train_params(p, true);
   if (rc) return rc;
-  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, scratch, stream, nullptr);
+  const TrainWs w = train_ws(P, scene->nv);
+  return forward_layerwise(scene, p, xyz, viewdirs, P, out, (float*)workspace, scratch_base((float*)workspace, scratch, w), w, stream, nullptr);
 }
 extern "C" int diner_field_train_forward_f32(const DinerScene* scene, const DinerMlpParams* p, const float* xyz,
                                              const float* viewdirs, long long P, float* out, void* workspace, void* stream) {
@@ -1429,19 +1430,16 @@ __global__ void k_copy_flag(const int* __restrict__ src, int* __restrict__ dst) 
 enum { kFlagFusedOvf = 14 };
 }  // namespace
 
-extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
-                                                   const float* viewdirs, long long P, float* out, void* workspace, void* scratch,
-                                                   float* latent_proj_out, void* stream) {
-  DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && out && workspace && P > 0, "field_train_forward_fused: bad arguments");
-  int rc = check_train_params(p, true);
+int field_forward_save_supported(const DinerScene* scene, const DinerMlp* mlp);
+// one object of a step: its inputs, (first: the step's packed weights + flag block,) its projected maps, the fused kernels, the gated repeat
+static int fused_forward_core(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz, const float* viewdirs,
+                              long long P, float* out, float* ws, float* sc, const TrainWs& w, float* latent_proj_out, hipStream_t st, bool first) {
+  int rc = field_forward_save_supported(scene, mlp);      // host-known reasons to keep the layer-wise forward: before anything is enqueued
   if (rc) return rc;
-  DINER_CHECK_ARG(use_lin512() && (use_fwd_f16() || use_bwd_f16()), "field_train_forward_fused: needs the 512-layer kernels of the backward");
-  hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
-  const TrainWs w = train_ws(P, scene->nv);
+  void* stream = (void*)st;
   rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
   if (rc) return rc;
-  {   // packed weights of the backward's products + the flag block, as the layer-wise forward leaves them
+  if (first) {   // packed weights of the backward's products + the flag block, as the layer-wise forward leaves them
     PackMany pm;
     for (int b = 0; b < 5; ++b) { pm.W[kSlotFc0 + b] = p->fc0_w[b]; pm.W[kSlotFc1 + b] = p->fc1_w[b]; }
     for (int b = 0; b < 3; ++b) pm.W[kSlotLinZ + b] = p->lin_z_w[b];
@@ -1479,11 +1477,23 @@ extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, cons
   for (int b = 0; b < 5; ++b) { sv.bX[b] = reinterpret_cast<unsigned*>(ws + w.bX[b]); sv.bH[b] = reinterpret_cast<unsigned*>(ws + w.bH[b]); }
   int* ovf = nullptr;
   // hand-over + tile counters of the two kernels: the backward's dx buffer is free in the forward (8 KB per point; 2 KB + flags needed)
-  if ((rc = field_forward_save(&own, mlp, xyz, viewdirs, P, out, scratch_base(ws, scratch, w) + w.dx, sv, &ovf, st))) return rc;
+  if ((rc = field_forward_save(&own, mlp, xyz, viewdirs, P, out, sc + w.dx, sv, &ovf, st))) return rc;
   hipLaunchKernelGGL(k_copy_flag, dim3(1), dim3(1), 0, st, ovf, reinterpret_cast<int*>(ws + w.flags) + kFlagFusedOvf);
   DINER_LAUNCH_OK();
   // the exact repeat, on the device: the layer-wise forward behind the flag (its ~25 launches return at once when it stayed down)
-  return forward_layerwise(scene, p, xyz, viewdirs, P, out, workspace, scratch, stream, reinterpret_cast<const int*>(ws + w.flags) + kFlagFusedOvf);
+  return forward_layerwise(scene, p, xyz, viewdirs, P, out, ws, sc, w, stream, reinterpret_cast<const int*>(ws + w.flags) + kFlagFusedOvf);
+}
+
+extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
+                                                   const float* viewdirs, long long P, float* out, void* workspace, void* scratch,
+                                                   float* latent_proj_out, void* stream) {
+  DINER_CHECK_ARG(scene && mlp && xyz && viewdirs && out && workspace && P > 0, "field_train_forward_fused: bad arguments");
+  int rc = check_train_params(p, true);
+  if (rc) return rc;
+  DINER_CHECK_ARG(use_lin512() && (use_fwd_f16() || use_bwd_f16()), "field_train_forward_fused: needs the 512-layer kernels of the backward");
+  float* ws = (float*)workspace;
+  const TrainWs w = train_ws(P, scene->nv);
+  return fused_forward_core(scene, mlp, p, xyz, viewdirs, P, out, ws, scratch_base(ws, scratch, w), w, latent_proj_out, (hipStream_t)stream, true);
 }
 
 // 1 when the fused forward that filled `workspace` met an activation beyond the fp16 range (its saved activations are not usable), else 0;
@@ -1506,18 +1516,15 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
                                               void* stream) {
   return diner_field_train_backward_s_f32(scene, p, grads, P, d_out, workspace, nullptr, d_latent_cl, stream);
 }
-extern "C" int diner_field_train_backward_s_f32(const DinerScene* scene, const DinerMlpParams* p, const DinerMlpParams* grads, long long P,
-                                                const float* d_out, void* workspace, void* scratch, float* d_latent_cl, void* stream) {
-  DINER_CHECK_ARG(scene && d_out && workspace && P > 0, "field_train_backward: bad arguments");
-  int rc = check_train_params(p, false);
-  if (rc) return rc;
-  rc = check_train_params(grads, false);
-  if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
-  const TrainWs w = train_ws(P, scene->nv);
-  const long long cols = P * scene->nv;
-  float* sc = scratch_base(ws, scratch, w);
+// n_obj objects of P points each, object-major rows in every tensor of the workspace (w = train_ws(n_obj * P, nv): object o's rows of a
+// per-view tensor are [o cols, (o + 1) cols), of a post-mean tensor [o P, (o + 1) P)): the layer products run ONCE over all rows; per object
+// only the view-mean adjoint and the scatter of the latent gradient into that object's feature-map gradient d_latent_cl[o] (or null)
+static int backward_core(const DinerScene* const* scenes, int n_obj, const DinerMlpParams* p, const DinerMlpParams* grads, long long P_obj,
+                         const float* d_out, float* ws, float* sc, const TrainWs& w, float* const* d_latent_cl, hipStream_t st) {
+  int rc = 0;
+  const DinerScene* scene = scenes[0];
+  const long long P = P_obj * n_obj;
+  const long long cols = P * scene->nv, cols_obj = P_obj * scene->nv;
   float* dx = sc + w.dx;
   float* dH = sc + w.dH;
   // weight gradients of the 512 x 512 layers: every layer keeps its partial tiles in its own slot, one launch sums them all at the end
@@ -1536,7 +1543,7 @@ extern "C" int diner_field_train_backward_s_f32(const DinerScene* scene, const D
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   unsigned* amax = reinterpret_cast<unsigned*>(flags) + kAmax0;
   const bool z_sep = use_lin512() && lin512_ok(ws + w.lat, kLatent, sc + w.d_lat, kHidden, nullptr, nullptr);   // as the forward decided
-  const bool bwd16 = use_bwd_f16() && use_fwd_f16() && use_lin512() && use_wgrad512() && z_sep && (reinterpret_cast<size_t>(workspace) & 15) == 0;
+  const bool bwd16 = use_bwd_f16() && use_fwd_f16() && use_lin512() && use_wgrad512() && z_sep && (reinterpret_cast<size_t>(ws) & 15) == 0;
   if (bwd16) DINER_HIP_OK(hipMemsetAsync(amax, 0, 64 * sizeof(unsigned), st));
   int a_cur = 0, a_next = 1;                                  // slot of the current dx; next free slot
   BwdArith ar_store;
@@ -1579,8 +1586,9 @@ extern "C" int diner_field_train_backward_s_f32(const DinerScene* scene, const D
                                   wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job(), arith(kSlotLinZ + b, a_cur, -1)))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
       const int a_b = a_next++;
-      hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P * kHidden)), dim3(256), 0, st, dx, scene->nv, P * kHidden, dH,
-                         bwd16 ? amax + a_cur : nullptr, bwd16 ? amax + a_b : nullptr);
+      for (int o = 0; o < n_obj; ++o)
+        hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P_obj * kHidden)), dim3(256), 0, st, dx + (size_t)o * P_obj * kHidden, scene->nv, P_obj * kHidden,
+                           dH + (size_t)o * cols_obj * kHidden, bwd16 ? amax + a_cur : nullptr, bwd16 ? amax + a_b : nullptr);
       a_cur = a_b;
       float* t = dx; dx = dH; dH = t;
     }
@@ -1593,10 +1601,100 @@ extern "C" int diner_field_train_backward_s_f32(const DinerScene* scene, const D
       if (jobs.job[i].part) jobs.job[n++] = jobs.job[i];
     if ((rc = wgrad512_reduce_many(jobs, n, true, st))) return rc;
   }
-  if (d_latent_cl) {
-    DINER_HIP_OK(hipMemsetAsync(d_latent_cl, 0, (size_t)scene->nv * scene->Hf * scene->Wf * kLatent * sizeof(float), st));
-    if ((rc = scatter_latent_launch(sc + w.d_lat, (const int*)(ws + w.tap_row), ws + w.tap_w, cols, d_latent_cl, st))) return rc;
+  for (int o = 0; o < n_obj; ++o) {
+    if (!d_latent_cl || !d_latent_cl[o]) continue;
+    DINER_HIP_OK(hipMemsetAsync(d_latent_cl[o], 0, (size_t)scenes[o]->nv * scenes[o]->Hf * scenes[o]->Wf * kLatent * sizeof(float), st));
+    if ((rc = scatter_latent_launch(sc + w.d_lat + (size_t)o * cols_obj * kLatent, (const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4,
+                                    ws + w.tap_w + (size_t)o * cols_obj * 4, cols_obj, d_latent_cl[o], st))) return rc;
   }
   DINER_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int diner_field_train_backward_s_f32(const DinerScene* scene, const DinerMlpParams* p, const DinerMlpParams* grads, long long P,
+                                                const float* d_out, void* workspace, void* scratch, float* d_latent_cl, void* stream) {
+  DINER_CHECK_ARG(scene && d_out && workspace && P > 0, "field_train_backward: bad arguments");
+  int rc = check_train_params(p, false);
+  if (rc) return rc;
+  rc = check_train_params(grads, false);
+  if (rc) return rc;
+  float* ws = (float*)workspace;
+  const TrainWs w = train_ws(P, scene->nv);
+  return backward_core(&scene, 1, p, grads, P, d_out, ws, scratch_base(ws, scratch, w), w, &d_latent_cl, (hipStream_t)stream);
+}
+
+// ---- ABI v6: the SB objects of a training step as ONE call pair (VERDICT r5 #1c) ------------------------------------------------------
+// The layers are scene-independent: only the inputs / gather (forward) and the view-mean adjoint / scatter (backward) are per object.  The
+// forward runs object by object on the fused kernels (each object has its own maps) into one workspace with object-major rows; the backward's
+// 13 x (data gradient, weight gradient) products then run once over n_obj x P x nv rows: n_obj times fewer launches, one partial-tile sum,
+// the weight gradients of the step summed inside the kernels instead of by autograd.  Also re-packs the persistent handle `mlp` from `p`
+// (diner_mlp_update, training subset) -- no host synchronisation anywhere in the step.
+namespace {
+TrainWs obj_view(const TrainWs& t, long long P, int nv, int o) {
+  TrainWs v = t;
+  const size_t cols = (size_t)P * nv, oc = (size_t)o * cols, op = (size_t)o * P;
+  v.feat += oc * kDInPad;
+  v.tap_row += oc * 4;
+  v.tap_w += oc * 4;
+  v.lat += oc * kLatent;
+  for (int b = 0; b < 5; ++b) {
+    const size_t m = b < 3 ? oc : op;
+    v.X[b] += m * kHidden;
+    v.H[b] += m * kHidden;
+    v.bX[b] += m * 16;
+    v.bH[b] += m * 16;
+  }
+  v.x_last += op * kHidden;
+  v.raw += op * 4;
+  v.d_raw += op * 4;
+  v.dx += oc * kHidden;
+  v.dH += oc * kHidden;
+  v.d_lat += oc * kLatent;
+  return v;
+}
+int check_batch(const DinerScene* const* scenes, int n_obj, long long P) {
+  DINER_CHECK_ARG(scenes && n_obj > 0 && n_obj <= 64 && P > 0, "field_train_batch: bad arguments (1 <= n_obj <= 64)");
+  for (int o = 0; o < n_obj; ++o)
+    DINER_CHECK_ARG(scenes[o] && scenes[o]->nv == scenes[0]->nv, "field_train_batch: every object needs the same number of source views");
+  return 0;
+}
+}  // namespace
+
+extern "C" int diner_field_train_batch_workspace_split(long long P, int nv, int n_obj, size_t* saved_bytes, size_t* scratch_bytes) {
+  DINER_CHECK_ARG(P > 0 && nv > 0 && n_obj > 0 && saved_bytes && scratch_bytes, "field_train_batch_workspace_split: bad arguments");
+  return diner_field_train_workspace_split(P * n_obj, nv, saved_bytes, scratch_bytes);
+}
+
+extern "C" int diner_field_train_forward_batch_f32(const DinerScene* const* scenes, int n_obj, DinerMlp* mlp, const DinerMlpParams* p,
+                                                   const float* xyz, const float* viewdirs, long long P, float* out, void* saved,
+                                                   void* scratch, float* latent_proj_scratch, void* stream) {
+  int rc = check_batch(scenes, n_obj, P);
+  if (rc) return rc;
+  DINER_CHECK_ARG(mlp && xyz && viewdirs && out && saved && scratch && latent_proj_scratch, "field_train_forward_batch: null pointer argument");
+  if ((rc = check_train_params(p, true))) return rc;
+  DINER_CHECK_ARG(use_lin512() && (use_fwd_f16() || use_bwd_f16()), "field_train_forward_batch: needs the 512-layer kernels of the backward");
+  for (int o = 0; o < n_obj; ++o)
+    if ((rc = field_forward_save_supported(scenes[o], mlp))) return rc;
+  if ((rc = diner_mlp_update(mlp, p, DINER_MLP_UPDATE_TRAIN_ONLY, stream))) return rc;
+  float* ws = (float*)saved;
+  const int nv = scenes[0]->nv;
+  const TrainWs wt = train_ws(P * n_obj, nv);
+  for (int o = 0; o < n_obj; ++o) {
+    const TrainWs w = obj_view(wt, P, nv, o);
+    if ((rc = fused_forward_core(scenes[o], mlp, p, xyz + (size_t)o * P * 3, viewdirs + (size_t)o * P * 3, P, out + (size_t)o * P * 4, ws,
+                                 (float*)scratch, w, latent_proj_scratch, (hipStream_t)stream, o == 0))) return rc;
+  }
+  return 0;
+}
+
+extern "C" int diner_field_train_backward_batch_f32(const DinerScene* const* scenes, int n_obj, const DinerMlpParams* p, const DinerMlpParams* grads,
+                                                    long long P, const float* d_out, void* saved, void* scratch, float* const* d_latent_cl,
+                                                    void* stream) {
+  int rc = check_batch(scenes, n_obj, P);
+  if (rc) return rc;
+  DINER_CHECK_ARG(d_out && saved && scratch, "field_train_backward_batch: null pointer argument");
+  if ((rc = check_train_params(p, false))) return rc;
+  if ((rc = check_train_params(grads, false))) return rc;
+  const TrainWs wt = train_ws(P * n_obj, scenes[0]->nv);
+  return backward_core(scenes, n_obj, p, grads, P, d_out, (float*)saved, (float*)scratch, wt, d_latent_cl, (hipStream_t)stream);
 }

@@ -131,6 +131,14 @@ __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base, int* __res
 #ifndef DINER_L512_RING
 #define DINER_L512_RING 2
 #endif
+// -DDINER_L512_PROF (measurement build, tools/prof_l512.sh): shader clocks per wave summed over the launches since the last read --
+// [0] whole tile loop, [1] MFMA slab loops without their barriers, [2] slab barriers, [3] epilogues, [4] tiles, [5] waves, [6] prologue
+#ifdef DINER_L512_PROF
+__device__ unsigned long long g_l512_prof[8];
+#define L512_CLK() __builtin_readcyclecounter()
+#else
+#define L512_CLK() 0ull
+#endif
 #define DINER_BF16_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
 #define DINER_F16_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, A), __builtin_bit_cast(hf8, B), ACC, 0, 0, 0)
 
@@ -289,6 +297,8 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
 
   f32x16 acc[NRT][CT];
   int unit = 0;                                              // slabs processed by this workgroup so far (buffer = unit & 1)
+  [[maybe_unused]] unsigned long long pf_slab = 0, pf_bar = 0, pf_epi = 0, pf_tiles = 0;
+  [[maybe_unused]] const unsigned long long pf_t0 = L512_CLK();
   // weight ring: the first R - 1 steps; from then on every step requests the step R - 1 ahead of it (the stream repeats per tile)
   sfor<R - 1>([&](auto S) { load_w(wr[decltype(S)::value], decltype(S)::value, 0, NF); });
   for (; tile < n_tiles; tile += tile_stride) {
@@ -300,6 +310,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
         for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
 #pragma nounroll
     for (int slab = 0; slab < n_slabs; ++slab, ++unit) {
+      [[maybe_unused]] const unsigned long long pf_a = L512_CLK();
       relu_floor = (slab + 1 >= kSlabs && slab + 1 < n_slabs) ? relu_floor2 : relu_floor1;      // the slab converted during this one
       const int buf = unit & 1;
       // Staging, branch-free so that the conversion can be scheduled between the MFMAs: during this slab the NEXT slab (requested one
@@ -381,8 +392,14 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
           for (int rt = 0; rt < NRT; ++rt) asm volatile("" : "+a"(acc[rt][ct]));
         });
       });
+      [[maybe_unused]] const unsigned long long pf_b = L512_CLK();
       __syncthreads();                                       // slab buffer `buf` is free, the next one is complete
+#ifdef DINER_L512_PROF
+      pf_slab += pf_b - pf_a;
+      pf_bar += L512_CLK() - pf_b;
+#endif
     }
+    [[maybe_unused]] const unsigned long long pf_e = L512_CLK();
     // ---- epilogue: D layout of a 32 x 32 tile: lane holds row (of x) = lane & 31, features 8 (e >> 2) + 4 (lane >> 5) + (e & 3).
     // One 32-row half at a time into registers (the weight ring's are free here), then one pass per optional term -- a branch per term and
     // half, not one per term and four values (130 uniform branches per tile as first written).
@@ -453,7 +470,21 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
           for (int c = 0; c < 4; ++c) y_max = max(y_max, __float_as_uint(v[n][c]) & 0x7fffffffu);
       }
     }
+#ifdef DINER_L512_PROF
+    pf_epi += L512_CLK() - pf_e;
+    ++pf_tiles;
+#endif
   }
+#ifdef DINER_L512_PROF
+  if (lane == 0) {
+    atomicAdd(&g_l512_prof[0], L512_CLK() - pf_t0);
+    atomicAdd(&g_l512_prof[1], pf_slab);
+    atomicAdd(&g_l512_prof[2], pf_bar);
+    atomicAdd(&g_l512_prof[3], pf_epi);
+    atomicAdd(&g_l512_prof[4], pf_tiles);
+    atomicAdd(&g_l512_prof[5], 1ull);
+  }
+#endif
   if (a.amax_out) {                                          // (a NaN's pattern is the largest: it reaches the consumer, which then does not scale)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) y_max = max(y_max, (unsigned)__shfl_xor((int)y_max, o, 64));
@@ -467,6 +498,21 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   }
 }
 
+#ifdef DINER_L512_PROF
+}  // namespace train
+}  // namespace diner
+extern "C" int diner_debug_l512_prof(unsigned long long* out8, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(diner::train::g_l512_prof), 8 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[8] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(diner::train::g_l512_prof), z, sizeof(z));
+  }
+  return 0;
+}
+namespace diner {
+namespace train {
+#endif
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 int lin512_pack(const float* W, int transpose, void* dst, hipStream_t stream) {
   hipLaunchKernelGGL(k_pack_w512, dim3(128), dim3(256), 0, stream, W, transpose, (__bf16*)dst);

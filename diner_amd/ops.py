@@ -165,6 +165,19 @@ class HipMlp:
     reference key names (resnetfc.py:72-127); tensors must be on the HIP device."""
 
     def __init__(self, sd, prefix="", combine_layer=3, d_latent=512, num_freqs=6, freq_factor=6.28, include_input=True):
+        self._conf = dict(prefix=prefix, combine_layer=combine_layer, num_freqs=num_freqs, include_input=include_input)
+        p = self._params(sd, freq_factor)
+        self.device = self._keep["lin_in_w"].device
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            # returns once the packing has completed on the stream (the sources may then be freed or updated in place)
+            _lib.check(lib.diner_mlp_create(C.byref(p), _stream(), C.byref(h)))
+        self.handle = h
+        self._range = None
+
+    def _params(self, sd, freq_factor):
+        """DinerMlpParams over the tensors of a state_dict-like mapping (kept alive on self until the next call)."""
+        prefix, combine_layer = self._conf["prefix"], self._conf["combine_layer"]
         g = lambda k: _f32c(sd[prefix + k])
         n_blocks = len([k for k in sd if k.startswith(prefix + "blocks.") and k.endswith("fc_0.weight")])
         n_z = len([k for k in sd if k.startswith(prefix + "lin_z.") and k.endswith(".weight")])
@@ -185,7 +198,7 @@ class HipMlp:
         p.d_latent = lists["lin_z_w"][0].shape[1] if n_z else 0
         p.n_blocks, p.combine_layer = n_blocks, combine_layer
         # the positional encoding that produces the 55 inputs is evaluated inside the field kernels (pixelnerf.py:15-18)
-        p.num_freqs, p.include_input, p.freq_factor = int(num_freqs), int(bool(include_input)), float(freq_factor)
+        p.num_freqs, p.include_input, p.freq_factor = int(self._conf["num_freqs"]), int(bool(self._conf["include_input"])), float(freq_factor)
         p.lin_in_w, p.lin_in_b = keep["lin_in_w"].data_ptr(), keep["lin_in_b"].data_ptr()
         p.lin_out_w, p.lin_out_b = keep["lin_out_w"].data_ptr(), keep["lin_out_b"].data_ptr()
         self._arrays = {}
@@ -193,17 +206,36 @@ class HipMlp:
             arr = (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
             self._arrays[name] = arr
             setattr(p, name, C.cast(arr, C.POINTER(C.c_void_p)))
-        self.device = keep["lin_in_w"].device
-        h = C.c_void_p()
+        self._keep, self._lists = keep, lists
+        return p
+
+    def update(self, sd, freq_factor=6.28, train_only=False):
+        """New parameter values into this handle (diner_mlp_update, ABI v6): packed on the current stream, no allocation, no host
+        synchronisation.  train_only: only what the fused training forward reads -- the handle then serves diner_amd.train alone."""
+        p = self._params(sd, freq_factor)
         with torch.cuda.device(self.device):
-            # returns once the packing has completed on the stream (the sources may then be freed or updated in place)
-            _lib.check(lib.diner_mlp_create(C.byref(p), _stream(), C.byref(h)))
-        self.handle = h
-        # the fp16-operand modes carry the weights x16 as fp16 hi/lo parts: |w| must stay below 1024.  The range was
-        # reduced on the device while packing; the library itself falls back to the exact kernels when it does not fit.
-        wmax = C.c_float()
-        self.h3_ok = lib.diner_mlp_weights_fit_f16x3(h, C.byref(wmax)) == 1
-        self.wmax = float(wmax.value)
+            _lib.check(lib.diner_mlp_update(self.handle, C.byref(p), _lib.MLP_UPDATE_TRAIN_ONLY if train_only else 0, _stream()))
+        self._range = None
+
+    def _weight_range(self):
+        # the fp16-operand modes carry the weights x16 as fp16 hi/lo parts: |w| must stay below 1024.  The range was reduced on the
+        # device while packing (read back by diner_mlp_create; after update(): here, one stream wait); the library itself falls back
+        # to the exact kernels when it does not fit.
+        if self._range is None:
+            wmax = C.c_float()
+            ok = lib.diner_mlp_weights_fit_f16x3(self.handle, C.byref(wmax))
+            if ok < 0:
+                _lib.check(ok)
+            self._range = (ok == 1, float(wmax.value))
+        return self._range
+
+    @property
+    def h3_ok(self):
+        return self._weight_range()[0]
+
+    @property
+    def wmax(self):
+        return self._weight_range()[1]
 
     def fallback_launches(self, reset=False):
         """Field launches with this handle that the fp16-operand kernels could not finish (an activation left the fp16 range or an

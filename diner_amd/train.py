@@ -166,16 +166,39 @@ def workspace_split(P, nv):
     return int(a.value), int(b.value)
 
 
-_STEP_MLP = [None, None]
+_STEP_MLP = {}
+
+
+def _step_handle(params, freq_factor):
+    """The persistent packed-weights handle of the training path: ONE per device and stream, created at the first step (diner_mlp_create: a
+    dozen hipMallocs and one stream wait, once) and from then on re-packed in place ON THE STREAM with the parameter values of every call
+    (diner_mlp_update: no allocation, no host synchronisation; round 5 re-created a handle per parameter version -- hipMalloc / hipFree and a
+    stream wait per optimiser step: 103 of 136 ms of host time).  Nothing is cached per parameter address or version (`_version`
+    misses writes through `p.data`, a freed model's addresses can be recycled): the values are packed again for every call, ~40 small
+    launches = 0.2 ms.  `release_buffers()` drops the handles."""
+    from .ops import HipMlp
+    dev = params[0].device
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    h = _STEP_MLP.get(key)
+    if h is None:
+        _STEP_MLP[key] = h = HipMlp(dict(zip(PARAM_ORDER, params)), freq_factor=float(freq_factor))
+    return h
 
 
 def _step_mlp(params, freq_factor):
-    """Packed-weights handle of THIS step's parameters (shared by the SB objects of a step: rebuilt when a parameter was written)."""
-    from .ops import HipMlp
-    key = tuple((p.data_ptr(), p._version) for p in params) + (float(freq_factor),)
-    if _STEP_MLP[0] != key:
-        _STEP_MLP[0], _STEP_MLP[1] = key, HipMlp(dict(zip(PARAM_ORDER, params)), freq_factor=float(freq_factor))
-    return _STEP_MLP[1]
+    """... re-packed (training subset) with this call's parameter values: what the per-object fused forward takes."""
+    h = _step_handle(params, freq_factor)
+    h.update(dict(zip(PARAM_ORDER, params)), freq_factor=float(freq_factor), train_only=True)
+    return h
+
+
+def release_buffers():
+    """Frees what the training path keeps between steps: the shared work buffers (`_SCRATCH`: 4.6 GiB per stream at one object of 4096 rays
+    x 40 samples, 17 GiB for the batched step of four), the projected-map buffers (`_PROJ`) and the persistent packed-weights handles.  Call it
+    when leaving training for, e.g., a validation render in the same process; the next step allocates them again."""
+    _SCRATCH.clear()
+    _PROJ.clear()
+    _STEP_MLP.clear()
 
 
 class FieldFunction(torch.autograd.Function):
@@ -249,6 +272,101 @@ class FieldFunction(torch.autograd.Function):
                 d_lat = torch.empty(nv, Cc, Hf, Wf, device=d_out.device)
                 _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), nv, Hf * Wf, Cc, _ptr(d_lat), _stream()))
         return (None, None, None, d_lat, None) + tuple(grads)
+
+
+class FieldBatchFunction(torch.autograd.Function):
+    """PixelNeRF.forward for the SB objects of a training step in ONE library call pair (ABI v6, diner_field_train_forward_batch_f32 /
+    _backward_batch_f32): xyz, viewdirs (SB, P, 3) -> (SB, P, 4).  The forward runs the fused storing kernels object by object into one
+    workspace with object-major rows; the backward's layer products run once over SB x P x NV rows (the weight gradients of the step are
+    summed inside the kernels, the latent gradients scattered per object).  No host synchronisation: the persistent packed-weights handle is
+    re-packed on the stream inside the forward call."""
+
+    @staticmethod
+    def forward(ctx, scenes, xyz, viewdirs, latent, freq_factor, *params):
+        import ctypes as C
+        _require_hip(xyz, viewdirs, latent)
+        xyz, viewdirs = _f32c(xyz.detach()), _f32c(viewdirs.detach())
+        params = [_f32c(p.detach()) for p in params]
+        SB, P, NV = xyz.shape[0], xyz.shape[1], scenes[0].nv
+        dev = xyz.device
+        with torch.cuda.device(dev):
+            a, b = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(lib.diner_field_train_batch_workspace_split(P, NV, SB, C.byref(a), C.byref(b)))
+            ws = torch.empty(int(a.value), dtype=torch.uint8, device=dev)
+            scratch = _shared(_SCRATCH, dev, int(b.value))
+            proj = _shared(_PROJ, dev, max(int(lib.diner_scene_proj_bytes(sc.ref)) for sc in scenes))
+            out = torch.empty(SB, P, 4, device=dev)
+            ps, keep = _param_struct(params, freq_factor)
+            mlp = _step_handle(params, freq_factor)
+            arr = (C.POINTER(_lib.DinerScene) * SB)(*[C.pointer(sc.struct) for sc in scenes])
+            rc = lib.diner_field_train_forward_batch_f32(arr, SB, mlp.handle, C.byref(ps), _ptr(xyz), _ptr(viewdirs), P, _ptr(out), _ptr(ws),
+                                                         _ptr(scratch), _ptr(proj), _stream())
+            if rc == _lib.E_UNSUPPORTED:
+                raise _BatchUnsupported()
+            _lib.check(rc)
+            mlp._range = None
+            ctx.ps = (ps, keep)
+            ctx.latent_shape = tuple(latent.shape)
+            ctx.prealloc = FieldBatchFunction._alloc_outputs(params, ctx.latent_shape, dev) if any(ctx.needs_input_grad) else None
+        ctx.scenes, ctx.P, ctx.arr = list(scenes), P, arr
+        ctx.save_for_backward(ws, *params)
+        return out
+
+    @staticmethod
+    def _alloc_outputs(params, latent_shape, dev):
+        grads = [torch.empty_like(p) for p in params]
+        sb, nv, Cc, Hf, Wf = latent_shape
+        return grads, _param_struct(grads), torch.empty(sb, nv, Hf, Wf, Cc, device=dev)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        import ctypes as C
+        ws, params = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
+        dev = d_out.device
+        SB = len(ctx.scenes)
+        with torch.cuda.device(dev):
+            pre, ctx.prealloc = ctx.prealloc, None
+            grads, (gs, keep_g), d_cl = pre if pre is not None else FieldBatchFunction._alloc_outputs(params, ctx.latent_shape, dev)
+            want_lat = ctx.needs_input_grad[3]
+            ps, keep = ctx.ps
+            d_out = _f32c(d_out)
+            a, b = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(lib.diner_field_train_batch_workspace_split(ctx.P, ctx.scenes[0].nv, SB, C.byref(a), C.byref(b)))
+            scratch = _shared(_SCRATCH, dev, int(b.value))
+            dl = (C.c_void_p * SB)(*[d_cl[o].data_ptr() if want_lat else None for o in range(SB)])
+            _lib.check(lib.diner_field_train_backward_batch_f32(ctx.arr, SB, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out), _ptr(ws), _ptr(scratch),
+                                                                dl, _stream()))
+            d_lat = None
+            if want_lat:                     # channels-last -> the encoder's (SB, nv, C, Hf, Wf), contiguous: autograd takes it as it is
+                sb, nv, Cc, Hf, Wf = ctx.latent_shape
+                d_lat = torch.empty(sb, nv, Cc, Hf, Wf, device=dev)
+                _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), sb * nv, Hf * Wf, Cc, _ptr(d_lat), _stream()))
+        return (None, None, None, d_lat, None) + tuple(grads)
+
+
+class _BatchUnsupported(Exception):
+    pass
+
+
+def batch_enabled(P, scenes):
+    """The batched step (one call pair for the SB objects) runs on the fused forward: same conditions as fused_forward_enabled for every
+    object, same number of views and map sizes (the latent is one stacked tensor).  DINER_TRAIN_BATCH=0: one call pair per object (round 5)."""
+    if os.environ.get("DINER_TRAIN_BATCH", "") == "0":
+        return False
+    s0 = scenes[0]
+    return all(fused_forward_enabled(P, sc) and (sc.nv, sc.Hf, sc.Wf) == (s0.nv, s0.Hf, s0.Wf) for sc in scenes)
+
+
+def field_train_batch(scenes, xyz, viewdirs, latent, params, freq_factor=6.28):
+    """(SB, P, 3) x 2 -> (SB, P, 4), differentiable with respect to latent (SB, NV, C, Hf, Wf) and the MLP parameters; falls back to one
+    call pair per object when the library declines the fused forward (weights outside the fp16 split, maps of 4 GiB or more)."""
+    if batch_enabled(xyz.shape[1], scenes):
+        try:
+            return FieldBatchFunction.apply(list(scenes), xyz, viewdirs, latent, float(freq_factor), *params)
+        except _BatchUnsupported:
+            pass
+    slabs = object_slabs(latent)
+    return torch.stack([field_train(scenes[sb], xyz[sb], viewdirs[sb], slabs[sb], params, freq_factor) for sb in range(len(scenes))])
 
 
 class CompositeFunction(torch.autograd.Function):

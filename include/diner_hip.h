@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DINER_ABI_VERSION 5
+#define DINER_ABI_VERSION 6
 
 #define DINER_E_INVALID     (-1)  /* bad argument (null pointer, size, unsupported configuration) */
 #define DINER_E_UNSUPPORTED (-2)  /* configuration outside what the kernels are built for        */
@@ -97,6 +97,17 @@ const char* diner_last_error(void);
  * DINER_E_UNSUPPORTED before any device work.  A failed call leaves no allocation behind. */
 int diner_mlp_create(const DinerMlpParams* p, void* stream, DinerMlp** out);
 int diner_mlp_destroy(DinerMlp* mlp);
+/* ABI v6: new parameter values into an EXISTING handle, packed on `stream` -- no allocation and no synchronisation (diner_mlp_create
+ * hipMallocs ~12 buffers, waits for the stream once, and diner_mlp_destroy hipFrees them: three device-wide synchronisations per optimiser
+ * step when a training loop re-creates its handle; resnetfc.py:72-127 under the optimiser's in-place updates, diner.py:217-290).  The
+ * parameter tensors must stay valid until the packing has run on `stream`.  The handle gets a new diner_mlp_stamp(): maps projected with
+ * the old values are refused.  The weight range is not read back: diner_mlp_weights_fit_f16x3 and the inference entry points read it
+ * (one stream wait) the first time they need it after an update; the fused training forward never does -- it tests the range on the device.
+ * flags: DINER_MLP_UPDATE_TRAIN_ONLY packs only what diner_field_train_forward_fused_f32 / _batch_f32 read (the four-wave f16x3 layouts,
+ * biases, the constants of the projected maps): the inference entry points then return DINER_E_INVALID for this handle until an update
+ * without the flag. */
+#define DINER_MLP_UPDATE_TRAIN_ONLY 1
+int diner_mlp_update(DinerMlp* mlp, const DinerMlpParams* p, int flags, void* stream);
 /* Largest |weight| over all weight matrices (biases stay fp32 in every mode), reduced on the device at pack time (one 4-byte read back, after a
  * stream synchronise): DINER_PRECISION_F16X3 / _F16 carry the weights x16 as fp16 and need it below 1024.
  * Returns 1 when the f16 modes may be used with this handle, 0 when not, <0 on error; *max_abs (optional) receives the value. */
@@ -321,6 +332,24 @@ int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp*
                                         const float* viewdirs, long long P, float* out, void* workspace, void* scratch,
                                         float* latent_proj_out, void* stream);
 int diner_field_train_fused_overflowed(const void* workspace, long long P, int nv, int* overflowed, void* stream);
+/* ABI v6: the SB objects of a training step in ONE call pair (DINER.calc_losses renders SB = 4 objects x 4096 rays per step,
+ * diner.py:217-290, configs/train_dtu.yaml:16,52-63; the reference's batched tensors (SB, B, ...) of pixelnerf.py:55-145 amount to this).
+ * The ResnetFC layers are scene-independent: only the inputs / gather (forward) and the view-mean adjoint / latent-gradient scatter
+ * (backward) are per object.  scenes: HOST array of n_obj scene pointers (same nv; same map sizes not required); xyz / viewdirs
+ * (n_obj, P, 3), out / d_out (n_obj, P, 4), object-major.  `saved` / `scratch`: diner_field_train_batch_workspace_split bytes (the layout
+ * of diner_field_train_workspace_split for n_obj * P points, rows object-major: diner_field_train_ws_layout(n_obj * P, nv) locates the saved
+ * pre-activations).  forward: re-packs the PERSISTENT handle `mlp` from `p` (diner_mlp_update, training subset; no host synchronisation),
+ * packs the step's 13 matrices once, then per object projects its latent map into latent_proj_scratch (the largest object's
+ * diner_scene_proj_bytes; reused object after object) and runs the fused storing kernels with the gated layer-wise repeat behind them.
+ * backward: the 13 x (data gradient, weight gradient) products ONCE over n_obj x P x nv rows -- n_obj times fewer launches, one partial-tile
+ * sum, weight gradients of the step summed in-kernel -- then per object the scatter into d_latent_cl[o] (HOST array of n_obj device
+ * pointers, entries or the array may be NULL).  DINER_E_UNSUPPORTED as diner_field_train_forward_fused_f32 (before anything is enqueued). */
+int diner_field_train_batch_workspace_split(long long P, int nv, int n_obj, size_t* saved_bytes, size_t* scratch_bytes);
+int diner_field_train_forward_batch_f32(const DinerScene* const* scenes, int n_obj, DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
+                                        const float* viewdirs, long long P, float* out, void* saved, void* scratch,
+                                        float* latent_proj_scratch, void* stream);
+int diner_field_train_backward_batch_f32(const DinerScene* const* scenes, int n_obj, const DinerMlpParams* p, const DinerMlpParams* grads,
+                                         long long P, const float* d_out, void* saved, void* scratch, float* const* d_latent_cl, void* stream);
 /* Test aid: float offsets into the training workspace of the pre-activations the forward saved -- [0..4] X_b, the residual stream
  * entering block b (P*nv rows of 512 for b < 3, P rows behind the view mean), [5..9] H_b, the fc_0 outputs of block b, [10] the
  * stream entering lin_out (P x 512), [11] lin_out's raw outputs (P x 4).  The signs of these values are the relu decisions of the

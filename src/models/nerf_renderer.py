@@ -43,20 +43,23 @@ class NeRFRendererDGS(torch.nn.Module):
         if not (hasattr(model, "hip_scene") and hasattr(model, "hip_mlp")):
             raise TypeError("diner_amd: `model` must be src.models.pixelnerf.PixelNeRF of this package")
 
-    def _render_train(self, model, sb, rays, z, want_weights, latent_sb=None):
-        """Differentiable composite for one object (training): sample points as in
-        nerf_renderer.py:304, the radiance field and the compositor through diner_amd/train.py (HIP forward + backward).
-        Gradients reach the MLP parameters and encoder.latent; z and rays carry none (the sampler is @no_grad)."""
+    def _render_train_batch(self, model, rays, z, want_weights):
+        """The SB objects of a training step at once (ABI v6): rays (SB,NR,8), z (SB,NR,K) -> weights | None, rgb (SB,NR,3), depth (SB,NR).
+        One field node for all objects (diner_amd.train.field_train_batch: the layer products of the backward run once over SB x NR x K x NV
+        rows), one compositor node over the SB x NR rays."""
         from diner_amd import train
-        NR, K = z.shape
+        SB, NR, K = z.shape
         r = rays.detach()
-        xyz = (r[:, None, :3] + z[..., None] * r[:, None, 3:6]).reshape(-1, 3)
-        dirs = r[:, None, 3:6].expand(-1, K, -1).reshape(-1, 3)
-        field = train.field_train(model.hip_scene(sb), xyz, dirs, model.encoder.latent[sb] if latent_sb is None else latent_sb,
-                                  train.mlp_params(model.mlp_fine), model.poscode.freq_factor).view(NR, K, 4)
-        rgb, depth = train.composite_train(field, z, r, self.white_bkgd)
-        w = ops.composite(field.detach(), z, r, self.white_bkgd, want_weights=True)[0] if want_weights else None
-        return w, rgb, depth
+        z = z.detach()
+        xyz = (r[:, :, None, :3] + z[..., None] * r[:, :, None, 3:6]).reshape(SB, NR * K, 3)
+        dirs = r[:, :, None, 3:6].expand(-1, -1, K, -1).reshape(SB, NR * K, 3)
+        scenes = [model.hip_scene(sb) for sb in range(SB)]
+        field = train.field_train_batch(scenes, xyz, dirs, model.encoder.latent, train.mlp_params(model.mlp_fine),
+                                        model.poscode.freq_factor).view(SB * NR, K, 4)
+        zf, rf = z.reshape(SB * NR, K), r.reshape(SB * NR, 8)
+        rgb, depth = train.composite_train(field, zf, rf, self.white_bkgd)
+        w = ops.composite(field.detach(), zf, rf, self.white_bkgd, want_weights=True)[0].view(SB, NR, K) if want_weights else None
+        return w, rgb.view(SB, NR, 3), depth.view(SB, NR)
 
     def sample_coarse(self, rays, n_coarse=None):
         """Stratified candidates (:39-63) as a stand-alone helper (torch ops on the rays' device).  The depth-guided
@@ -106,9 +109,7 @@ class NeRFRendererDGS(torch.nn.Module):
         model._check_poscode()
         SB = rays.shape[0]
         if model.needs_grad():
-            from diner_amd import train
-            slabs = train.object_slabs(model.encoder.latent)      # one autograd node for the SB objects' latent gradients
-            res = [self._render_train(model, sb, rays[sb], z_samp[sb].detach(), True, slabs[sb]) for sb in range(SB)]
+            return self._render_train_batch(model, rays, z_samp, True)
         else:
             mlp = model.hip_mlp()
             res = [ops.render(model.hip_scene(sb), mlp, rays[sb], z_samp[sb], self.white_bkgd, want_weights=True)
@@ -124,21 +125,25 @@ class NeRFRendererDGS(torch.nn.Module):
         SB = rays.shape[0]
         training = model.needs_grad()
         mlp = None if training else model.hip_mlp()
-        if training:
-            from diner_amd import train
-            slabs = train.object_slabs(model.encoder.latent)      # one autograd node for the SB objects' latent gradients
         inj = _noise.current()
         rgbs, depths, wts = [], [], []
+        if training:
+            # the sampler per object (each has its own maps), then field + compositor for the SB objects as ONE autograd node each
+            zs = []
+            for sb in range(SB):
+                nz = None if inj is None else tuple(None if t is None else t[sb] for t in inj)
+                seed, r0 = _key(sb)
+                zs.append(ops.sample_depthguided(model.hip_scene(sb), rays[sb], self.n_samples, self.n_depth_candidates, self.n_gaussian,
+                                                 0.05, noise=nz, seed=seed, ray_index0=r0))
+            w, rgb, depth = self._render_train_batch(model, rays, torch.stack(zs), want_weights)
+            return DotMap(fine=self._format_outputs(w, rgb, depth, want_weights=want_weights))
         for sb in range(SB):
             scene = model.hip_scene(sb)
             nz = None if inj is None else tuple(None if t is None else t[sb] for t in inj)
             seed, r0 = _key(sb)
             z = ops.sample_depthguided(scene, rays[sb], self.n_samples, self.n_depth_candidates, self.n_gaussian,
                                        0.05, noise=nz, seed=seed, ray_index0=r0)
-            if training:
-                w, rgb, depth = self._render_train(model, sb, rays[sb], z, want_weights, slabs[sb])
-            else:
-                w, rgb, depth = ops.render(scene, mlp, rays[sb], z, self.white_bkgd, want_weights=want_weights)
+            w, rgb, depth = ops.render(scene, mlp, rays[sb], z, self.white_bkgd, want_weights=want_weights)
             rgbs.append(rgb)
             depths.append(depth)
             wts.append(w)

@@ -113,10 +113,8 @@ class PixelNeRF(torch.nn.Module):
             # training: un-fused HIP forward that keeps the activations + HIP backward
             # (diner_amd/train.py); gradients reach the MLP parameters and, through encoder.latent, the image encoder
             from diner_amd import train
-            params = train.mlp_params(self.mlp_fine)
-            slabs = train.object_slabs(self.encoder.latent)
-            return torch.stack([train.field_train(self.hip_scene(sb), xyz[sb], viewdirs[sb], slabs[sb], params,
-                                                  self.poscode.freq_factor) for sb in range(SB)])
+            return train.field_train_batch([self.hip_scene(sb) for sb in range(SB)], xyz, viewdirs, self.encoder.latent,
+                                           train.mlp_params(self.mlp_fine), self.poscode.freq_factor)
         mlp = self.hip_mlp()
         if isinstance(mlp, ops.GenericMlp):
             return torch.stack([ops.field_generic(self.hip_scene(sb), mlp, xyz=xyz[sb], viewdirs=viewdirs[sb]) for sb in range(SB)])

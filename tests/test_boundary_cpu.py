@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libdiner_hip.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with include/diner_hip.h"
-    assert lib.diner_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.diner_abi_version() == _lib.ABI_VERSION == 6
     assert isinstance(lib.diner_last_error(), bytes)
 
 

@@ -515,15 +515,19 @@ def _field_nodes(t):
         if n is None or n in seen:
             continue
         seen.add(n)
-        if "FieldFunction" in type(n).__name__:
+        if "FieldFunction" in type(n).__name__ or "FieldBatchFunction" in type(n).__name__:
             out.append(n)
             continue
         stack.extend(f for f, _ in n.next_functions)
     return out
 
 
-def test_training_step_two_objects_patch_of_rays(ops):
-    """The step the shipped configs run, in small (DINER.calc_losses, diner.py:217-290 with configs/train_dtu.yaml:16,63: SB objects, a square
+@pytest.mark.parametrize("batched", [True, False], ids=["one_call_pair_for_the_objects", "one_call_pair_per_object"])
+def test_training_step_two_objects_patch_of_rays(ops, monkeypatch, batched):
+    """(round 6) batched: the SB objects as ONE field node (ABI v6, diner_field_train_forward_batch_f32 / _backward_batch_f32: the layer
+    products of the backward run once over all objects' rows, weight gradients summed in-kernel); else DINER_TRAIN_BATCH=0, round 5's one
+    call pair per object with autograd summing the gradient sets.
+    The step the shipped configs run, in small (DINER.calc_losses, diner.py:217-290 with configs/train_dtu.yaml:16,63: SB objects, a square
     patch of rays per object, ONE renderer.forward on (SB, B, 8) rays in grad mode): SB = 2 objects with their own source views and
     feature maps, a 32 x 32 patch each (the shipped patch is 64 x 64 = 4096 rays; the CPU oracle's saved activations are 10 GB per object at
     32 x 32 already), loss on fine.rgb.  Statements: per-object rgb as the inference path; gradients of every MLP parameter -- SUMMED over the
@@ -533,6 +537,7 @@ def test_training_step_two_objects_patch_of_rays(ops):
     from diner_amd.synthetic import make_scene, make_mlp_state_dict, build_modules
     from tests.tests_train_util import oracle_key, saved_relu_masks
     from src.util.depth2normal import depth2normal
+    monkeypatch.setenv("DINER_TRAIN_BATCH", "1" if batched else "0")
     W = H = 64
     SB, side, K, G, n_cand = 2, 32, 40, 15, 1000
     NR = side * side
@@ -559,8 +564,12 @@ def test_training_step_two_objects_patch_of_rays(ops):
     assert out.fine.rgb.shape == (SB, NR, 3) and out.fine.rgb.requires_grad
     assert max_norm_rel(out.fine.rgb.detach().cpu(), ref_out.cpu()) < 2e-5
     nodes = _field_nodes(out.fine.rgb)
-    assert len(nodes) == SB
-    masks = [saved_relu_masks(type("o", (), {"grad_fn": n})(), NR * K) for n in nodes]
+    assert len(nodes) == (1 if batched else SB)
+    if len(nodes) == 1 and "Batch" in type(nodes[0]).__name__:      # ABI v6: ONE node for the SB objects, rows object-major in one workspace
+        masks = [saved_relu_masks(type("o", (), {"grad_fn": nodes[0]})(), NR * K, obj=sb, n_obj=SB) for sb in range(SB)]
+    else:                                                           # DINER_TRAIN_BATCH=0: one node per object
+        assert len(nodes) == SB
+        masks = [saved_relu_masks(type("o", (), {"grad_fn": n})(), NR * K) for n in nodes]
     Gm = torch.randn(SB, NR, 3, generator=gen)
     (out.fine.rgb * Gm.cuda()).sum().backward()
     assert nerf.encoder.latent.grad.shape == nerf.encoder.latent.shape

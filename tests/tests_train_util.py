@@ -33,18 +33,21 @@ def module_param_list(msd):
     return params, names
 
 
-def saved_relu_masks(out, P, nv=4):
-    """The relu decisions of the HIP training forward that produced `out` (diner_amd.train.field_train): signs of the pre-activations it
-    saved in its workspace (diner_field_train_ws_layout) -> the relu_masks dict of oracle.diner_oracle.mlp_forward (CPU bool tensors)."""
+def saved_relu_masks(out, P, nv=4, obj=0, n_obj=1):
+    """The relu decisions of the HIP training forward that produced `out` (diner_amd.train.field_train / field_train_batch): signs of the
+    pre-activations it saved in its workspace (diner_field_train_ws_layout) -> the relu_masks dict of oracle.diner_oracle.mlp_forward (CPU
+    bool tensors).  A batched node (ABI v6) keeps the n_obj objects' rows object-major in one workspace laid out for n_obj * P points:
+    `obj` selects the object."""
     import ctypes as C
     from diner_amd import _lib
     lib = _lib.load()
     ws = out.grad_fn.saved_tensors[0]
     off = (C.c_longlong * 12)()
-    _lib.check(lib.diner_field_train_ws_layout(P, nv, off, 12))
+    _lib.check(lib.diner_field_train_ws_layout(P * n_obj, nv, off, 12))
     wf = ws.view(torch.float32)
 
     def grab(o, rows, cols=512):
+        o = o + obj * rows * cols
         return (wf[o:o + rows * cols].view(rows, cols) > 0).cpu()
     X = [grab(off[b], P * nv).view(nv, P, 512) if b < 3 else grab(off[b], P) for b in range(5)]
     H = [grab(off[5 + b], P * nv).view(nv, P, 512) if b < 3 else grab(off[5 + b], P) for b in range(5)]

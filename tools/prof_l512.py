@@ -1,0 +1,61 @@
+"""Phase timer of lin512_body (the 512 x 512 layer products of the training path, csrc/train_lin512.hip):
+
+    python -c "from diner_amd.build import build_variant; build_variant('l512prof', ['DINER_L512_PROF'])"
+    DINER_AMD_LIB=diner_amd/libdiner_hip_l512prof.so python tools/prof_l512.py [rows]
+
+Shader clocks per wave, summed by the kernel: the MFMA slab loops, the slab barriers, the epilogues.  (1) the forward product in f16x3 at
+`rows` rows (128-row tiles), plain / with a residual / accumulating; (2) one object-step of the training path (every lin512 launch of it)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from diner_amd import _lib, train                                      # noqa: E402
+
+lib = _lib.load()
+raw = C.CDLL(_lib.LIB_PATH)
+raw.diner_debug_l512_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+
+
+def read(tag, ms=None):
+    a = (C.c_ulonglong * 8)()
+    raw.diner_debug_l512_prof(a, 1)
+    tot, slab, bar, epi, tiles, waves = (float(a[i]) for i in range(6))
+    if not waves:
+        print(tag, "no lin512 launches")
+        return
+    mf = 49152.0 * tiles / 1.0      # MFMA clocks of a 128-row f16x3 tile per wave: 4 slabs x 8 steps x 12 groups x 4 MFMAs x 32 clocks
+    print(f"{tag}: waves {waves:.0f} tiles/wave {tiles / waves:.1f}  clocks/tile {tot / tiles:.0f} = slabs {slab / tiles:.0f} + barriers {bar / tiles:.0f} + "
+          f"epilogue {epi / tiles:.0f} + rest {(tot - slab - bar - epi) / tiles:.0f}   (MFMA issue alone 49152 at 128-row tiles: {mf / tot:.3f} of the clocks)"
+          + (f"  {ms:.3f} ms" if ms else ""), flush=True)
+
+
+dev = torch.device("cuda", 0)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 655360
+x = torch.randn(M, 512, device=dev)
+W = torch.randn(512, 512, device=dev) * 0.04
+y = torch.empty(M, 512, device=dev)
+res = torch.randn(M, 512, device=dev)
+b = torch.randn(512, device=dev)
+
+
+def run(tag, **kw):
+    train.linear512(x, W, y, f16x3=True, bias=b, **kw)
+    torch.cuda.synchronize()
+    read("warm-up " + tag)
+    t = time.perf_counter()
+    for _ in range(5):
+        train.linear512(x, W, y, f16x3=True, bias=b, **kw)
+    torch.cuda.synchronize()
+    read(tag, (time.perf_counter() - t) / 5 * 1e3)
+
+
+run("forward f16x3 plain")
+run("forward f16x3 + residual", resid=res)
+run("forward f16x3 relu_in", relu_in=True)
+for Msmall in (163840, 20480):
+    x, y, res = x[:Msmall], y[:Msmall], res[:Msmall]
+    run(f"forward f16x3 plain, {Msmall} rows")
