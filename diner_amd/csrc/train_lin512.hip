@@ -165,6 +165,11 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   // fragment are 512 bytes apart by the MFMA layout); the fragment reads stay 1 KB contiguous per instruction.
   constexpr int kStepBytes = CT * NP * 1024 + kStepPad, kSlabBytes = kStepsPerSlab * kStepBytes;
   constexpr int NRT = 16 / (FH * NW), NF = NP * NRT;         // MFMA row (= feature) tiles per wave, weight fragments per k16 step
+#ifdef DINER_L512_OLD_EPI      // A/B build: the direct epilogue for every shape
+  constexpr bool kLdsEpi = false;
+#else
+  constexpr bool kLdsEpi = CT == 4 && NW == 4 && FH == 1 && AR == 1;      // the epilogue leaves through LDS (below)
+#endif
   if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
   if (a.gate2 && *a.gate2 == 0) return;
   if (a.skip && *a.skip != 0) {                              // f16x3 launch of a step whose weights do not fit: the bf16x6 twin works
@@ -400,74 +405,219 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
 #endif
     }
     [[maybe_unused]] const unsigned long long pf_e = L512_CLK();
+    if constexpr (kLdsEpi) {
+      // ---- epilogue through LDS (round 6; the 128-row f16x3 shape).  In the D layout a lane holds ONE row and 4 consecutive features per
+      // register quad: a 16-byte store instruction touches 32 rows x 32 bytes -- 32 cache lines for 1 KB -- and the phase timer
+      // (tools/prof_l512.py, profiles/r06_l512_phase_timer.txt) booked 31 k of a 91 k-clock tile on the epilogue (69 k of 129 k with one
+      // tensor term read the same way).  Here every 32-row part goes through the wave's share of the slab buffer that has just been
+      // consumed and comes back ROW-CONTIGUOUS: lanes 0..31 hold the 512 bytes of the wave's feature slice of one row, lanes 32..63 the
+      // next row's -- every store / residual / accumulate access is 2 x 512 contiguous bytes.  The region is exactly the bytes THIS wave
+      // writes when it stages (row part `wave` of each of the 8 steps: NP KB per step), nobody reads them before the next slab barrier:
+      // no barrier around the epilogue.  16-byte slot s of row r sits at slot s ^ (r & 15): conflict-free writes (16 rows per pass) and reads.
+      // Buffer descriptors over the tile's valid rows: rows past M read as zeros and their stores are dropped.
+      typedef __attribute__((address_space(3))) f32x4* lds_f4;
+      const int fb = (unit - 1) & 1;
+      lds_ptr eb = (lds_ptr)smem + fb * kSlabBytes + wave * (NP * 1024);
+      // every per-lane value of the epilogue is derived HERE from an opaque copy of the lane id: derived from `lane` itself they are
+      // loop-invariant, the compiler hoists ~40 of them (16 read and 16 write addresses among them) out of the tile loop, keeps them across
+      // the slab loop and spills -- and a spill reload between the epilogue's stores is a load that waits for those stores' acknowledgement
+      int el = lane;
+      asm volatile("" : "+v"(el));
+      const int er = el & 31, eh = el >> 5;
+      const long long row0 = tile * kRows;
+      const long long left_ll = a.M - row0;
+      const int left = left_ll > kRows ? kRows : (int)left_ll;
+      const int left_lane = left - eh;                                          // row 2 i + eh of a part is valid iff 32 ct + 2 i < left_lane
+      const unsigned rowbytes = (unsigned)a.ldy * 4u;
+      auto rsrc = [&](const float* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p + (size_t)row0 * a.ldy), 0, left * a.ldy * 4, 0x00020000); };
+      const __amdgpu_buffer_rsrc_t rs_y = rsrc(a.Y);
+      const unsigned gvoff = ((unsigned)eh * (unsigned)a.ldy + 128u * wslice + 4u * er) * 4u;
+      lds_ptr wbase_e = eb + (er >> 2) * kStepBytes + (er & 3) * 512;          // write side: this lane's row er
+      const int wx = ((er & 15) ^ eh) * 16;                                     // (8 rt + 2 q4 + eh) ^ (er & 15) = (8 rt + 2 q4) ^ wx / 16
+      lds_ptr rbase_e = eb + eh * 512;                                          // read side: row 2 i + eh, slot er ^ (row & 15) = (er ^ eh) ^ 2 (i & 7)
+      const int rx = (er ^ eh) * 16;
+      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + 128 * wslice + 4 * er);
+      if (a.bias2) bv += *reinterpret_cast<const f32x4*>(a.bias2 + 128 * wslice + 4 * er);
+      const bool has_bias = a.bias || a.bias2;
+      // The tensor terms are requested ONE GROUP (4 instructions = 8 rows) AHEAD: the requests of group g + 1 are issued in front of the
+      // stores of group g.  Memory operations of a wave retire in order, so a load issued behind a store waits for that store's
+      // acknowledgement -- with loads, wait, stores per group every group paid a store round trip plus a load round trip (78 k clocks per tile
+      // with one residual; the direct epilogue: 69 k).  Registers decide the rest (the staging requests of the next tile, the first step
+      // of the weight ring and the other parts' accumulators stay live here; a spill reload is a load behind stores as well), and so does
+      // the control flow: with one uniform branch per optional term inside the unrolled groups the compiler waited for every mask-bits
+      // dword and spilled it.  So the term set is a COMPILE-TIME parameter of the epilogue (PK: the pipelined 16-byte term -- 0 none, 1 the
+      // residual, 2 the old output of an accumulating product; BITS: mask bits) and the five sets the training step has are dispatched
+      // once per tile; anything else (a second residual, fp32 masks: measurement switches) takes the GEN variant, which reads its
+      // terms in place.
+      constexpr int GN = 4, GPC = 16 / GN, NGRP = GPC * CT;                     // instructions per group, groups per 32-row part / per tile
+      const bool accum = (a.flags & kL512Accum) != 0;
+      const unsigned bvoff = ((unsigned)eh * 16u + 4u * wslice + (er & 3)) * 4u;      // mask bits: the lane's features 4 er .. + 3 of the wave's 128-feature
+      const int sh = 4 * (er >> 2);                                                   // slice: dword 4 wslice + (er & 3) of the row's 16, bits 4 (er >> 2) + c
+      auto rsrc_bits = [&]() { return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.maskbits + (size_t)row0 * 16), 0, left * 64, 0x00020000); };
+      auto epilogue = [&](auto PKc, auto BITSc, auto GENc) {
+        constexpr int PK = decltype(PKc)::value;
+        constexpr bool BITS = decltype(BITSc)::value, GEN = decltype(GENc)::value;
+        const __amdgpu_buffer_rsrc_t rs_p = rsrc(PK == 1 ? a.resid : a.Y);
+        const __amdgpu_buffer_rsrc_t rs_mb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>((BITS ? a.maskbits : (const unsigned*)a.Y) + (size_t)row0 * 16), 0, left * 64, 0x00020000);
+        f32x4 pre[GN];
+        unsigned mb[GN];
+        auto issue = [&](f32x4 (&tp)[GN], unsigned (&tm)[GN], int g) {
+#pragma unroll
+          for (int j = 0; j < GN; ++j) {
+            const int rw = 32 * (g / GPC) + 2 * (GN * (g % GPC) + j);
+            if constexpr (PK != 0) tp[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, gvoff, (unsigned)rw * rowbytes, 0));
+            if constexpr (BITS) tm[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_mb, bvoff, (unsigned)rw * 64u, 0);
+          }
+        };
+        issue(pre, mb, 0);
+        sfor<NGRP>([&](auto Gi) {
+          constexpr int g = decltype(Gi)::value, ct = g / GPC, gi = g % GPC;
+          if constexpr (gi == 0) {                                              // this part's accumulators -> the wave's LDS region
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                f32x4 t;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[c] = acc[rt][ct][4 * q4 + c] * inv_scale;
+                *(lds_f4)(wbase_e + (wx ^ ((8 * rt + 2 * q4) * 16))) = t;
+              }
+          }
+          f32x4 v[GN];
+#pragma unroll
+          for (int j = 0; j < GN; ++j) {
+            const int i = GN * gi + j;
+            v[j] = *(lds_f4)(rbase_e + (i >> 1) * kStepBytes + (i & 1) * 1024 + (rx ^ ((i & 7) * 32)));
+          }
+          f32x4 nxt[GN];
+          unsigned mbn[GN];
+          if constexpr (g + 1 < NGRP) issue(nxt, mbn, g + 1);                   // (rows past M: the descriptors return zeros, nothing of them is stored)
+#pragma unroll
+          for (int j = 0; j < GN; ++j) {
+            const int rw = 32 * ct + 2 * (GN * gi + j);
+            const unsigned so = (unsigned)rw * rowbytes;
+            if (has_bias) v[j] += bv;
+            if constexpr (PK == 1) v[j] += pre[j];
+            if constexpr (GEN) {
+              if (a.resid) v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.resid), gvoff, so, 0));
+              if (a.resid2) v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.resid2), gvoff, so, 0));
+              if (a.mask) {
+                const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.mask), gvoff, so, 0));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[j][c] = m[c] > 0.0f ? v[j][c] : 0.0f;
+              }
+              if (a.maskbits) {
+                const unsigned m = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc_bits(), bvoff, (unsigned)rw * 64u, 0) >> sh;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[j][c] = ((m >> c) & 1u) ? v[j][c] : 0.0f;
+              }
+              if (accum) v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, gvoff, so, 0));
+            }
+            if constexpr (BITS) {
+              const unsigned m = mb[j] >> sh;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[j][c] = ((m >> c) & 1u) ? v[j][c] : 0.0f;
+            }
+            if constexpr (PK == 2) v[j] += pre[j];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs_y, gvoff, so, 0);
+            if (a.amax_out && rw < left_lane) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) y_max = max(y_max, __float_as_uint(v[j][c]) & 0x7fffffffu);
+            }
+          }
+          if constexpr (g + 1 < NGRP) {
+#pragma unroll
+            for (int j = 0; j < GN; ++j) {
+              pre[j] = nxt[j];
+              mb[j] = mbn[j];
+            }
+          }
+        });
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using BT = std::integral_constant<bool, true>;
+      using BF = std::integral_constant<bool, false>;
+      const bool generic = a.resid2 || a.mask || (a.resid && (accum || a.maskbits));
+      if (generic) epilogue(I0{}, BF{}, BT{});
+      else if (a.maskbits) {
+        if (accum) epilogue(I2{}, BT{}, BF{});
+        else epilogue(I0{}, BT{}, BF{});
+      } else if (accum) epilogue(I2{}, BF{}, BF{});
+      else if (a.resid) epilogue(I1{}, BF{}, BF{});
+      else epilogue(I0{}, BF{}, BF{});
+    } else {
     // ---- epilogue: D layout of a 32 x 32 tile: lane holds row (of x) = lane & 31, features 8 (e >> 2) + 4 (lane >> 5) + (e & 3).
-    // One 32-row half at a time into registers (the weight ring's are free here), then one pass per optional term -- a branch per term and
-    // half, not one per term and four values (130 uniform branches per tile as first written).
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const long long row = tile * kRows + 32 * ct + (lane & 31);
-      if (row >= a.M) continue;
-      constexpr int NV = 4 * NRT;
-      f32x4 v[NV];
-      const size_t at0 = (size_t)row * a.ldy + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);        // + 32 rt + 8 q4
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[4 * rt + q4][c] = acc[rt][ct][4 * q4 + c];
-          if constexpr (AR == 1) v[4 * rt + q4] *= inv_scale;
+      // One 32-row half at a time into registers (the weight ring's are free here), then one pass per optional term -- a branch per term and
+      // half, not one per term and four values (130 uniform branches per tile as first written).
+  #pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const long long row = tile * kRows + 32 * ct + (lane & 31);
+        if (row >= a.M) continue;
+        constexpr int NV = 4 * NRT;
+        f32x4 v[NV];
+        const size_t at0 = (size_t)row * a.ldy + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);        // + 32 rt + 8 q4
+  #pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+  #pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * rt + q4][c] = acc[rt][ct][4 * q4 + c];
+            if constexpr (AR == 1) v[4 * rt + q4] *= inv_scale;
+          }
+        if (a.bias) {
+          const float* bp = a.bias + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);
+  #pragma unroll
+          for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(bp + 32 * (n >> 2) + 8 * (n & 3));
         }
-      if (a.bias) {
-        const float* bp = a.bias + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);
-#pragma unroll
-        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(bp + 32 * (n >> 2) + 8 * (n & 3));
-      }
-      if (a.bias2) {
-        const float* bp = a.bias2 + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);
-#pragma unroll
-        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(bp + 32 * (n >> 2) + 8 * (n & 3));
-      }
-      if (a.resid) {
-#pragma unroll
-        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.resid + at0 + 32 * (n >> 2) + 8 * (n & 3));
-      }
-      if (a.resid2) {
-#pragma unroll
-        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.resid2 + at0 + 32 * (n >> 2) + 8 * (n & 3));
-      }
-      if (a.mask) {
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + at0 + 32 * (n >> 2) + 8 * (n & 3));
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[n][c] = m[c] > 0.0f ? v[n][c] : 0.0f;
+        if (a.bias2) {
+          const float* bp = a.bias2 + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);
+  #pragma unroll
+          for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(bp + 32 * (n >> 2) + 8 * (n & 3));
         }
-      }
-      if (a.maskbits) {
-        // one 16-byte load per row: the 128 decisions of the wave's feature slice; v[n][c] is feature 32 (rt0 + rt) + 8 q4 + 4 h + c of it
-        // (n = 4 rt + q4, h = lane / 32): dword 2 (q4 % 2) + h, bit 8 (rt0 + rt) + 4 (q4 / 2) + c
-        const u32x4 mb = *reinterpret_cast<const u32x4*>(a.maskbits + (size_t)row * 16 + 4 * wslice);
-        const bool hi = lane >= 32;
-        const unsigned m0 = (hi ? mb[1] : mb[0]) >> (8 * rt0), m1 = (hi ? mb[3] : mb[2]) >> (8 * rt0);
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-          const unsigned m = (n & 1) ? m1 : m0;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[n][c] = ((m >> (8 * (n >> 2) + 4 * ((n & 3) >> 1) + c)) & 1u) ? v[n][c] : 0.0f;
+        if (a.resid) {
+  #pragma unroll
+          for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.resid + at0 + 32 * (n >> 2) + 8 * (n & 3));
         }
-      }
-      if (a.flags & kL512Accum) {
-#pragma unroll
-        for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3));
-      }
-#pragma unroll
-      for (int n = 0; n < NV; ++n) *reinterpret_cast<f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3)) = v[n];
-      if (a.amax_out) {
-#pragma unroll
-        for (int n = 0; n < NV; ++n)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) y_max = max(y_max, __float_as_uint(v[n][c]) & 0x7fffffffu);
+        if (a.resid2) {
+  #pragma unroll
+          for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.resid2 + at0 + 32 * (n >> 2) + 8 * (n & 3));
+        }
+        if (a.mask) {
+  #pragma unroll
+          for (int n = 0; n < NV; ++n) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + at0 + 32 * (n >> 2) + 8 * (n & 3));
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) v[n][c] = m[c] > 0.0f ? v[n][c] : 0.0f;
+          }
+        }
+        if (a.maskbits) {
+          // one 16-byte load per row: the 128 decisions of the wave's feature slice; v[n][c] is feature 32 (rt0 + rt) + 8 q4 + 4 h + c of it
+          // (n = 4 rt + q4, h = lane / 32): dword 2 (q4 % 2) + h, bit 8 (rt0 + rt) + 4 (q4 / 2) + c
+          const u32x4 mb = *reinterpret_cast<const u32x4*>(a.maskbits + (size_t)row * 16 + 4 * wslice);
+          const bool hi = lane >= 32;
+          const unsigned m0 = (hi ? mb[1] : mb[0]) >> (8 * rt0), m1 = (hi ? mb[3] : mb[2]) >> (8 * rt0);
+  #pragma unroll
+          for (int n = 0; n < NV; ++n) {
+            const unsigned m = (n & 1) ? m1 : m0;
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) v[n][c] = ((m >> (8 * (n >> 2) + 4 * ((n & 3) >> 1) + c)) & 1u) ? v[n][c] : 0.0f;
+          }
+        }
+        if (a.flags & kL512Accum) {
+  #pragma unroll
+          for (int n = 0; n < NV; ++n) v[n] += *reinterpret_cast<const f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3));
+        }
+  #pragma unroll
+        for (int n = 0; n < NV; ++n) *reinterpret_cast<f32x4*>(a.Y + at0 + 32 * (n >> 2) + 8 * (n & 3)) = v[n];
+        if (a.amax_out) {
+  #pragma unroll
+          for (int n = 0; n < NV; ++n)
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) y_max = max(y_max, __float_as_uint(v[n][c]) & 0x7fffffffu);
+        }
       }
     }
 #ifdef DINER_L512_PROF

@@ -299,7 +299,7 @@ def test_no_spill_code_in_the_training_kernels(tmp_path):
             # slab loop (no spill / reload is interleaved with MFMAs).  Bounded here.
             # round 5: the counts are pinned -- 40 / 54 with hipcc of ROCm 7.2 (35 / 49 before the bit-mask branch of the epilogue,
             # which keeps one more pointer) -- so that drift is visible
-            assert len(spills) <= {"k_fwd512_f16x3": 40, "k_run512_f16x3": 54}[name], (name, len(spills))
+            assert len(spills) <= {"k_fwd512_f16x3": 6, "k_run512_f16x3": 18}[name], (name, len(spills))      # round 6 (epilogue of the 128-row shape through LDS, compile-time term sets): 0 / 12
             for i, l in enumerate(body):
                 if "scratch_" in l:      # not interleaved with MFMAs: none within 25 instructions on BOTH sides
                     before = any("v_mfma" in x for x in body[max(0, i - 25):i])

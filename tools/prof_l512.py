@@ -56,6 +56,8 @@ def run(tag, **kw):
 run("forward f16x3 plain")
 run("forward f16x3 + residual", resid=res)
 run("forward f16x3 relu_in", relu_in=True)
+run("forward f16x3 accumulating", accumulate=True)
+run("forward f16x3 fp32 mask + accumulating", accumulate=True, mask=res)
 for Msmall in (163840, 20480):
     x, y, res = x[:Msmall], y[:Msmall], res[:Msmall]
     run(f"forward f16x3 plain, {Msmall} rows")
