@@ -185,3 +185,45 @@ def build_modules(sc, msd, device, normals=None):
     nerf.focal = Kin[:, :, [0, 1], [0, 1]].contiguous()
     nerf.image_shape = scs[0]["image_shape"].clone().to(device)
     return nerf, import_obj("src.models.nerf_renderer.NeRFRendererDGS")
+
+
+# ---- "realistic magnitudes" (round 6, fixture G20): what a trained checkpoint's tensors look like, as far as magnitudes go --------------
+# ResNet34 features are non-negative and heavy-tailed and trained weights are not Kaiming-distributed; the f16x3 split of the field kernels
+# (|w| < 1024, activations below the fp16 range, DESIGN.md "Arithmetic modes") was exercised by N(0,1) latents and init-distributed weights
+# only.  Both recipes use exactly rounded element-wise operations on seeded normal / uniform draws (powers of two, multiplications,
+# additions), so that they are bit-identical on every host; the fixture pins a sha256 of what they produce.
+def realistic_latent(nv, C, Hf, Wf, seed, hot_gain=8.0, n_hot=6):
+    """(nv, C, Hf, Wf): relu(N(0,1)) x a per-channel power-of-two scale 2^round(1.2 N(0,1)) (clamped to [1/8, 16]) x a heavy element tail
+    (1 + |N(0,1)|^3 / 8), and n_hot channels x hot_gain (a few dominant feature channels): mean 0.74, 99.9 % below 30, maximum ~470 at the defaults."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.relu(torch.randn(nv, C, Hf, Wf, generator=g))
+    n = torch.round(1.2 * torch.randn(1, C, 1, 1, generator=g)).clamp(-3, 4)
+    x = x * torch.ldexp(torch.ones_like(n), n.to(torch.int32))
+    t = torch.randn(nv, C, Hf, Wf, generator=g).abs()
+    x = x * (1.0 + 0.125 * (t * t * t))
+    hot = torch.randperm(C, generator=g)[:n_hot]
+    x[:, hot] = x[:, hot] * hot_gain
+    return x.contiguous()
+
+
+def realistic_mlp_state_dict(seed=4321, n_planted=3, planted_lo=10.0, planted_hi=50.0, bias_std=1.0):
+    """make_mlp_state_dict's tensors with row-wise power-of-two scales 2^round(0.8 N(0,1)) (clamped to [1/4, 8]), n_planted entries per weight
+    matrix of magnitude planted_lo .. planted_hi (random sign) and biases of O(1)."""
+    sd = make_mlp_state_dict(seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    out = {}
+    for k in sorted(sd):
+        v = sd[k].clone()
+        if k.endswith(".weight"):
+            o, i = v.shape
+            n = torch.round(0.8 * torch.randn(o, 1, generator=g)).clamp(-2, 3)
+            if not k.startswith("lin_out"):
+                v = v * torch.ldexp(torch.ones_like(n), n.to(torch.int32))
+                idx = torch.randint(0, o * i, (n_planted,), generator=g)
+                mag = planted_lo + (planted_hi - planted_lo) * torch.rand(n_planted, generator=g)
+                sgn = torch.where(torch.rand(n_planted, generator=g) < 0.5, -torch.ones(n_planted), torch.ones(n_planted))
+                v.view(-1)[idx] = mag * sgn
+        else:
+            v = torch.randn(v.shape, generator=g) * bias_std
+        out[k] = v.contiguous()
+    return out

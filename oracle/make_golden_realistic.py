@@ -1,0 +1,119 @@
+"""G20 (round 6): parity on REALISTIC MAGNITUDES, from the IMPORTED reference (build container only; test infrastructure).
+
+    python oracle/make_golden_realistic.py
+
+Every other fixture uses the reference's random init (fc_1 ~ N(0, 0.03)) and an N(0,1) latent.  ResNet34 features are non-negative and
+heavy-tailed and trained weights are not Kaiming-distributed; here the latent follows diner_amd.synthetic.realistic_latent (relu, per-channel
+power-of-two scales, a heavy element tail, six channels x 8: mean 0.74, maximum ~470) and the MLP diner_amd.synthetic.realistic_mlp_state_dict
+(row-wise scales, three planted entries of |w| = 10 .. 50 per matrix, biases of O(1)).  The reference's renderer.forward (nerf_renderer.py:399-430 -> pixelnerf.py:55-145,
+resnetfc.py:129-159, image_encoder.py:97-146) runs on 512 rays of a 64 x 64 scene at K = 128 / G = 48 / 1000 candidates with injected noise:
+  variant A  magnitudes as above: residual stream up to ~8e3, hidden activations up to ~2e3 -- inside the fp16 range of the f16x3 split; the GPU test asserts that the
+             fall-back counter stays 0 (or reports the rate) and holds both parity-grade modes to 1e-4;
+  variant B  the same scene with the hot channels x 128 (hidden activations up to ~1.2e5, the fp16 maximum is 65504): beyond the range ON PURPOSE inside a full render -- the fp16-operand
+             kernels must raise their flag and the gated exact-fp32 pass must deliver the reference's values.
+The sampler sees the depth maps only, so both variants share the sample positions.  The oracle restatement runs on every 8th ray and must agree
+with the reference to fp32 round-off; the reference's outputs are what is stored (inputs are regenerated from seeds, sha256-guarded)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import diner_oracle as O                                     # noqa: E402
+from oracle.ref_import import import_reference, build_reference_nerf     # noqa: E402
+from oracle.make_golden import inject_noise, report, sha, OUT            # noqa: E402
+from diner_amd.synthetic import make_scene, realistic_latent, realistic_mlp_state_dict   # noqa: E402
+
+W = H = 64
+K, G, N_CAND, NR = 128, 48, 1000, 512
+SCENE_SEED, LATENT_SEED, MLP_SEED, NOISE_SEED = 31, 2020, 4321, 2021
+HOT_A, HOT_B = 8.0, 8.0 * 128.0
+
+
+def activation_range(scene, w, xyz, dirs):
+    """(largest |residual stream|, largest hidden activation) of resnetfc.py:129-159 on these points: what the fp16-operand kernels must hold
+    below 65504 x 16 (stream, carried at scale 16 in fp32) and 65504 (B operands) -- documentation of the fixture, not a test input."""
+    import torch.nn.functional as F
+    zx = O.mlp_input(scene, xyz, dirs)
+    z = zx[..., :w.d_latent]
+    x = F.linear(zx[..., w.d_latent:], w.lin_in_w, w.lin_in_b)
+    xm = hm = 0.0
+    for b in range(len(w.fc0_w)):
+        if b == w.combine_layer:
+            x = x.mean(0)
+        if b < w.combine_layer:
+            x = x + F.linear(z, w.lin_z_w[b], w.lin_z_b[b])
+        net = F.linear(torch.relu(x), w.fc0_w[b], w.fc0_b[b])
+        xm, hm = max(xm, float(x.abs().max())), max(hm, float(net.max()))
+        x = x + F.linear(torch.relu(net), w.fc1_w[b], w.fc1_b[b])
+    return max(xm, float(x.abs().max())), hm
+
+
+def main():
+    torch.manual_seed(0)
+    ns = import_reference()
+    sc = make_scene(W, H, seed=SCENE_SEED, latent=False)
+    normals = ns.depth2normal.depth2normal(sc["depths"], sc["src_intrinsics"])
+    Hf = Wf = (H + 128) // 2
+    msd = realistic_mlp_state_dict(MLP_SEED)
+    rays_all = ns.cam_geometry.gen_rays(sc["target_extrinsics"][None], sc["target_intrinsics"][None], W, H,
+                                        torch.tensor([sc["znear"]]), torch.tensor([sc["zfar"]])).view(H * W, 8)
+    idx = torch.linspace(0, H * W - 1, NR).round().long()
+    rs = rays_all[idx].contiguous()
+    g = torch.Generator().manual_seed(NOISE_SEED)
+    ncz, ngz, nfz = torch.rand(NR, N_CAND, generator=g), torch.randn(NR, G, generator=g), torch.rand(NR, K, generator=g)
+    out = {}
+    for tag, hot in (("a", HOT_A), ("b", HOT_B)):
+        lat = realistic_latent(4, 512, Hf, Wf, LATENT_SEED, hot_gain=hot)
+        nerf = build_reference_nerf(ns)
+        nerf.mlp_fine.load_state_dict(msd, strict=True)
+        enc = nerf.encoder
+        enc.depths, enc.depths_std, enc.normals = sc["depths"][None], sc["depths_std"][None], normals[None]
+        enc.latent = lat[None]
+        enc.nviews, enc.nobjects = 4, 1
+        nerf.poses = sc["src_extrinsics"][None]
+        nerf.c = sc["src_intrinsics"][None, :, :2, -1]
+        nerf.focal = sc["src_intrinsics"][None][:, :, [0, 1], [0, 1]]
+        nerf.image_shape = sc["image_shape"].clone()
+        ren = ns.nerf_renderer.NeRFRendererDGS(n_samples=K, n_depth_candidates=N_CAND, n_gaussian=G, white_bkgd=False)
+        with torch.no_grad(), inject_noise(ncz, ngz, nfz):
+            o = ren.forward(nerf, rs[None], want_weights=True)
+            z_ref = ren.fill_up_uniform_samples(
+                ren.sample_depthguided(rs[None], nerf, n_samples=K, n_candidates=N_CAND, n_gaussian=G), rs[None])[0]
+            # the field itself on the reference's samples of every 4th ray (what the compositor turns into colours)
+            sub4 = slice(0, NR, 4)
+            pts = (rs[sub4, None, :3] + z_ref[sub4, :, None] * rs[sub4, None, 3:6]).reshape(1, -1, 3)
+            dirs = rs[sub4, None, 3:6].expand(-1, K, -1).reshape(1, -1, 3)
+            field = nerf(pts, dirs)[0]
+        scene = O.Scene(latent=lat, depths=sc["depths"], depths_std=sc["depths_std"], normals=normals, poses=sc["src_extrinsics"],
+                        focal=nerf.focal[0], c=nerf.c[0], image_shape=sc["image_shape"], feature_padding=float(enc.feature_padding))
+        w = O.MLPWeights.from_state_dict(msd)
+        sub = slice(0, NR, 8)
+        with torch.no_grad():
+            oo = O.render(scene, w, rs[sub].contiguous(), K, N_CAND, G, False, ncz[sub], ngz[sub], nfz[sub])
+            # how large the activations get: the residual stream and the hidden layers of the oracle's MLP on a slice of the points
+            acts = activation_range(scene, w, pts[0][:8192], dirs[0][:8192])
+        report(f"g20{tag} z", z_ref[sub], oo["z"], exact=True)
+        report(f"g20{tag} rgb", o.fine.rgb[0][sub], oo["rgb"])
+        report(f"g20{tag} depth", o.fine.depth[0][sub], oo["depth"])
+        print(f"    variant {tag}: latent max {float(lat.max()):.3g} (mean {float(lat.mean()):.3g}), max |w| {max(float(v.abs().max()) for k, v in msd.items() if k.endswith('weight')):.3g}, "
+              f"field sigma max {float(field[:, 3].max()):.3g}, rgb range [{float(o.fine.rgb.min()):.3g}, {float(o.fine.rgb.max()):.3g}]"
+              f", residual stream up to {acts[0]:.3g}, hidden activations up to {acts[1]:.3g}")
+        out.update({f"rgb_{tag}": o.fine.rgb[0].numpy(), f"depth_{tag}": o.fine.depth[0].numpy(), f"field_{tag}": field.numpy(),
+                    f"weights_sum_{tag}": o.fine.weights[0].sum(-1).numpy(), f"lat_sha_{tag}": sha(lat[:, :8, :4, :4], lat[:, -8:, -4:, -4:]),
+                    f"stream_max_{tag}": acts[0], f"hidden_max_{tag}": acts[1], f"hot_gain_{tag}": hot})
+        if tag == "a":
+            out["z"] = z_ref.numpy()
+        else:
+            assert np.array_equal(out["z"], z_ref.numpy()), "the sampler must not depend on the latent / the MLP"
+    np.savez_compressed(os.path.join(OUT, "g20_realistic.npz"), W=W, H=H, K=K, G=G, n_cand=N_CAND, scene_seed=SCENE_SEED, latent_seed=LATENT_SEED,
+                        mlp_seed=MLP_SEED, noise_seed=NOISE_SEED, znear=sc["znear"], zfar=sc["zfar"], ray_idx=idx.numpy(), rays=rs.numpy(),
+                        in_sha=sha(ncz[:64], ngz[:64], nfz[:64]), mlp_sha=sha(*[msd[k] for k in sorted(msd)]), **out)
+    print("wrote", os.path.join(OUT, "g20_realistic.npz"))
+
+
+if __name__ == "__main__":
+    main()

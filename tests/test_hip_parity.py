@@ -898,3 +898,61 @@ def test_tile_queues_hand_out_every_tile_once(ops):
             tol = 2e-5 if mode == "f16x3" else 2e-2
             assert max_norm_rel(got.cpu(), exact.cpu()) < tol, (NR, K, mode)
     assert hm.fallback_launches() == 0
+
+
+def _g20_inputs(variant):
+    """The realistic-magnitude scene of G20 rebuilt from its seeds (sha256-guarded): (fixture, scene dict with latent, mlp state dict)."""
+    from diner_amd.synthetic import make_scene, realistic_latent, realistic_mlp_state_dict
+    from src.util.depth2normal import depth2normal
+    g = load("g20_realistic.npz")
+    W, H = int(g["W"]), int(g["H"])
+    sc = make_scene(W, H, seed=int(g["scene_seed"]), latent=False)
+    sc["normals"] = depth2normal(sc["depths"], sc["src_intrinsics"])
+    Hf = (H + 128) // 2
+    lat = realistic_latent(4, 512, Hf, Hf, int(g["latent_seed"]), hot_gain=float(g[f"hot_gain_{variant}"]))
+    assert sha(lat[:, :8, :4, :4], lat[:, -8:, -4:, -4:]) == str(g[f"lat_sha_{variant}"]), "realistic_latent is not the fixture's on this host"
+    sc["latent"] = lat
+    msd = realistic_mlp_state_dict(int(g["mlp_seed"]))
+    assert sha(*[msd[k] for k in sorted(msd)]) == str(g["mlp_sha"]), "realistic_mlp_state_dict is not the fixture's on this host"
+    return g, sc, msd
+
+
+@pytest.mark.parametrize("variant", ["a", "b"], ids=["realistic_magnitudes", "beyond_the_fp16_range_inside_a_render"])
+def test_realistic_magnitudes_g20(ops, precision, variant):
+    """G20 (round 6): the reference's renderer.forward on a latent with ResNet-feature statistics (non-negative, heavy-tailed, a few dominant
+    channels: mean 0.74, maximum 470) and an MLP that is not the init (row-wise scales, |w| up to 50, biases of O(1)) -- K = 128, 512 rays,
+    the reference's sample positions, both parity-grade arithmetic modes at 1e-4 (oracle/make_golden_realistic.py; resnetfc.py:129-159,
+    image_encoder.py:97-146).  Variant a: residual stream up to 5e3, hidden activations up to 1.2e3 -- the f16x3 kernels must NOT fall back
+    (fallback_launches() == 0: the headline mode is the mode such a checkpoint runs in).  Variant b: the hot channels x 128, hidden
+    activations up to 1.1e5 (fp16 ends at 65504) -- the fp16-operand kernels must raise their flag INSIDE a full render and the gated
+    exact-fp32 pass must deliver the reference's values (until round 6 only hand-planted values exercised it)."""
+    g, sc, msd = _g20_inputs(variant)
+    hs, hm = hip_scene(ops, sc), hip_mlp(ops, msd)
+    assert hm.h3_ok and hm.wmax < 64, hm.wmax
+    rays, z = T(g["rays"]).cuda(), T(g["z"]).cuda()
+    K = int(g["K"])
+    hm.fallback_launches(reset=True)
+    field = ops.field_from_rays(hs, hm, rays, z).cpu()                       # (NR, K, 4)
+    wts, rgb, depth = ops.render(hs, hm, rays, z, False, want_weights=True)
+    fb = hm.fallback_launches(reset=True)
+    ref_f = T(g[f"field_{variant}"]).view(-1, K, 4)
+    e_sig = ((field[::4, :, 3] - ref_f[..., 3]).abs().max() / ref_f[..., 3].abs().max()).item()
+    e_col = (field[::4, :, :3] - ref_f[..., :3]).abs().max().item()
+    ref_rgb, ref_d = T(g[f"rgb_{variant}"]), T(g[f"depth_{variant}"])
+    ok = torch.isfinite(ref_rgb).all(-1) & torch.isfinite(ref_d)            # (variant b: the REFERENCE's compositor overflows fp32 on a few rays
+    n_bad = int((~ok).sum())                                                 # whose last sample lies beyond `far`: exp(+|delta| sigma) at sigma ~ 5e3)
+    e_rgb = ((rgb.cpu() - ref_rgb)[ok].abs().max() / ref_rgb[ok].abs().max()).item()
+    e_d = ((depth.cpu() - ref_d)[ok].abs().max() / ref_d[ok].abs().max()).item()
+    print(f"G20 {variant} [{precision}]: field sigma {e_sig:.2e} (max-norm-rel, sigma up to {float(ref_f[..., 3].max()):.3g}), colours {e_col:.2e} (abs), "
+          f"rgb {e_rgb:.2e}, depth {e_d:.2e} on {int(ok.sum())} rays ({n_bad} rays non-finite in the reference itself); fall-back launches {fb}; "
+          f"reference activations: residual stream up to {float(g[f'stream_max_{variant}']):.3g}, hidden up to {float(g[f'hidden_max_{variant}']):.3g}")
+    assert e_sig < TOL and e_col < TOL and e_rgb < TOL and e_d < TOL
+    assert n_bad <= 4
+    np.testing.assert_allclose(wts.cpu().sum(-1)[ok].numpy(), g[f"weights_sum_{variant}"][ok.numpy()], rtol=1e-4, atol=3e-5)
+    if precision == "f16x3":
+        if variant == "a":
+            assert fb == 0, f"the f16x3 kernels fell back on realistic magnitudes ({fb} launches): the headline mode is not what such a checkpoint runs in"
+        else:
+            assert fb >= 1, "activations beyond the fp16 range did not raise the range flag inside a render"
+    else:
+        assert fb == 0

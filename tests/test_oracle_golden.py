@@ -174,3 +174,32 @@ def test_oracle_generalises_to_other_mlp_shapes():
     raw = O.mlp_forward(w, O.mlp_input(scene, xyz, dirs, PIX["num_freqs"], PIX["freq_factor"]))
     f = torch.cat([torch.sigmoid(raw[..., :3]), torch.relu(raw[..., 3:4])], dim=-1)
     assert torch.equal(f, torch.from_numpy(g["pix_field"]))
+
+
+def test_oracle_on_realistic_magnitudes_g20():
+    """G20: the oracle against the imported reference's outputs on the realistic-magnitude scene (a slice of the rays: the whole fixture is a
+    GPU test), and the seeded recipes reproduce the fixture's inputs on this host (sha256)."""
+    import numpy as np
+    from tests.helpers import load, sha, max_norm_rel
+    from diner_amd.synthetic import make_scene, realistic_latent, realistic_mlp_state_dict
+    from src.util.depth2normal import depth2normal
+    g = load("g20_realistic.npz")
+    W, H, K = int(g["W"]), int(g["H"]), int(g["K"])
+    sc = make_scene(W, H, seed=int(g["scene_seed"]), latent=False)
+    normals = depth2normal(sc["depths"], sc["src_intrinsics"])
+    msd = realistic_mlp_state_dict(int(g["mlp_seed"]))
+    assert sha(*[msd[k] for k in sorted(msd)]) == str(g["mlp_sha"])
+    w = O.MLPWeights.from_state_dict(msd)
+    Kin = sc["src_intrinsics"]
+    rays, z = torch.from_numpy(g["rays"]), torch.from_numpy(g["z"])
+    sub = slice(0, rays.shape[0], 32)
+    for variant in "ab":
+        lat = realistic_latent(4, 512, (H + 128) // 2, (W + 128) // 2, int(g["latent_seed"]), hot_gain=float(g[f"hot_gain_{variant}"]))
+        assert sha(lat[:, :8, :4, :4], lat[:, -8:, -4:, -4:]) == str(g[f"lat_sha_{variant}"])
+        scene = O.Scene(latent=lat, depths=sc["depths"], depths_std=sc["depths_std"], normals=normals, poses=sc["src_extrinsics"],
+                        focal=Kin[:, [0, 1], [0, 1]], c=Kin[:, :2, -1], image_shape=sc["image_shape"], feature_padding=sc["feature_padding"])
+        with torch.no_grad():
+            _, rgb, depth, _ = O.composite(scene, w, rays[sub].contiguous(), z[sub].contiguous(), False)
+        ref_rgb, ref_d = torch.from_numpy(g[f"rgb_{variant}"])[sub], torch.from_numpy(g[f"depth_{variant}"])[sub]
+        ok = torch.isfinite(ref_rgb).all(-1) & torch.isfinite(ref_d)
+        assert max_norm_rel(rgb[ok], ref_rgb[ok]) < 2e-6 and max_norm_rel(depth[ok], ref_d[ok]) < 2e-6
