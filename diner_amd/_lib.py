@@ -91,6 +91,13 @@ SIGNATURES = {
     "diner_mlp_generic_workspace_bytes": (C.c_size_t, [C.POINTER(DinerMlpParams), C.c_int, C.c_longlong]),
     "diner_mlp_generic_forward_f32": (C.c_int, [C.POINTER(DinerMlpParams), C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p,
                                                 C.c_void_p, C.c_void_p]),
+    "diner_mlp_generic_train_workspace_bytes": (C.c_size_t, [C.POINTER(DinerMlpParams), C.c_int, C.c_longlong]),
+    "diner_mlp_generic_train_forward_f32": (C.c_int, [C.POINTER(DinerMlpParams), C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p]),
+    "diner_mlp_generic_backward_f32": (C.c_int, [C.POINTER(DinerMlpParams), C.POINTER(DinerMlpParams), C.c_float, C.c_void_p, C.c_int, C.c_longlong,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "diner_field_inputs_generic_bwd_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]),
     "diner_field_inputs_generic_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "diner_field_train_forward_fused_f32": (C.c_int, [C.POINTER(DinerScene), C.c_void_p, C.POINTER(DinerMlpParams), C.c_void_p, C.c_void_p,

@@ -419,6 +419,118 @@ def object_slabs(latent):
     return tuple(latent[sb] for sb in range(latent.shape[0]))
 
 
+# ---- training through the generic slow path (ABI v6): any ResnetFC / PixelNeRF configuration the reference's constructors accept
+class GenericMlpFunction(torch.autograd.Function):
+    """ResnetFC.forward on an explicit (NV, B, d_latent + d_in) matrix (resnetfc.py:129-159), differentiable with respect to the matrix and
+    the parameters: forward and backward are one library call each (diner_mlp_generic_train_forward_f32 / diner_mlp_generic_backward_f32:
+    the layers and their adjoints chained on the exact-fp32 MFMA GEMM)."""
+
+    @staticmethod
+    def forward(ctx, conf, names, zx, *params):
+        import ctypes as C
+        from .ops import GenericMlp
+        _require_hip(zx)
+        zx = _f32c(zx.detach())
+        params = [_f32c(p.detach()) for p in params]
+        gm = GenericMlp(dict(zip(names, params)), **conf)
+        NV, B, D = zx.shape
+        if D != gm.d_latent + gm.d_in:
+            raise ValueError(f"diner_amd: ResnetFC input width {D} != d_latent + d_in = {gm.d_latent + gm.d_in}")
+        out = torch.empty((B, gm.d_out) if gm.combines else (NV, B, gm.d_out), device=zx.device)
+        with torch.cuda.device(zx.device):
+            ws = torch.empty(int(lib.diner_mlp_generic_train_workspace_bytes(C.byref(gm.params), NV, B)), dtype=torch.uint8, device=zx.device)
+            _lib.check(lib.diner_mlp_generic_train_forward_f32(C.byref(gm.params), gm.beta, _ptr(zx), NV, B, _ptr(out), _ptr(ws), _stream()))
+        ctx.gm, ctx.conf, ctx.names = gm, conf, names
+        ctx.save_for_backward(ws, zx, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        import ctypes as C
+        from .ops import GenericMlp
+        ws, zx, params = ctx.saved_tensors[0], ctx.saved_tensors[1], list(ctx.saved_tensors[2:])
+        NV, B, D = zx.shape
+        grads = [torch.empty_like(p) for p in params]
+        gg = GenericMlp(dict(zip(ctx.names, grads)), **ctx.conf)
+        d_zx = torch.empty_like(zx) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(zx.device):
+            _lib.check(lib.diner_mlp_generic_backward_f32(C.byref(ctx.gm.params), C.byref(gg.params), ctx.gm.beta, _ptr(zx), NV, B,
+                                                          _ptr(_f32c(d_out)), _ptr(ws), _ptr(d_zx), _stream()))
+        return (None, None, d_zx) + tuple(grads)
+
+
+def generic_mlp_train(mlp_module, zx):
+    """ResnetFC.forward(zx (NV, B, C)) in grad mode for ANY configuration (the fused shape included: an explicit matrix has no scene to gather
+    from, so it runs on the generic exact-fp32 path)."""
+    names = [k for k, _ in mlp_module.named_parameters()]
+    conf = dict(combine_layer=mlp_module.combine_layer, beta=mlp_module.beta, d_latent=mlp_module.d_latent)
+    return GenericMlpFunction.apply(conf, names, zx, *[p for _, p in mlp_module.named_parameters()])
+
+
+class _GenericInputs(torch.autograd.Function):
+    """(xyz, viewdirs) -> the per-view MLP input rows of PixelNeRF.forward for any encoding / latent width (pixelnerf.py:84-128), differentiable
+    with respect to the encoder's latent (the bilinear lookup's adjoint, diner_field_inputs_generic_bwd_f32); the geometry carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, scene, xyz, viewdirs, latent, num_freqs, include_input, freq_factor, d_row):
+        xyz, viewdirs = _f32c(xyz.detach()), _f32c(viewdirs.detach())
+        P = xyz.shape[0]
+        zx = torch.empty(scene.nv, P, d_row, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.check(lib.diner_field_inputs_generic_f32(scene.ref, None, None, 0, _ptr(xyz), _ptr(viewdirs), P, int(num_freqs), int(include_input),
+                                                          float(freq_factor), _ptr(zx), _stream()))
+        ctx.scene, ctx.d_row, ctx.latent_shape = scene, d_row, tuple(latent.shape)
+        ctx.save_for_backward(xyz, viewdirs)
+        return zx
+
+    @staticmethod
+    def backward(ctx, d_zx):
+        xyz, viewdirs = ctx.saved_tensors
+        d_lat = None
+        if ctx.needs_input_grad[3]:
+            nv, Cc, Hf, Wf = ctx.latent_shape
+            with torch.cuda.device(xyz.device):
+                d_cl = torch.empty(nv, Hf, Wf, Cc, device=xyz.device)
+                _lib.check(lib.diner_field_inputs_generic_bwd_f32(ctx.scene.ref, _ptr(xyz), _ptr(viewdirs), xyz.shape[0], ctx.d_row, _ptr(_f32c(d_zx)),
+                                                                  _ptr(d_cl), _stream()))
+                d_lat = torch.empty(nv, Cc, Hf, Wf, device=xyz.device)
+                _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), nv, Hf * Wf, Cc, _ptr(d_lat), _stream()))
+        return (None, None, None, d_lat, None, None, None, None)
+
+
+class _FieldAct(torch.autograd.Function):
+    """raw (P, 4) -> [sigmoid(rgb), relu(sigma)] (pixelnerf.py:139-143) and its adjoint (diner_field_act_f32)."""
+
+    @staticmethod
+    def forward(ctx, raw):
+        raw = _f32c(raw.detach())
+        out = torch.empty_like(raw)
+        with torch.cuda.device(raw.device):
+            _lib.check(lib.diner_field_act_f32(_ptr(raw), None, raw.shape[0], 4, _ptr(out), _stream()))
+        ctx.save_for_backward(raw)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        raw, = ctx.saved_tensors
+        d_raw = torch.empty_like(raw)
+        with torch.cuda.device(raw.device):
+            _lib.check(lib.diner_field_act_f32(_ptr(raw), _ptr(_f32c(d_out)), raw.shape[0], 4, _ptr(d_raw), _stream()))
+        return d_raw
+
+
+def field_train_generic(scene: HipScene, mlp_module, xyz, viewdirs, latent, num_freqs, include_input, freq_factor):
+    """PixelNeRF.forward for one object in grad mode on the generic path: (P, 3) x 2 -> (P, 4), differentiable with respect to the latent
+    (NV, C, Hf, Wf) and the MLP parameters (any d_hidden / n_blocks / combine_layer < n_blocks / encoding / latent width / NV <= 4 / Softplus)."""
+    per = 2 * int(num_freqs) + (1 if include_input else 0)
+    d_row = scene.C + 4 * per + 3
+    zx = _GenericInputs.apply(scene, xyz, viewdirs, latent, num_freqs, include_input, freq_factor, d_row)
+    raw = generic_mlp_train(mlp_module, zx)
+    if raw.dim() != 2 or raw.shape[-1] != 4:
+        raise NotImplementedError("diner_amd: PixelNeRF needs an MLP that combines its views (combine_layer < n_blocks) and has 4 outputs")
+    return _FieldAct.apply(raw)
+
+
 def field_train(scene: HipScene, xyz, viewdirs, latent, params, freq_factor=6.28):
     return FieldFunction.apply(scene, xyz, viewdirs, latent, float(freq_factor), *params)
 

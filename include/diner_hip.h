@@ -361,14 +361,27 @@ int diner_field_train_ws_layout(long long P, int nv, long long* float_offsets, i
  * default 128, any n_blocks / combine_layer / d_in / d_latent / d_out, Softplus for beta > 0; combine_type "average" is the only one
  * the reference implements, :9-14) and any number of views: the layers chained on the general exact-fp32 MFMA GEMM (diner_gemm_f32 with
  * its exact flag), one launch per layer, the mean over the views at block `combine_layer`.  The fused field kernels remain the path of
- * the shipped configuration; this one exists so that "same constructor kwargs" is "same behaviour" (forward only; training through it
- * is not built).  `p` holds DEVICE pointers to the parameters as nn.Linear stores them; no packing, no handle.
+ * the shipped configuration; this one exists so that "same constructor kwargs" is "same behaviour" (training through it: the _train_
+ * entry points below, ABI v6).  `p` holds DEVICE pointers to the parameters as nn.Linear stores them; no packing, no handle.
  *   zx   (nv, B, d_latent + d_in) row-major, the latent part first (resnetfc.py:140-142)
  *   out  (B, d_out) when 0 <= combine_layer < n_blocks (views averaged inside the network), else (nv, B, d_out)
  *   workspace: diner_mlp_generic_workspace_bytes(p, nv, B) bytes */
 size_t diner_mlp_generic_workspace_bytes(const DinerMlpParams* p, int nv, long long B);
 int diner_mlp_generic_forward_f32(const DinerMlpParams* p, float beta, const float* zx, int nv, long long B, float* out,
                                   void* workspace, void* stream);
+/* ABI v6: training through the generic path (resnetfc.py:72-159 under torch autograd; e.g. ResnetFC's default d_hidden = 128).  The forward
+ * keeps the pre-activations in `workspace` (diner_mlp_generic_train_workspace_bytes: (2 n_blocks + 1) saved tensors + three temporaries);
+ * the backward chains data / weight / bias gradients, the adjoint of the view mean and -- when d_zx is not NULL -- the gradient with
+ * respect to zx on the same exact-fp32 GEMM.  grads: device buffers of the parameters' shapes (overwritten).  n_blocks <= 64. */
+size_t diner_mlp_generic_train_workspace_bytes(const DinerMlpParams* p, int nv, long long B);
+int diner_mlp_generic_train_forward_f32(const DinerMlpParams* p, float beta, const float* zx, int nv, long long B, float* out,
+                                        void* workspace, void* stream);
+int diner_mlp_generic_backward_f32(const DinerMlpParams* p, const DinerMlpParams* grads, float beta, const float* zx, int nv, long long B,
+                                   const float* d_out, void* workspace, float* d_zx, void* stream);
+/* ... and the adjoint of the bilinear latent lookup of diner_field_inputs_generic_f32 (image_encoder.py:97-146 under autograd): d_latent_cl
+ * (nv, Hf, Wf, C) channels-last, overwritten, from the first C columns of d_zx (nv, P, d_row); points given as xyz / viewdirs (P, 3). */
+int diner_field_inputs_generic_bwd_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P, int d_row,
+                                       const float* d_zx, float* d_latent_cl, void* stream);
 /* The matrix PixelNeRF.forward hands to its MLP (pixelnerf.py:84-128) for any positional encoding / latent width / NV <= 4:
  * zx (nv, P, C + d_in) with d_in = 4 (2 num_freqs + include_input) + 3, rows [latent (bilinear / border) ; poscode(x_c) ; R d ;
  * poscode(depth_nearest - z_c)].  Point source: (rays (NR,8), z (NR,K), K) with P = NR K, or (xyz, viewdirs) (P,3) with rays == NULL. */

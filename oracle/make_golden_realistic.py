@@ -96,15 +96,29 @@ def main():
             oo = O.render(scene, w, rs[sub].contiguous(), K, N_CAND, G, False, ncz[sub], ngz[sub], nfz[sub])
             # how large the activations get: the residual stream and the hidden layers of the oracle's MLP on a slice of the points
             acts = activation_range(scene, w, pts[0][:8192], dirs[0][:8192])
+            # the conditioning yardstick: the same MLP inputs (fp32) through the network in FLOAT64 -- how far fp32 round-off alone moves the
+            # reference's own field values at these magnitudes (variant b: a residual stream of 6e5 in front of a sigmoid)
+            zx = O.mlp_input(scene, pts[0], dirs[0])
+            w64 = O.MLPWeights.from_state_dict(msd)                 # (from_state_dict casts to float32: lift the fields afterwards)
+            for k64, v64 in vars(w64).items():
+                if torch.is_tensor(v64):
+                    setattr(w64, k64, v64.double())
+                elif isinstance(v64, list):
+                    setattr(w64, k64, [t.double() for t in v64])
+            raw64 = O.mlp_forward(w64, zx.double())
+            f64 = torch.cat([torch.sigmoid(raw64[..., :3]), torch.relu(raw64[..., 3:4])], dim=-1)
+            yard_col = float((field[:, :3].double() - f64[:, :3]).abs().max())
+            yard_sig = float((field[:, 3].double() - f64[:, 3]).abs().max() / f64[:, 3].abs().max())
         report(f"g20{tag} z", z_ref[sub], oo["z"], exact=True)
         report(f"g20{tag} rgb", o.fine.rgb[0][sub], oo["rgb"])
         report(f"g20{tag} depth", o.fine.depth[0][sub], oo["depth"])
         print(f"    variant {tag}: latent max {float(lat.max()):.3g} (mean {float(lat.mean()):.3g}), max |w| {max(float(v.abs().max()) for k, v in msd.items() if k.endswith('weight')):.3g}, "
               f"field sigma max {float(field[:, 3].max()):.3g}, rgb range [{float(o.fine.rgb.min()):.3g}, {float(o.fine.rgb.max()):.3g}]"
-              f", residual stream up to {acts[0]:.3g}, hidden activations up to {acts[1]:.3g}")
+              f", residual stream up to {acts[0]:.3g}, hidden activations up to {acts[1]:.3g}; the reference's fp32 field against a float64 evaluation of its MLP: "
+              f"colours {yard_col:.2e} (abs), sigma {yard_sig:.2e} (max-norm-rel)")
         out.update({f"rgb_{tag}": o.fine.rgb[0].numpy(), f"depth_{tag}": o.fine.depth[0].numpy(), f"field_{tag}": field.numpy(),
                     f"weights_sum_{tag}": o.fine.weights[0].sum(-1).numpy(), f"lat_sha_{tag}": sha(lat[:, :8, :4, :4], lat[:, -8:, -4:, -4:]),
-                    f"stream_max_{tag}": acts[0], f"hidden_max_{tag}": acts[1], f"hot_gain_{tag}": hot})
+                    f"yard_col_{tag}": yard_col, f"yard_sig_{tag}": yard_sig, f"stream_max_{tag}": acts[0], f"hidden_max_{tag}": acts[1], f"hot_gain_{tag}": hot})
         if tag == "a":
             out["z"] = z_ref.numpy()
         else:

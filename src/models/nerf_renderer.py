@@ -53,9 +53,12 @@ class NeRFRendererDGS(torch.nn.Module):
         z = z.detach()
         xyz = (r[:, :, None, :3] + z[..., None] * r[:, :, None, 3:6]).reshape(SB, NR * K, 3)
         dirs = r[:, :, None, 3:6].expand(-1, -1, K, -1).reshape(SB, NR * K, 3)
-        scenes = [model.hip_scene(sb) for sb in range(SB)]
-        field = train.field_train_batch(scenes, xyz, dirs, model.encoder.latent, train.mlp_params(model.mlp_fine),
-                                        model.poscode.freq_factor).view(SB * NR, K, 4)
+        if model.is_generic():          # a configuration outside the fused kernels: the generic differentiable path, object by object
+            field = model.forward(xyz, dirs).view(SB * NR, K, 4)
+        else:
+            scenes = [model.hip_scene(sb) for sb in range(SB)]
+            field = train.field_train_batch(scenes, xyz, dirs, model.encoder.latent, train.mlp_params(model.mlp_fine),
+                                            model.poscode.freq_factor).view(SB * NR, K, 4)
         zf, rf = z.reshape(SB * NR, K), r.reshape(SB * NR, 8)
         rgb, depth = train.composite_train(field, zf, rf, self.white_bkgd)
         w = ops.composite(field.detach(), zf, rf, self.white_bkgd, want_weights=True)[0].view(SB, NR, K) if want_weights else None

@@ -98,11 +98,10 @@ class PixelNeRF(torch.nn.Module):
                                             any(p.requires_grad for p in self.mlp_fine.parameters()))
 
     def _check_poscode(self):
-        """The fused kernels (and the training path) are built for poscode num_freqs=6, include_input=True (d_in = 55); other encodings
-        run on the generic path (inference only).  depthcode shares poscode's configuration (pixelnerf.py:15-16)."""
-        if self.is_generic() and self.needs_grad():
-            raise NotImplementedError("diner_amd: training is built for the shipped configuration (d_hidden 512, 5 blocks, combine 3, NV 4, "
-                                      "poscode num_freqs=6 / include_input=True); other configurations are inference-only")
+        """The fused kernels (and the fast training path) are built for poscode num_freqs=6, include_input=True (d_in = 55); other
+        configurations run on the generic path -- since round 6 in grad mode too (diner_amd.train.field_train_generic).  depthcode shares
+        poscode's configuration (pixelnerf.py:15-16)."""
+        return None
 
     def forward(self, xyz, viewdirs):
         """(r, g, b, sigma) at world-space points: xyz (SB,B,3), viewdirs (SB,B,3) -> (SB,B,4) (:55-145)."""
@@ -113,6 +112,10 @@ class PixelNeRF(torch.nn.Module):
             # training: un-fused HIP forward that keeps the activations + HIP backward
             # (diner_amd/train.py); gradients reach the MLP parameters and, through encoder.latent, the image encoder
             from diner_amd import train
+            if self.is_generic():       # any other configuration: exact fp32, one GEMM launch per layer and adjoint
+                pc = self.poscode
+                return torch.stack([train.field_train_generic(self.hip_scene(sb), self.mlp_fine, xyz[sb], viewdirs[sb], self.encoder.latent[sb],
+                                                              pc.num_freqs, pc.include_input, pc.freq_factor) for sb in range(SB)])
             return train.field_train_batch([self.hip_scene(sb) for sb in range(SB)], xyz, viewdirs, self.encoder.latent,
                                            train.mlp_params(self.mlp_fine), self.poscode.freq_factor)
         mlp = self.hip_mlp()

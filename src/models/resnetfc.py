@@ -92,9 +92,16 @@ class ResnetFC(nn.Module):
         (combine_layer >= n_blocks, the constructor's default) the views stay: (SB, NV, B, d_out) / (NV, B, d_out)  (resnetfc.py:129-159)."""
         assert zx.size(-1) == self.d_latent + self.d_in
         if torch.is_grad_enabled() and (zx.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("diner_amd: ResnetFC.forward on an explicit matrix is inference-only; the "
-                                      "differentiable path is PixelNeRF.forward / NeRFRendererDGS.forward "
-                                      "(diner_amd/train.py, DESIGN.md row f1)")
+            # round 6: differentiable for ANY configuration on the generic exact-fp32 path (diner_mlp_generic_train_forward_f32 /
+            # _backward_f32); the fast differentiable path of the shipped configuration is PixelNeRF.forward / NeRFRendererDGS.forward
+            self._check_supported()
+            from diner_amd import train
+            if zx.dim() == 4 and combine_dim in (1, -3):
+                return torch.stack([train.generic_mlp_train(self, zx[i]) for i in range(zx.shape[0])])
+            if zx.dim() == 3 and combine_dim in (0, -3):
+                return train.generic_mlp_train(self, zx)
+            raise NotImplementedError(f"diner_amd: ResnetFC.forward supports (SB,NV,B,C)/combine_dim=1 and (NV,B,C)/combine_dim=0, got shape "
+                                      f"{tuple(zx.shape)}, combine_dim={combine_dim}")
         if zx.dim() == 4 and combine_dim in (1, -3):
             mlp = self.hip_mlp(nv=zx.shape[1])
             run = mlp.forward if isinstance(mlp, ops.GenericMlp) else (lambda m: ops.mlp_forward(mlp, m))

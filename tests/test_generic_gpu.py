@@ -111,9 +111,92 @@ def test_pixelnerf_and_renderer_in_a_non_shipped_configuration():
           f"renderer.forward: {int(same.sum())}/{PIX['NR']} rays with the reference's sample set, rgb {s_rgb:.2e} depth {s_d:.2e}")
     assert e_f < 2e-5 and e_rgb < TOL and e_d < TOL
     assert int(same.sum()) >= PIX["NR"] - 4 and s_rgb < TOL and s_d < TOL
-    # training through a non-shipped configuration is refused, not silently wrong
+    # round 6: training through a non-shipped configuration -- gradients of PixelNeRF.forward with respect to the MLP parameters and the
+    # encoder's latent against torch autograd through the CPU oracle (the restatement covers this configuration bit-exactly, test_oracle_golden)
+    from oracle import diner_oracle as O
+    from tests.tests_train_util import oracle_key
     nerf.train()
     for p in nerf.mlp_fine.parameters():
         p.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        nerf(xyz[None].cuda(), viewdirs=dirs[None].cuda())
+    nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+    Gm = torch.randn(xyz.shape[0], 4, generator=torch.Generator().manual_seed(3))
+    out = nerf(xyz[None].cuda(), viewdirs=dirs[None].cuda())
+    assert out.requires_grad and max_norm_rel(out[0].detach().cpu(), g["pix_field"]) < 2e-5
+    (out[0] * Gm.cuda()).sum().backward()
+    Kin = sc["src_intrinsics"]
+    lat = sc["latent"].clone().requires_grad_(True)
+    scene = O.Scene(latent=lat, depths=sc["depths"], depths_std=sc["depths_std"], normals=sc["normals"], poses=sc["src_extrinsics"],
+                    focal=Kin[:, [0, 1], [0, 1]], c=Kin[:, :2, -1], image_shape=sc["image_shape"], feature_padding=sc["feature_padding"])
+    w = O.MLPWeights.from_state_dict(msd, combine_layer=PIX["mlp"]["combine_layer"], d_latent=PIX["latent_ch"])
+    leaves = {}
+    for k, v in vars(w).items():
+        for i, t in enumerate(v if isinstance(v, (list, tuple)) else [v]):
+            if torch.is_tensor(t) and t.is_floating_point():
+                leaves[(k, i if isinstance(v, (list, tuple)) else None)] = t.requires_grad_(True)
+    raw = O.mlp_forward(w, O.mlp_input(scene, xyz, dirs, PIX["num_freqs"], PIX["freq_factor"]))
+    f = torch.cat([torch.sigmoid(raw[..., :3]), torch.relu(raw[..., 3:4])], dim=-1)
+    (f * Gm).sum().backward()
+    worst = max(((n, max_norm_rel(p.grad.cpu(), leaves[oracle_key(n)].grad)) for n, p in nerf.mlp_fine.named_parameters()), key=lambda t: t[1])
+    e_lat = max_norm_rel(nerf.encoder.latent.grad[0].cpu(), lat.grad)
+    print(f"generic PixelNeRF in grad mode: worst parameter gradient {worst[0]} {worst[1]:.2e}, d latent {e_lat:.2e} (max-norm-rel against the oracle's autograd)")
+    assert worst[1] < TOL and e_lat < TOL
+    # ... and through the renderer (sampler + field + compositor nodes): finite gradients on every parameter and the latent
+    for p in nerf.mlp_fine.parameters():
+        p.grad = None
+    nerf.encoder.latent.grad = None
+    with noise.inject(*(t.cuda()[None] for t in nz)):
+        o2 = ren.forward(nerf, rc)
+    o2.fine.rgb.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in nerf.mlp_fine.parameters())
+    assert torch.isfinite(nerf.encoder.latent.grad).all() and float(nerf.encoder.latent.grad.abs().max()) > 0
+
+
+def _ref_resnetfc64(zx, sd, kw):
+    """float64 torch restatement of ResnetFC.forward (resnetfc.py:129-159) for the gradient check: ReLU or Softplus(beta), mean over the views
+    at combine_layer, lin_z on the blocks in front of it."""
+    import torch.nn.functional as F
+    full = dict(d_in=0, d_out=4, n_blocks=5, d_latent=0, d_hidden=128, combine_layer=1000, beta=0.0)
+    full.update(kw)
+    act = (lambda t: F.softplus(t, beta=full["beta"])) if full["beta"] > 0 else torch.relu
+    z, x_in = zx[..., :full["d_latent"]], zx[..., full["d_latent"]:]
+    x = F.linear(x_in, sd["lin_in.weight"], sd["lin_in.bias"]) if full["d_in"] > 0 else torch.zeros(*zx.shape[:-1], full["d_hidden"], dtype=zx.dtype)
+    for b in range(full["n_blocks"]):
+        if b == full["combine_layer"]:
+            x = x.mean(0)
+        if full["d_latent"] > 0 and b < full["combine_layer"]:
+            x = x + F.linear(z, sd[f"lin_z.{b}.weight"], sd[f"lin_z.{b}.bias"])
+        net = F.linear(act(x), sd[f"blocks.{b}.fc_0.weight"], sd[f"blocks.{b}.fc_0.bias"])
+        x = x + F.linear(act(net), sd[f"blocks.{b}.fc_1.weight"], sd[f"blocks.{b}.fc_1.bias"])
+    return F.linear(act(x), sd["lin_out.weight"], sd["lin_out.bias"])
+
+
+@pytest.mark.parametrize("name", sorted(MLP_CASES))
+def test_resnetfc_any_configuration_trains(name):
+    """Round 6: ResnetFC.forward in grad mode for any configuration -- the constructor DEFAULTS (d_hidden 128, no view fusion),
+    the reduced variant with a combine layer and three views, Softplus -- gradients of every parameter and of the input matrix against float64
+    torch autograd of a restatement of resnetfc.py:129-159 (diner_mlp_generic_train_forward_f32 / _backward_f32: exact-fp32 GEMMs)."""
+    from src.models.resnetfc import ResnetFC
+    kw, nv, SB, B, seed = MLP_CASES[name]
+    sd = mlp_state_dict(kw, seed)
+    m = ResnetFC(**kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    zx = mlp_inputs(kw, nv, SB, B, seed)
+    zg = zx.cuda().requires_grad_(True)
+    y = m(zg, combine_dim=1)
+    with torch.no_grad():
+        m.eval()
+        y_inf = m(zx.cuda(), combine_dim=1)
+        m.train()
+    assert max_norm_rel(y.detach().cpu(), y_inf.cpu()) < 1e-6            # the training forward is the inference forward
+    Gm = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 7))
+    (y * Gm.cuda()).sum().backward()
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    z64 = zx.double().requires_grad_(True)
+    y64 = torch.stack([_ref_resnetfc64(z64[i], sd64, kw) for i in range(SB)])
+    assert max_norm_rel(y.detach().cpu(), y64.detach().float()) < 2e-5
+    (y64 * Gm.double()).sum().backward()
+    worst = max(((k, max_norm_rel(p.grad.cpu(), sd64[k].grad.float())) for k, p in m.named_parameters()), key=lambda t: t[1])
+    e_z = max_norm_rel(zg.grad.cpu(), z64.grad.float())
+    print(f"ResnetFC case {name} in grad mode: worst parameter gradient {worst[0]} {worst[1]:.2e}, d zx {e_z:.2e} (max-norm-rel against float64 autograd)")
+    assert worst[1] < TOL and e_z < TOL

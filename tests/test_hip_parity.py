@@ -946,7 +946,12 @@ def test_realistic_magnitudes_g20(ops, precision, variant):
     print(f"G20 {variant} [{precision}]: field sigma {e_sig:.2e} (max-norm-rel, sigma up to {float(ref_f[..., 3].max()):.3g}), colours {e_col:.2e} (abs), "
           f"rgb {e_rgb:.2e}, depth {e_d:.2e} on {int(ok.sum())} rays ({n_bad} rays non-finite in the reference itself); fall-back launches {fb}; "
           f"reference activations: residual stream up to {float(g[f'stream_max_{variant}']):.3g}, hidden up to {float(g[f'hidden_max_{variant}']):.3g}")
-    assert e_sig < TOL and e_col < TOL and e_rgb < TOL and e_d < TOL
+    # The bar: 1e-4 -- except where fp32 itself cannot deliver it: the fixture carries the distance between the REFERENCE's fp32 field and a
+    # float64 evaluation of the same network on the same inputs (variant a: colours 7.7e-5, variant b: 1.3e-3 -- a residual stream of 6e5 in
+    # front of a sigmoid); a second fp32 implementation (another summation order) is held to 3 x that yardstick where it exceeds 1e-4.
+    tol_col = max(TOL, 3.0 * float(g[f"yard_col_{variant}"]))
+    print(f"    colour tolerance {tol_col:.2e} (the reference's own fp32-vs-float64 distance: {float(g[f'yard_col_{variant}']):.2e})")
+    assert e_sig < TOL and e_d < TOL and e_col < tol_col and e_rgb < tol_col
     assert n_bad <= 4
     np.testing.assert_allclose(wts.cpu().sum(-1)[ok].numpy(), g[f"weights_sum_{variant}"][ok.numpy()], rtol=1e-4, atol=3e-5)
     if precision == "f16x3":

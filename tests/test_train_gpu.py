@@ -573,6 +573,24 @@ def test_training_step_two_objects_patch_of_rays(ops, monkeypatch, batched):
     Gm = torch.randn(SB, NR, 3, generator=gen)
     (out.fine.rgb * Gm.cuda()).sum().backward()
     assert nerf.encoder.latent.grad.shape == nerf.encoder.latent.shape
+    if not batched:
+        # one call pair per object (round 5's path, still what mismatched scenes and DINER_TRAIN_BATCH=0 take): the same step as one node must
+        # give the same colours bit for bit and the same gradients to summation order -- the oracle comparison below runs on the batched case
+        g_obj = {k: p.grad.clone() for k, p in nerf.mlp_fine.named_parameters()}
+        l_obj, rgb_obj = nerf.encoder.latent.grad.clone(), out.fine.rgb.detach().clone()
+        for p in nerf.mlp_fine.parameters():
+            p.grad = None
+        nerf.encoder.latent.grad = None
+        monkeypatch.setenv("DINER_TRAIN_BATCH", "1")
+        with noise.inject(*inj):
+            out_b = ren.forward(nerf, r)
+        assert len(_field_nodes(out_b.fine.rgb)) == 1 and torch.equal(out_b.fine.rgb.detach(), rgb_obj)
+        (out_b.fine.rgb * Gm.cuda()).sum().backward()
+        worst = max(max_norm_rel(p.grad.cpu(), g_obj[k].cpu()) for k, p in nerf.mlp_fine.named_parameters())
+        e_l = max_norm_rel(nerf.encoder.latent.grad.cpu(), l_obj.cpu())
+        print(f"SB=2: one node per object against one node for the objects: parameter gradients {worst:.2e}, d latent {e_l:.2e}, rgb bit-equal")
+        assert worst < 1e-5 and e_l < 1e-5
+        return
 
     def oracle(cond):
         w = O.MLPWeights.from_state_dict(msd)
