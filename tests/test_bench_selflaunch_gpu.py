@@ -56,7 +56,7 @@ def test_bench_launches_its_own_ranks(n):
 def test_single_rank_line_names_no_collective():
     """N = 1: no process group, the parallelism string says so; --check-frame emulates the 8-way shard in one process."""
     rc, out, err = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--width", "200", "--height", "152", "--no-modes", "--no-configs",
-                         "--cpu-rays", "0", "--check-frame"])
+                         "--cpu-rays", "0", "--check-frame", "--no-train", "--no-encode", "--no-power"])
     assert rc == 0, err[-3000:]
     line = json.loads(out.strip().splitlines()[-1])
     assert line["backend"] is None and line["dist"] is None

@@ -369,6 +369,24 @@ def test_bench_line_contract():
     assert abs(line["value"] - line["config"]["rays_per_step"] / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
     # CPU baseline as SURVEY.md section 8d specifies it: >= 4096 rays, warm-up at size, >= 3 timed repeats, threads stated
     assert len(c["repeats_s"]) >= 3 and "4096 rays" in c["sample"] and c["host_threads"] >= c["cores"]
+    if "train" in line:      # round 6: the line proves what it ran (VERDICT r5 #1a, #2)
+        assert line["fallback_launches"] == 0, "the headline number is the exact-fp32 pass's, not the mode's it names"
+        for e in list(line["modes"].values()) + list(line["configs"].values()):
+            assert e["fallback_launches"] == 0
+        en = line["energy"]
+        assert set(("power_w", "sclk_mhz", "joule_per_mray", "power_samples")) <= set(en)
+        if en["power_w"] is not None:
+            assert 200 < en["power_w"] < 1500 and abs(en["joule_per_mray"] - en["power_w"] * line["ms_per_step"] * 1e-3 * line["steps"] /
+                                                      (line["config"]["rays_per_step"] * line["steps"] / 1e6)) < 0.02 * en["joule_per_mray"]
+        enc = line["encode"]
+        assert enc["encode_ms"] > 0 and abs(enc["encode_ms"] - (enc["trunk_and_prep_ms"] + enc["relayout_ms"] + enc["hoist_ms"])) < 0.01
+        t = line["train"]
+        assert t["steps"] >= 5 and len(t["ms_all"]) == t["steps"] and t["batched"] is True
+        assert t["config"]["objects"] == 4 and t["config"]["rays_per_object"] == 4096 and t["config"]["samples_per_ray"] == 40
+        assert t["host_enqueue_ms"] <= 10.0, "the training step waits for the host again"
+        assert abs(t["rays_per_s"] - 4 * 4096 / (t["ms_per_step"] * 1e-3)) < 0.01 * t["rays_per_s"]
+        assert abs(t["frac"] - t["mfma_issued_tflops"] / 2500.0) < 1e-3 and 0 < t["frac"] < 1
+        assert c["host_cores"] is None or c["host_cores"] <= c["host_threads"]
 
 
 def test_png_writer_roundtrip(tmp_path):
