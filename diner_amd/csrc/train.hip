@@ -542,32 +542,39 @@ __global__ __launch_bounds__(256) void k_scatter_latent(const float* __restrict_
 // block of d_lat into LDS, (3) per distinct texel sums w * d_lat over that texel's taps -- a thread owns two channels, independent LDS
 // reads, no read-modify-write chain (a first version accumulated into a (slot, channel) table in LDS: one dependent LDS round trip per tap)
 // -- and adds the sum to the texel with one atomic per channel.
-constexpr int kScatCols = 64;
+// round 6: COLS columns per workgroup as a template parameter -- 64 columns stage 128 KB of d_lat in LDS, i.e. ONE workgroup per CU whose
+// load, sort and atomic phases nothing overlaps (1.7 ms per object at 4096 rays x 40 samples, 1.25 TB/s); 32 / 16 columns let 2 / 4 workgroups
+// share a CU (DINER_TRAIN_SCATTER_COLS, default below; consecutive columns are samples along one ray, so the texel merge still finds its
+// duplicates within 16-32 columns).
 typedef float f32x2s __attribute__((ext_vector_type(2)));
+template <int COLS>
 __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __restrict__ d_lat, const int* __restrict__ tap_row,
                                                                const float* __restrict__ tap_w, long long cols,
                                                                float* __restrict__ d_latent_cl) {
+  constexpr int NT = 4 * COLS;                                                    // taps of the workgroup (threads 0 .. NT - 1 own one each)
   extern __shared__ __attribute__((aligned(16))) char smem_scat[];
-  f32x2s* dl = reinterpret_cast<f32x2s*>(smem_scat);                             // [kScatCols][256] pairs of channels
-  __shared__ int s_id[256], s_uniq[256], s_start[257], s_fill[256], s_wave_n[4];
-  __shared__ float s_w[256], s_tw[256];
-  __shared__ short s_lead_slot[256];
-  __shared__ unsigned char s_tcol[256];
+  f32x2s* dl = reinterpret_cast<f32x2s*>(smem_scat);                             // [COLS][256] pairs of channels
+  __shared__ int s_id[NT], s_uniq[NT], s_start[NT + 1], s_fill[NT], s_wave_n[4];
+  __shared__ float s_w[NT], s_tw[NT];
+  __shared__ short s_lead_slot[NT];
+  __shared__ unsigned char s_tcol[NT];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const long long col0 = (long long)blockIdx.x * kScatCols;
+  const long long col0 = (long long)blockIdx.x * COLS;
   const long long mycol = col0 + (t >> 2);
   int id = -1;
   float w = 0.0f;
-  if (mycol < cols) {
+  if (t < NT && mycol < cols) {
     id = tap_row[mycol * 4 + (t & 3)];
     w = tap_w[mycol * 4 + (t & 3)];
     if (w == 0.0f) id = -1;
   }
-  s_id[t] = id;
-  s_w[t] = w;
-  s_fill[t] = 0;
-  // (2) the block of d_lat, 64 rows of 2 KB (rows past the end: never referenced)
-  const long long last = cols - col0 < kScatCols ? cols - col0 : kScatCols;
+  if (t < NT) {
+    s_id[t] = id;
+    s_w[t] = w;
+    s_fill[t] = 0;
+  }
+  // (2) the block of d_lat, COLS rows of 2 KB (rows past the end: never referenced)
+  const long long last = cols - col0 < COLS ? cols - col0 : COLS;
   for (int g = 0; g < (int)last; ++g)
     dl[g * 256 + t] = *reinterpret_cast<const f32x2s*>(d_lat + (size_t)(col0 + g) * kLatent + 2 * t);
   __syncthreads();
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   const int slot = id >= 0 ? (int)s_lead_slot[leader] : -1;
   if (slot >= 0) atomicAdd(&s_fill[slot], 1);               // taps per texel
   __syncthreads();
-  if (t == 0) {                                              // exclusive prefix over <= 256 counts (a few hundred cycles once per workgroup)
+  if (t == 0) {                                              // exclusive prefix over <= NT counts (a few hundred cycles once per workgroup)
     int run = 0;
     for (int i = 0; i < n_unique; ++i) {
       s_start[i] = run;
@@ -622,23 +629,30 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
     atomicAdd(dst + 1, a[1]);
   }
 }
+template <int COLS>
+static int scatter_merged_launch(const float* d_lat, const int* tap_row, const float* tap_w, long long cols, float* d_latent_cl, hipStream_t st) {
+  static std::atomic<int> attr_set[64];
+  int dev = 0;
+  DINER_HIP_OK(hipGetDevice(&dev));
+  dev &= 63;
+  constexpr int lds = COLS * 256 * (int)sizeof(f32x2s);      // the COLS x 512 block of d_lat
+  if (!attr_set[dev].load()) {
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_scatter_latent_merged<COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set[dev].store(1);
+  }
+  hipLaunchKernelGGL(k_scatter_latent_merged<COLS>, dim3((unsigned)((cols + COLS - 1) / COLS)), dim3(256), lds, st, d_lat, tap_row, tap_w, cols, d_latent_cl);
+  DINER_LAUNCH_OK();
+  return 0;
+}
 int scatter_latent_launch(const float* d_lat, const int* tap_row, const float* tap_w, long long cols, float* d_latent_cl, hipStream_t st) {
   static const bool merged = [] { const char* e = getenv("DINER_TRAIN_SCATTER_MERGED"); return !(e && *e == '0'); }();
+  static const int ncols = [] { const char* e = getenv("DINER_TRAIN_SCATTER_COLS"); return e ? atoi(e) : 32; }();      // same-box A/B 64 / 32 / 16: 123.6 / 121.9 / 122.2 ms per SB 4 step (profiles/r06_train_scatter_cols_ab.txt)
   if (merged && (reinterpret_cast<size_t>(d_lat) & 7) == 0) {
-    static std::atomic<int> attr_set[64];
-    int dev = 0;
-    DINER_HIP_OK(hipGetDevice(&dev));
-    dev &= 63;
-    constexpr int lds = kScatCols * 256 * (int)sizeof(f32x2s);      // the 64 x 512 block of d_lat: 128 KB
-    if (!attr_set[dev].load()) {
-      DINER_HIP_OK(hipFuncSetAttribute((const void*)k_scatter_latent_merged, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr_set[dev].store(1);
-    }
-    hipLaunchKernelGGL(k_scatter_latent_merged, dim3((unsigned)((cols + kScatCols - 1) / kScatCols)), dim3(256), lds, st, d_lat, tap_row,
-                       tap_w, cols, d_latent_cl);
-  } else {
-    hipLaunchKernelGGL(k_scatter_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, d_lat, tap_row, tap_w, cols, d_latent_cl);
+    if (ncols == 16) return scatter_merged_launch<16>(d_lat, tap_row, tap_w, cols, d_latent_cl, st);
+    if (ncols == 32) return scatter_merged_launch<32>(d_lat, tap_row, tap_w, cols, d_latent_cl, st);
+    return scatter_merged_launch<64>(d_lat, tap_row, tap_w, cols, d_latent_cl, st);
   }
+  hipLaunchKernelGGL(k_scatter_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, d_lat, tap_row, tap_w, cols, d_latent_cl);
   DINER_LAUNCH_OK();
   return 0;
 }
