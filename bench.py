@@ -799,6 +799,11 @@ def main():
                          f"{times[-1]:.1f}); {best} of {hw} hardware threads = fastest of the sweep {sweep} (rays/s on 256 rays)",
                "repeats_s": [round(t, 2) for t in times], "thread_sweep_rays_per_s": sweep, "host_threads": hw,
                "host_cores": host_physical_cores()[0], "torch_threads_used": best,
+               "oracle_over_reference": 1.415,
+               "oracle_over_reference_note": "throughput of this restatement / throughput of the IMPORTED reference on the same 1024 rays in the build "
+                                             "container (8 threads, 5 alternating repeats, outputs bit-equal: medians 74.2 / 52.4 rays/s; oracle/"
+                                             "time_vs_reference.py, profiles/r06_cpu_oracle_vs_reference_timing.txt): the reference's own CPU path is "
+                                             "~1.4x SLOWER than `value`, i.e. the baseline flatters the CPU",
                "cores_note": "`cores` = torch intra-op threads of the fastest setting of the sweep (what was actually used); `host_cores` = physical "
                              "cores of the box (distinct thread-sibling sets), `host_threads` = hardware threads"}
 

@@ -8,9 +8,9 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${1:-r02}; shift
 ARGS="$@"
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-modes --no-configs $ARGS > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-modes --no-configs --no-train --no-encode --no-power $ARGS > $OUT/bench_stats.log 2>&1
 grep '"metric"' $OUT/bench_stats.log > $OUT/bench_line.json
-CMD="python bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-modes --no-configs $ARGS"
+CMD="python bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-modes --no-configs --no-train --no-encode --no-power $ARGS"
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$n -o pmc -- $CMD > $OUT/pmc_$n.log 2>&1
