@@ -1607,8 +1607,15 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
       float* t = dx; dx = dH; dH = t;
     }
   }
-  if ((rc = linear_bwd(dx, kHidden, ws + w.feat, kDInPad, false, p->lin_in_w, (float*)grads->lin_in_w,
-                       (float*)grads->lin_in_b, cols, kHidden, kDIn, nullptr, nullptr, false, st))) return rc;
+  // lin_in's weight / bias gradient: round 6 on a kernel of its own in the f16x3 arithmetic (dy scaled from its maximum; the encoded inputs are
+  // O(1): no range flag needed) -- DINER_TRAIN_WGRAD_IN=0: the general bf16x6 product (A/B measurement)
+  static const bool wgrad_in_on = [] { const char* e = getenv("DINER_TRAIN_WGRAD_IN"); return !(e && *e == '0'); }();
+  if (bwd16 && wgrad_in_on && cols >= 4096 && (reinterpret_cast<size_t>(dx) & 15) == 0) {
+    DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_in_w, 0, (size_t)kHidden * kDIn * sizeof(float), st));
+    DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_in_b, 0, (size_t)kHidden * sizeof(float), st));
+    if ((rc = wgrad_in_launch(dx, kHidden, ws + w.feat, kDInPad, kDIn, cols, (float*)grads->lin_in_w, (float*)grads->lin_in_b, amax + a_cur, st))) return rc;
+  } else if ((rc = linear_bwd(dx, kHidden, ws + w.feat, kDInPad, false, p->lin_in_w, (float*)grads->lin_in_w,
+                              (float*)grads->lin_in_b, cols, kHidden, kDIn, nullptr, nullptr, false, st))) return rc;
   {   // (a job the general kernel served -- fewer than 256 rows, odd strides -- stays empty: dropped)
     int n = 0;
     for (int i = 0; i < n_jobs; ++i)

@@ -100,6 +100,7 @@ int device_cus(int* cus) {                                   // per device: dyna
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_run512_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad512_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_dgrad512_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad_in_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesWgradIn));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(c > 1 ? c & ~1 : 256);
@@ -192,6 +193,23 @@ int plan_wgrad512(const float* dY, int ldy, const float* X, int ldx, bool relu_x
   return (wide ? 4 : 8) * (int)(n_chunks <= 8 ? 8 : n_chunks);   // the block -> (tile, chunk) map needs whole groups of 8 chunks
 }
 }  // namespace
+
+int wgrad_in_launch(const float* dY, int ldy, const float* F, int ldf, int n_in, long long M, float* dW, float* db, const unsigned* amax_dy,
+                    hipStream_t stream) {
+  DINER_CHECK_ARG(dY && F && dW && M > 0 && n_in > 0 && n_in <= 64 && ldf >= 64 && ldy >= 512 && (ldy & 3) == 0 &&
+                  (reinterpret_cast<size_t>(dY) & 15) == 0 && (reinterpret_cast<size_t>(F) & 3) == 0, "wgrad_in: bad arguments");
+  int cus = 0;
+  int rc = device_cus(&cus);
+  if (rc) return rc;
+  long long chunks = cus;
+  while (chunks > 1 && (M + chunks - 1) / chunks < 64) chunks >>= 1;
+  long long rows = (M + chunks - 1) / chunks;
+  rows = (rows + 31) / 32 * 32;
+  const WgradInArgs a{dY, F, dW, db, M, rows, ldy, ldf, n_in, amax_dy};
+  hipLaunchKernelGGL(k_wgrad_in_f16x3, dim3((unsigned)((M + rows - 1) / rows)), dim3(512), kLdsBytesWgradIn, stream, a);
+  DINER_LAUNCH_OK();
+  return 0;
+}
 
 int lin512_launch(const Lin512Args& a, hipStream_t stream, int arith) {
   int cus = 0;

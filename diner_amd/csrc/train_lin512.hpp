@@ -62,6 +62,10 @@ int wgrad512_launch(const float* dY, int ldy, const float* X, int ldx, bool relu
                     hipStream_t stream, float* part = nullptr, bool overwrite = false, WgReduceJob* defer = nullptr,
                     const Lin512Args* dgrad = nullptr,       // dgrad: the data-gradient product of the same layer in the same launch
                     const WgradArith* ar = nullptr);
+// round 6: lin_in's weight / bias gradient on a kernel of its own (train_wgrad512.hip: k_wgrad_in_f16x3): dW (512, n_in <= 64) += dY^T F, db (512) +=
+// column sums of dY over M rows; dW / db zeroed by the caller; dY staged times the power of two from *amax_dy (null: unscaled)
+int wgrad_in_launch(const float* dY, int ldy, const float* F, int ldf, int n_in, long long M, float* dW, float* db, const unsigned* amax_dy,
+                    hipStream_t stream);
 int wgrad512_reduce_many(const WgReduceJobs& jobs, int n, bool overwrite, hipStream_t stream);
 size_t wgrad512_part_bytes();
 

@@ -690,5 +690,172 @@ int wgrad512_reduce_many(const WgReduceJobs& jobs, int n, bool overwrite, hipStr
 
 size_t wgrad512_part_bytes() { return (size_t)kWgMaxChunks * (512 * 512 + 512) * sizeof(float); }
 
+
+// ---- round 6: lin_in's weight / bias gradient, dW (512, 55) = dy^T feat, db = column sums of dy, over the step's 2.6 M per-view rows -----------
+// The general bf16x6 GEMM served this product with 128 x 128 tiles of which half the columns are padding and four N-tiles that each re-read
+// the encoded inputs: 3.1 ms per SB 4 x 4096 x 40 step at 2 TB/s for 6 GB of operands (profiles/r06_train_batched_kernel_stats.md).  Here: one
+// persistent workgroup per row chunk, eight waves (two per SIMD); wave w owns features [64 w, 64 w + 64) x all 64 (padded) inputs = 4
+// accumulator tiles; per 32-row slab every wave stages its 64 columns of dy (fp32 -> fp16 hi / lo of dy * 2^(14 - E), as wgrad512_body_w8)
+// and 8 columns of feat (encoded inputs: |x| of a few units, no scaling); 24 MFMAs per wave and slab -- HBM-bound by a wide margin (72 KB per
+// slab and CU for 1.5 k MFMA clocks).  Partial products go to dW / db with float atomics (both zeroed by the caller).
+struct WgradInArgs {
+  const float* dY;       // (M, ldy) gradient of lin_in's output
+  const float* F;        // (M, ldf >= 64) encoded inputs, columns >= n_in ignored
+  float* dW;             // (512, n_in) row-major, += (zeroed by the caller)
+  float* db;             // (512), +=
+  long long M, rows_per_chunk;
+  int ldy, ldf, n_in;
+  const unsigned* amax_dy;
+};
+constexpr int kWgInFrags = (16 + 2) * 2;                        // 1 KB fragments per k16 step: 16 feature tiles of dy + 2 input tiles, two planes each
+constexpr int kWgInSlab = 2 * kWgInFrags * 1024;                // 72 KB per slab buffer
+constexpr size_t kLdsBytesWgradIn = (size_t)2 * kWgInSlab;      // 144 KB
+
+__global__ __launch_bounds__(512, 1) void k_wgrad_in_f16x3(WgradInArgs a) {
+  float sy = 1.0f, inv_sy = 1.0f;
+  if (a.amax_dy) {
+    const unsigned e = (*a.amax_dy >> 23) & 0xffu;
+    if (e >= 32u && e < 255u) {
+      sy = __uint_as_float((268u - e) << 23);
+      inv_sy = __uint_as_float((e - 14u) << 23);
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  typedef __attribute__((address_space(3))) bf8w* lds_bf8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long long m_begin = (long long)blockIdx.x * a.rows_per_chunk;
+  long long m_end = m_begin + a.rows_per_chunk;
+  if (m_end > a.M) m_end = a.M;
+  if (m_begin >= a.M) return;
+  const int n_slabs = (int)((m_end - m_begin + 31) / 32);
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 vr[8];                                               // dy: rows 8 g .. 8 g + 7 of the lane's 4 columns (64 w + 4 li ..)
+  float vf[8];                                               // feat: the same rows of column 8 w + li (lanes li < 8)
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dY + (size_t)m_begin * a.ldy), 0,
+                                                                        (int)((m_end - m_begin) * (long long)a.ldy * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F + (size_t)m_begin * a.ldf), 0,
+                                                                        (int)((m_end - m_begin) * (long long)a.ldf * 4), 0x00020000);
+  const unsigned voff_y = (unsigned)(8 * g) * (unsigned)a.ldy * 4u + (unsigned)(64 * wave + 4 * li) * 4u;
+  const unsigned voff_f = (unsigned)(8 * g) * (unsigned)a.ldf * 4u + (unsigned)(8 * wave + (li & 7)) * 4u;
+  auto request = [&](long long m0) {
+    const unsigned row0 = (unsigned)(m0 - m_begin);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      vr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, voff_y, (row0 + j) * (unsigned)a.ldy * 4u, 0));
+      vf[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff_f, (row0 + j) * (unsigned)a.ldf * 4u, 0));
+    }
+  };
+  // where the lane's values go: step s = g / 2, row half g % 2; dy column i of the lane: feature 64 w + 4 li + i -> tile 2 w + li / 8, fragment
+  // lane 4 (li % 8) + i + 32 half; 16-byte slots swizzled inside every fragment as in wgrad512_body_w8 (slot L at L ^ ((L >> 3) & 3))
+  lds_ptr sbase = (lds_ptr)smem + (g >> 1) * (kWgInFrags * 1024) + (32 * (g & 1)) * 16;
+  const int slot_y = ((2 * wave + (li >> 3)) * 2) * 1024 + (4 * (li & 7)) * 16;
+  const int sw16 = ((li >> 1) & 3) * 16;
+  // feat column 8 w + li (li < 8): tile (8 w + li) / 32 = w / 4, fragment lane 8 (w % 4) + li + 32 half, swizzle ((L >> 3) & 3) = w % 4
+  const int slot_f = ((16 + (wave >> 2)) * 2) * 1024 + (((8 * (wave & 3) + (li & 7)) ^ (wave & 3)) * 16);
+  float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4w sp0, sp1;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = vr[4 * half + j][i];
+        rs[i] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= sy;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned h = cvt_pk_f16_w(v[2 * j], v[2 * j + 1]);
+          sp0[2 * half + j] = h;
+          sp1[2 * half + j] = cvt_pk_f16_w(resid_lo_w(h, v[2 * j]), resid_hi_w(h, v[2 * j + 1]));
+        }
+      }
+      lds_ptr d = sbase + buf * kWgInSlab + slot_y + ((i * 16) ^ sw16);
+      *(lds_bf8)(d) = __builtin_bit_cast(bf8w, sp0);
+      *(lds_bf8)(d + 1024) = __builtin_bit_cast(bf8w, sp1);
+    }
+    if (li < 8) {
+      u32x4w sp0, sp1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned h = cvt_pk_f16_w(vf[2 * j], vf[2 * j + 1]);
+        sp0[j] = h;
+        sp1[j] = cvt_pk_f16_w(resid_lo_w(h, vf[2 * j]), resid_hi_w(h, vf[2 * j + 1]));
+      }
+      lds_ptr d = sbase + buf * kWgInSlab + slot_f;
+      *(lds_bf8)(d) = __builtin_bit_cast(bf8w, sp0);
+      *(lds_bf8)(d + 1024) = __builtin_bit_cast(bf8w, sp1);
+    }
+  };
+  request(m_begin);
+  stash(0);
+  request(m_begin + 32);                                     // (past the chunk: zeros)
+  __syncthreads();
+  f32x16w acc[2][2];
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[fi][kt][e] = 0.0f;
+  lds_ptr lbase = (lds_ptr)smem + (lane ^ ((lane >> 3) & 3)) * 16;
+#pragma nounroll
+  for (int slab = 0; slab < n_slabs; ++slab) {
+    const int buf = slab & 1;
+    lds_ptr rb = lbase + buf * kWgInSlab;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf8w af[2][2], bfr[2][2];
+#pragma unroll
+      for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[fi][pl] = *(lds_bf8)(rb + (s * kWgInFrags + (2 * wave + fi) * 2 + pl) * 1024);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) bfr[kt][pl] = *(lds_bf8)(rb + (s * kWgInFrags + (16 + kt) * 2 + pl) * 1024);
+#pragma unroll
+      for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          DINER_WG_MFMA_F16(acc[fi][kt], af[fi][1], bfr[kt][0]);       // smallest terms first
+          DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], bfr[kt][1]);
+          DINER_WG_MFMA_F16(acc[fi][kt], af[fi][0], bfr[kt][0]);
+        }
+    }
+    stash(buf ^ 1);                                          // the next slab (requested one slab ago) into the other buffer
+    request(m_begin + 32ll * (slab + 2));
+    __syncthreads();
+  }
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int k = 32 * kt + (lane & 31);
+      if (k >= a.n_in) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int f = 64 * wave + 32 * fi + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        atomicAdd(a.dW + (size_t)f * a.n_in + k, acc[fi][kt][e] * inv_sy);
+      }
+    }
+  if (a.db) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      rs[c] += __shfl_xor(rs[c], 16);
+      rs[c] += __shfl_xor(rs[c], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) atomicAdd(a.db + 64 * wave + 4 * li + c, rs[c]);
+    }
+  }
+}
+
 }  // namespace train
 }  // namespace diner
