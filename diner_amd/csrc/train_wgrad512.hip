@@ -469,6 +469,9 @@ __device__ __forceinline__ void wgrad512_body_wide(const Wgrad512Args& a, const 
 // operand (columns [64 w, +64) of the tile's k range), waves 4..7 the dy operand (columns [64 (w - 4), +64) of its f range) -- the lane
 // mapping, the LDS layout (64 KB slabs, two buffers) and the partial-tile layout of wgrad512_body_wide; 32 values per thread and slab for
 // 48 MFMAs.  Its own kernel (k_wgrad512_w8: 512 threads); the data gradient of the layer is the launch in front of it.
+#ifdef DINER_L512_PROF
+__device__ unsigned long long g_wg_prof[8];      // wgrad512_body_w8: [0] clocks per wave, [1] slab sections, [2] slab barriers, [3] slabs, [4] waves
+#endif
 __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const int bid) {
   constexpr int NP = 2, kFrags = 16 * NP, kSlab = 2 * kFrags * 1024;
   if (a.gate && *a.gate == 0) return;
@@ -550,6 +553,10 @@ __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const in
   for (int j = 0; j < 8; ++j) request(j, m_begin + 32);      // (past the chunk: zeros)
   __syncthreads();
 
+#ifdef DINER_L512_PROF
+  unsigned long long pw_mf = 0, pw_bar = 0;
+  const unsigned long long pw_t0 = __builtin_readcyclecounter();
+#endif
   const int wf = wave >> 2, wk = wave & 3;                    // this wave's 128 f x 64 k part of the tile
   f32x16w acc[4][2];
 #pragma unroll
@@ -561,6 +568,9 @@ __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const in
   lds_ptr lbase = (lds_ptr)smem + (lane ^ ((lane >> 3) & 3)) * 16;      // (the swizzled slot of fragment lane `lane`)
 #pragma nounroll
   for (int slab = 0; slab < n_slabs; ++slab) {
+#ifdef DINER_L512_PROF
+    const unsigned long long pw_a = __builtin_readcyclecounter();
+#endif
     const int buf = slab & 1;
     const long long m_next2 = m_begin + 32ll * (slab + 2);
     lds_ptr rb = lbase + buf * kSlab;
@@ -581,6 +591,8 @@ __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const in
         constexpr int u = s * 8 + gi;                        // 16 groups of 3 MFMAs per slab
         __builtin_amdgcn_sched_barrier(0);
         // staging side task: the next slab's four lane-fragment columns, each in two halves, groups 1..8; requests re-armed in group 9
+        // (round 6, measured and not kept: both halves of a column per group in groups 1..4 and the requests in group 5 -- 800 clocks more lead
+        // time for the loads -- is SLOWER: 4.78 k against 4.63 k clocks per slab, 125.4 against 124.1 ms per step, profiles/r06_train_wgrad_phase_timer.txt)
         if constexpr (u >= 1 && u <= 8) stash_half(buf ^ 1, (u - 1) >> 1, (u - 1) & 1);
         if constexpr (u == 9) {
 #pragma unroll
@@ -600,8 +612,24 @@ __device__ __forceinline__ void wgrad512_body_w8(const Wgrad512Args& a, const in
         asm volatile("" : "+a"(acc[fi][kt]));
       });
     });
+#ifdef DINER_L512_PROF
+    const unsigned long long pw_b = __builtin_readcyclecounter();
     __syncthreads();
+    pw_mf += pw_b - pw_a;
+    pw_bar += __builtin_readcyclecounter() - pw_b;
+#else
+    __syncthreads();
+#endif
   }
+#ifdef DINER_L512_PROF
+  if (lane == 0) {
+    atomicAdd(&g_wg_prof[0], __builtin_readcyclecounter() - pw_t0);
+    atomicAdd(&g_wg_prof[1], pw_mf);
+    atomicAdd(&g_wg_prof[2], pw_bar);
+    atomicAdd(&g_wg_prof[3], (unsigned long long)n_slabs);
+    atomicAdd(&g_wg_prof[4], 1ull);
+  }
+#endif
 #pragma unroll
   for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -857,5 +885,20 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_in_f16x3(WgradInArgs a) {
   }
 }
 
+#ifdef DINER_L512_PROF
+}  // namespace train
+}  // namespace diner
+extern "C" int diner_debug_wgrad_prof(unsigned long long* out8, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(diner::train::g_wg_prof), 8 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[8] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(diner::train::g_wg_prof), z, sizeof(z));
+  }
+  return 0;
+}
+namespace diner {
+namespace train {
+#endif
 }  // namespace train
 }  // namespace diner

@@ -61,3 +61,38 @@ run("forward f16x3 fp32 mask + accumulating", accumulate=True, mask=res)
 for Msmall in (163840, 20480):
     x, y, res = x[:Msmall], y[:Msmall], res[:Msmall]
     run(f"forward f16x3 plain, {Msmall} rows")
+
+# ---- (round 6) one training step (1 object x 4096 rays x 40 samples): every lin512 launch of it, and the eight-wave weight gradient
+# (k_wgrad512_w8: slab sections against slab barriers, per wave)
+try:
+    raw.diner_debug_wgrad_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    from diner_amd import ops
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict, build_modules
+    del x, y, res
+    torch.cuda.empty_cache()
+    Wt, Ht, NR, K = 400, 300, 4096, 40
+    scs = [make_scene(Wt, Ht, seed=0)]
+    nerf, R = build_modules(scs, make_mlp_state_dict(), dev)
+    nerf.train()
+    nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+    rays_all = ops.gen_rays(torch.stack([scs[0]["target_extrinsics"]]), torch.stack([scs[0]["target_intrinsics"]]), Wt, Ht, scs[0]["znear"], scs[0]["zfar"], dev)
+    ys, xs = torch.meshgrid(torch.arange(64) + (Ht - 64) // 2, torch.arange(64) + (Wt - 64) // 2, indexing="ij")
+    r = rays_all[:, (ys * Wt + xs).reshape(-1).to(dev)].contiguous()
+    gt = torch.rand(1, NR, 3, device=dev)
+    ren = R(n_samples=K, n_depth_candidates=1000, n_gaussian=15, white_bkgd=True)
+    a8 = (C.c_ulonglong * 8)()
+    for rep in range(2):
+        for p in nerf.parameters():
+            p.grad = None
+        nerf.encoder.latent.grad = None
+        torch.nn.functional.mse_loss(ren.forward(nerf, r).fine.rgb, gt).backward()
+        torch.cuda.synchronize()
+        read(f"training step ({'warm-up' if rep == 0 else 'second'}): all lin512 launches")
+        raw.diner_debug_wgrad_prof(a8, 1)
+        tot, mf, bar, slabs, waves = (float(a8[i]) for i in range(5))
+        if waves:
+            print(f"k_wgrad512_w8 over the step: waves {waves:.0f}, slabs/wave {slabs / waves:.0f}; clocks per 32-row slab {tot / slabs:.0f} = slab section "
+                  f"{mf / slabs:.0f} + barrier {bar / slabs:.0f} + rest {(tot - mf - bar) / slabs:.0f}  (MFMA issue alone: 48 x 32 = 1536 clocks per wave and slab, two waves per SIMD: 3072)",
+                  flush=True)
+except AttributeError:
+    pass
