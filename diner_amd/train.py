@@ -22,6 +22,10 @@ no host synchronisation) redoes the object; weights outside the fp16 split go to
 4 views = 655 k columns per object and step (configs/train_dtu.yaml:16,52-63); the workspace of saved activations is 94 KB per sample
 point = 15.4 GiB per object at that size (diner_field_train_workspace_bytes); round 5: 10.8 GiB of it are what the backward reads (kept per
 object by autograd, four alive between forward and backward), the other 4.6 GiB are work buffers shared by the objects of a step.
+Round 6 (ABI v6): the SB objects of a step are ONE autograd node (FieldBatchFunction -> diner_field_train_forward_batch_f32 / _backward_batch_f32:
+object-major rows in one workspace, the backward's layer products once over all objects' rows); the packed-weights handle is persistent and re-packed
+on the stream (diner_mlp_update) -- no host synchronisation per step; configurations outside the fused kernels train on the generic exact-fp32 path
+(GenericMlpFunction, field_train_generic); release_buffers() frees what the path keeps between steps.
 """
 import os
 
