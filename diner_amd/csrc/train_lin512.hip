@@ -131,6 +131,9 @@ __global__ void k_pack_w512_many(PackMany w, char* __restrict__ base, int* __res
 #ifndef DINER_L512_RING
 #define DINER_L512_RING 2
 #endif
+#ifndef DINER_L512_EPI_PD      // groups of tensor-term requests in flight in the epilogue of the 128-row shape (1 = round 6's first version)
+#define DINER_L512_EPI_PD 1
+#endif
 // -DDINER_L512_PROF (measurement build, tools/prof_l512.sh): shader clocks per wave summed over the launches since the last read --
 // [0] whole tile loop, [1] MFMA slab loops without their barriers, [2] slab barriers, [3] epilogues, [4] tiles, [5] waves, [6] prologue
 #ifdef DINER_L512_PROF
@@ -460,8 +463,12 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
         constexpr bool BITS = decltype(BITSc)::value, GEN = decltype(GENc)::value;
         const __amdgpu_buffer_rsrc_t rs_p = rsrc(PK == 1 ? a.resid : a.Y);
         const __amdgpu_buffer_rsrc_t rs_mb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>((BITS ? a.maskbits : (const unsigned*)a.Y) + (size_t)row0 * 16), 0, left * 64, 0x00020000);
-        f32x4 pre[GN];
-        unsigned mb[GN];
+        // a ring of PD groups of term requests in flight (DINER_L512_EPI_PD).  Measured (profiles/r06_train_wgrad_phase_timer.txt): 2 groups ahead
+        // change nothing (accumulating epilogue 22.3 k clocks per tile, step 120.9 ms against 120.9), 3 cost 70 spill instructions and 1 ms:
+        // the epilogue is not waiting for latency any more.  Default 1.
+        constexpr int PD = (PK != 0 || BITS) ? DINER_L512_EPI_PD : 1;
+        f32x4 pre[PD][GN];
+        unsigned mb[PD][GN];
         auto issue = [&](f32x4 (&tp)[GN], unsigned (&tm)[GN], int g) {
 #pragma unroll
           for (int j = 0; j < GN; ++j) {
@@ -470,9 +477,12 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
             if constexpr (BITS) tm[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_mb, bvoff, (unsigned)rw * 64u, 0);
           }
         };
-        issue(pre, mb, 0);
+        sfor<PD>([&](auto Pi) {
+          constexpr int pg = decltype(Pi)::value;
+          if constexpr (pg < NGRP) issue(pre[pg], mb[pg], pg);
+        });
         sfor<NGRP>([&](auto Gi) {
-          constexpr int g = decltype(Gi)::value, ct = g / GPC, gi = g % GPC;
+          constexpr int g = decltype(Gi)::value, ct = g / GPC, gi = g % GPC, slot = g % PD;
           if constexpr (gi == 0) {                                              // this part's accumulators -> the wave's LDS region
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
@@ -490,15 +500,20 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
             const int i = GN * gi + j;
             v[j] = *(lds_f4)(rbase_e + (i >> 1) * kStepBytes + (i & 1) * 1024 + (rx ^ ((i & 7) * 32)));
           }
-          f32x4 nxt[GN];
-          unsigned mbn[GN];
-          if constexpr (g + 1 < NGRP) issue(nxt, mbn, g + 1);                   // (rows past M: the descriptors return zeros, nothing of them is stored)
+          f32x4 cur[GN];
+          unsigned curb[GN];
+#pragma unroll
+          for (int j = 0; j < GN; ++j) {
+            cur[j] = pre[slot][j];
+            curb[j] = mb[slot][j];
+          }
+          if constexpr (g + PD < NGRP) issue(pre[slot], mb[slot], g + PD);      // (in front of this group's stores; rows past M: the descriptors return zeros)
 #pragma unroll
           for (int j = 0; j < GN; ++j) {
             const int rw = 32 * ct + 2 * (GN * gi + j);
             const unsigned so = (unsigned)rw * rowbytes;
             if (has_bias) v[j] += bv;
-            if constexpr (PK == 1) v[j] += pre[j];
+            if constexpr (PK == 1) v[j] += cur[j];
             if constexpr (GEN) {
               if (a.resid) v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.resid), gvoff, so, 0));
               if (a.resid2) v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.resid2), gvoff, so, 0));
@@ -515,22 +530,15 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
               if (accum) v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, gvoff, so, 0));
             }
             if constexpr (BITS) {
-              const unsigned m = mb[j] >> sh;
+              const unsigned m = curb[j] >> sh;
 #pragma unroll
               for (int c = 0; c < 4; ++c) v[j][c] = ((m >> c) & 1u) ? v[j][c] : 0.0f;
             }
-            if constexpr (PK == 2) v[j] += pre[j];
+            if constexpr (PK == 2) v[j] += cur[j];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs_y, gvoff, so, 0);
             if (a.amax_out && rw < left_lane) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) y_max = max(y_max, __float_as_uint(v[j][c]) & 0x7fffffffu);
-            }
-          }
-          if constexpr (g + 1 < NGRP) {
-#pragma unroll
-            for (int j = 0; j < GN; ++j) {
-              pre[j] = nxt[j];
-              mb[j] = mbn[j];
             }
           }
         });
