@@ -897,7 +897,8 @@ def main():
                        "frame": frame_name, "parallelism": par},
             "backend": backend, "ranks_share_gpu": bool(shared and world > 1),
             "fallback_launches": head_fallbacks,
-            "energy": psamp.summary(elapsed, rays_per_step * args.steps),
+            # (N > 1: rank 0 samples ITS device only -- power_w / sclk_mhz are that device's, the energy per ray of the job is not computed)
+            "energy": psamp.summary(elapsed, rays_per_step * args.steps if world == 1 else 0),
             "encode": encode,
             "train": train_line,
             "dist": dist_info, "frame_check": frame_check,
