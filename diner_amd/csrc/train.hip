@@ -672,6 +672,45 @@ __global__ __launch_bounds__(256) void k_cl_to_nchw(const float* __restrict__ sr
     if (c0 + r < C && p0 + tx < HW) dst[img + (size_t)(c0 + r) * HW + p0 + tx] = tile[tx][r];
 }
 
+// ---- round 6: the latent rows a training batch touches ----------------------------------------------------------------------------------
+// The fused forward gathers its lin_z terms from the latent map projected through lin_z[0..2]; projecting the WHOLE map per object and step
+// costs a map's worth of rows whatever the batch (226 k rows at 400 x 300: 1.1 ms per object; 1024 x 1024 maps fell back to the layer-wise
+// forward), while a 64 x 64 patch of rays with 40 depth-guided samples touches 2.4 % of the texels (5.5 k of 226 k).  So: mark the texel rows
+// the batch's taps name, compact them into a list, project THAT list (gather rows -> product over a device-side row count -> scatter rows).
+// Texels a tap could name under another rounding of the last bit carry a weight of ~1e-7: they read whatever finite value the buffer holds
+// (the host zero-fills it once), never an unwritten NaN.
+__global__ __launch_bounds__(256) void k_mark_rows(const int* __restrict__ tap_row, long long n, int* __restrict__ mark) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) mark[tap_row[i]] = 1;
+}
+// idx[0 .. count) = the marked rows (order: whatever the atomics give; the products are row-wise); *dense = 1 when more than cap rows are marked
+// (the list is then unusable: the caller's dense projection, gated on the flag, takes over)
+__global__ __launch_bounds__(256) void k_compact_rows(const int* __restrict__ mark, int nrows, int cap, int* __restrict__ idx, int* __restrict__ count,
+                                                      int* __restrict__ dense) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nrows; i += gridDim.x * 256) {
+    if (mark[i]) {
+      const int at = atomicAdd(count, 1);
+      if (at < cap) idx[at] = i;
+      else *dense = 1;
+    }
+  }
+}
+// dst[r] = src[idx[r]] (gather) or dst[idx[r]] = src[r] (scatter) for r < min(*count, cap), rows of 512 floats; blockIdx.y = plane (strides in floats)
+__global__ __launch_bounds__(256) void k_move_rows(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ idx,
+                                                   const int* __restrict__ count, int cap, int scatter, size_t src_plane, size_t dst_plane,
+                                                   const int* __restrict__ skip) {
+  if (skip && *skip != 0) return;
+  int n = *count;
+  n = n < cap ? n : cap;
+  const float* s = src + (size_t)blockIdx.y * src_plane;
+  float* d = dst + (size_t)blockIdx.y * dst_plane;
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+    const size_t a = (size_t)(scatter ? r : idx[r]) * kLatent, b = (size_t)(scatter ? idx[r] : r) * kLatent;
+    reinterpret_cast<f32x4*>(d + b)[lane] = reinterpret_cast<const f32x4*>(s + a)[lane];
+    reinterpret_cast<f32x4*>(d + b)[64 + lane] = reinterpret_cast<const f32x4*>(s + a)[64 + lane];
+  }
+}
+
 // relu decisions of (rows, 512) pre-activations as bits in the layout Lin512Args.maskbits names: one thread per dword = 32 features
 // 128 s + 16 mo + 4 q + i (s = dword / 4, q = dword % 4; bit 4 mo + i) -- eight 16-byte reads; blockIdx.y = tensor
 struct MakeBits { const float* src[10]; unsigned* dst[10]; long long rows[10]; };
@@ -1468,19 +1507,64 @@ static int fused_forward_core(const DinerScene* scene, const DinerMlp* mlp, cons
     DINER_CHECK_ARG(scene->latent_cl && scene->C == kLatent && scene->Hf > 0 && scene->Wf > 0, "field_train_forward_fused: channels-last latent missing");
     const long long rows = (long long)scene->nv * scene->Hf * scene->Wf;
     DINER_CHECK_ARG(lin512_ok(scene->latent_cl, kLatent, latent_proj_out, kHidden, nullptr, nullptr), "field_train_forward_fused: unaligned latent / projection buffer");
+    int* flags = reinterpret_cast<int*>(ws + w.flags);
+    // round 6: project only the texel rows this batch touches (see k_mark_rows).  Work buffers in the backward's dH region, free in the
+    // forward: [mark rows][idx rows][count, dense][Xc cap x 512][Yc 3 x cap x 512], cap = cols / 4 rows (the region holds cols x 512 floats).
+    // More marked rows than cap (a batch spread over most of a small map): `dense` goes up and the whole-map projection below, gated on it, runs.
+    const char* e_touched = getenv("DINER_TRAIN_PROJ_TOUCHED");      // (read per call: the tests switch them)
+    const char* e_cap = getenv("DINER_TRAIN_PROJ_CAP");              // test aid: a small cap forces the overflow of the list -> the gated dense projection
+    const bool touched_only = !(e_touched && *e_touched == '0');
+    const long long cap_env = e_cap ? atoll(e_cap) : 0ll;
+    const long long cols = P * scene->nv;
+    long long cap = (cols - (2 * rows + 64 + 511) / 512 - 2) / 4;      // Xc + 3 planes of Yc behind the two int arrays (rows of 512 floats)
+    if (cap_env > 0 && cap_env < cap) cap = cap_env;
+    const bool sparse = touched_only && cap >= 64 && rows < (1ll << 31) && cols * 4 < (1ll << 31);
+    int* mark = reinterpret_cast<int*>(sc + w.dH);
+    int* idx = mark + rows;
+    int* cnt = idx + rows;                 // cnt[0] = marked rows, cnt[1] = dense
+    float* Xc = reinterpret_cast<float*>(cnt + 64);
+    Xc += (64 - ((reinterpret_cast<size_t>(Xc) / sizeof(float)) & 63)) & 63;      // (16-byte alignment and then some)
+    float* Yc = Xc + (size_t)(sparse ? cap : 0) * kLatent;
+    const int* dense = sparse ? cnt + 1 : nullptr;
+    if (sparse) {
+      DINER_HIP_OK(hipMemsetAsync(mark, 0, (size_t)rows * sizeof(int), st));
+      DINER_HIP_OK(hipMemsetAsync(cnt, 0, 64 * sizeof(int), st));
+      hipLaunchKernelGGL(k_mark_rows, dim3(grid1d(cols * 4)), dim3(256), 0, st, (const int*)(ws + w.tap_row), cols * 4, mark);
+      hipLaunchKernelGGL(k_compact_rows, dim3(grid1d(rows)), dim3(256), 0, st, mark, (int)rows, (int)cap, idx, cnt, cnt + 1);
+      hipLaunchKernelGGL(k_move_rows, dim3(1024, 1), dim3(256), 0, st, (const float*)scene->latent_cl, Xc, idx, cnt, (int)cap, 0, (size_t)0, (size_t)0, dense);
+    }
     for (int b = 0; b < 3; ++b) {
       // (the handle's constants: planes 1 and 2 also carry fc_1's bias of the block before, as the per-view kernel expects them)
+      int* flag = flags + kSlotLinZ + b;
+      if (sparse) {          // the touched rows: X = the gathered rows, Y = compact plane b; row count on the device
+        Lin512Args a{Xc, wpack_slot(ws, w, kSlotLinZ + b, false), Yc + (size_t)b * cap * kHidden, mlp_hoist_bias(mlp) + kHidden * b,
+                     nullptr, nullptr, cap, kLatent, kHidden, 0};
+        a.m_dev = cnt;
+        a.skip_silent = dense;
+        Lin512Args h = a;
+        h.Wp = wpack_slot(ws, w, kSlotLinZ + b, false, true);
+        h.ovf = flag;
+        h.skip = flags + kFlagWBad;
+        if ((rc = lin512_launch(h, st, 1))) return rc;
+        a.gate = flag;
+        if ((rc = lin512_launch(a, st))) return rc;
+      }
+      // the whole map: always without the list, else only when the list overflowed (gated on `dense`)
       Lin512Args a{scene->latent_cl, wpack_slot(ws, w, kSlotLinZ + b, false), latent_proj_out + (size_t)b * rows * kHidden, mlp_hoist_bias(mlp) + kHidden * b,
                    nullptr, nullptr, rows, kLatent, kHidden, 0};
-      int* flag = reinterpret_cast<int*>(ws + w.flags) + kSlotLinZ + b;
       Lin512Args h = a;
       h.Wp = wpack_slot(ws, w, kSlotLinZ + b, false, true);
       h.ovf = flag;
-      h.skip = reinterpret_cast<int*>(ws + w.flags) + kFlagWBad;
+      h.skip = flags + kFlagWBad;
+      h.gate = dense;
       if ((rc = lin512_launch(h, st, 1))) return rc;
       a.gate = flag;
+      a.gate2 = dense;
       if ((rc = lin512_launch(a, st))) return rc;
     }
+    if (sparse)
+      hipLaunchKernelGGL(k_move_rows, dim3(1024, 3), dim3(256), 0, st, (const float*)Yc, latent_proj_out, idx, cnt, (int)cap, 1, (size_t)cap * kHidden,
+                         (size_t)rows * kHidden, dense);
     own.latent_proj = latent_proj_out;
     own.proj_stamp = diner_mlp_stamp(mlp);
   }

@@ -69,6 +69,12 @@ __global__ __launch_bounds__(256, 1) void k_run512(Run512 r) {
   wgrad512_body<0>(r.wg, b - r.n[1]);
 }
 
+// round 6: a product over a row list whose length lives on the device (Lin512Args.m_dev: the latent rows a training batch touches): 32-row
+// tiles on every CU, AR = 1 (f16x3) or 0 (its bf16x6 twin)
+template <int AR>
+__global__ __launch_bounds__(256, 1) void k_lin512_rows(Lin512Args a, int nblk) {
+  lin512_body<DINER_L512_RING, 1, 1, AR, 4, true>(a, blockIdx.x, nblk);
+}
 // round 5: the data gradient of an f16x3 launch on eight waves (lin512_body<.., NW = 8>: two waves per SIMD, 64 features and half the staging
 // rows per wave; the shared 32-row shape of a plan runs as plain 32-row tiles -- its second workgroups find no tile)
 __global__ __launch_bounds__(512, 1) void k_dgrad512_w8(Run512 r) {
@@ -101,6 +107,8 @@ int device_cus(int* cus) {                                   // per device: dyna
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad512_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_dgrad512_w8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_wgrad_in_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesWgradIn));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
+    DINER_HIP_OK(hipFuncSetAttribute((const void*)k_lin512_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesRun));
     int c = 0;
     DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
     cu_count[dev].store(c > 1 ? c & ~1 : 256);
@@ -215,6 +223,14 @@ int lin512_launch(const Lin512Args& a, hipStream_t stream, int arith) {
   int cus = 0;
   int rc = device_cus(&cus);
   if (rc) return rc;
+  if (a.m_dev || a.skip_silent) {      // the row count lives on the device: 32-row tiles handed to every CU (a short list fills the chip best that way)
+    const long long units = (a.M + 31) / 32;
+    const int n = (int)(units < cus ? units : cus);
+    if (arith == 1) hipLaunchKernelGGL(k_lin512_rows<1>, dim3(n), dim3(256), kLdsBytesRun, stream, a, n);
+    else hipLaunchKernelGGL(k_lin512_rows<0>, dim3(n), dim3(256), kLdsBytesRun, stream, a, n);
+    DINER_LAUNCH_OK();
+    return 0;
+  }
   Run512 r;
   plan_lin512(a, cus, &r, arith == 1);
   memset(&r.wg, 0, sizeof(r.wg));

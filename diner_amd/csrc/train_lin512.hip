@@ -156,7 +156,7 @@ __device__ unsigned long long g_l512_prof[8];
 // recomputes the product with AR = 0 -- the training FORWARD only, whose operands are activations)
 // NW (round 5): waves per workgroup.  8 = two waves per SIMD (512 threads, 256 registers per wave): wave w owns 64 features (the second half
 // of the wave slice w / 2 for odd w: the addressing of the shared 32-row shape, FH = 2, inside ONE workgroup) and stages half as many rows.
-template <int R, int CT, int FH, int AR = 0, int NW = 4>
+template <int R, int CT, int FH, int AR = 0, int NW = 4, bool MDEV = false>
 __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, const int nblk) {
   static_assert(NW == 4 || (NW == 8 && FH == 1), "eight waves: whole tiles only");
   constexpr int NP = AR == 1 ? 2 : 3, NT = AR == 1 ? 3 : 6;  // planes per operand, product terms
@@ -175,6 +175,14 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
 #endif
   if (a.gate && *a.gate == 0) return;                        // fall-back launch of an f16x3 product that stayed in range: nothing to do
   if (a.gate2 && *a.gate2 == 0) return;
+  long long Mrows = a.M;
+  if constexpr (MDEV) {                                      // a row list whose length only the device knows (k_lin512_rows; a separate
+    if (a.skip_silent && *a.skip_silent != 0) return;        // instantiation: one more live value costs the 128-row shapes spills)
+    if (a.m_dev) {
+      const long long md = *a.m_dev;
+      Mrows = md < Mrows ? md : Mrows;
+    }
+  }
   if (a.skip && *a.skip != 0) {                              // f16x3 launch of a step whose weights do not fit: the bf16x6 twin works
     if (a.ovf && threadIdx.x == 0) {                         // (the forward's twin is gated on this product's flag)
       *a.ovf = 1;
@@ -199,7 +207,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   typedef __attribute__((address_space(3))) bf8* lds_bf8;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const long long n_tiles = (a.M + kRows - 1) / kRows;
+  const long long n_tiles = (Mrows + kRows - 1) / kRows;
   const int relu_floor1 = (a.flags & kL512ReluIn) ? 0 : (int)0x80000000, relu_floor2 = a.relu2 ? 0 : (int)0x80000000;
   int relu_floor = relu_floor1;                              // of the slab being converted (two contraction segments: set per slab)
   const int n_slabs = a.X2 ? 2 * kSlabs : kSlabs;            // slabs kSlabs .. 2 kSlabs - 1: the second segment (X2, Wp2)
@@ -214,7 +222,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   const unsigned xvoff = ((unsigned)(kStageRows * wave + (lane >> 5)) * (unsigned)a.ldx + 4u * (lane & 31)) * 4u;
   auto request_one = [&](int i, long long tile, int slab) {
     const long long row0 = tile * kRows;
-    long long left = a.M - row0;
+    long long left = Mrows - row0;
     left = left < 0 ? 0 : (left > kRows ? kRows : left);
     const float* src = slab >= kSlabs ? a.X2 : a.X;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)row0 * a.ldx), 0,
@@ -428,7 +436,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
       asm volatile("" : "+v"(el));
       const int er = el & 31, eh = el >> 5;
       const long long row0 = tile * kRows;
-      const long long left_ll = a.M - row0;
+      const long long left_ll = Mrows - row0;
       const int left = left_ll > kRows ? kRows : (int)left_ll;
       const int left_lane = left - eh;                                          // row 2 i + eh of a part is valid iff 32 ct + 2 i < left_lane
       const unsigned rowbytes = (unsigned)a.ldy * 4u;
@@ -563,7 +571,7 @@ __device__ __forceinline__ void lin512_body(const Lin512Args& a, const int bid, 
   #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const long long row = tile * kRows + 32 * ct + (lane & 31);
-        if (row >= a.M) continue;
+        if (row >= Mrows) continue;
         constexpr int NV = 4 * NRT;
         f32x4 v[NV];
         const size_t at0 = (size_t)row * a.ldy + 128 * wslice + 32 * rt0 + 4 * (lane >> 5);        // + 32 rt + 8 q4

@@ -36,6 +36,9 @@ struct Lin512Args {
   const unsigned* maskbits;  // null, or (instead of mask) the relu decisions of the saved pre-activation as bits: 16 dwords per row (round 5;
                              // written by the forward -- save_block of mlp_h3n.hip / k_make_bits of train.hip: feature f of the row sits in
                              // dword 4 (f / 128) + (f % 16) / 4 at bit 4 ((f % 128) / 16) + f % 4); Y = 0 where the bit is down
+  // round 6 -- a product over a row list whose length only the device knows (the latent rows a training batch touches, train.hip):
+  const int* m_dev;          // null, or: the number of rows is min(*m_dev, M) (M = the capacity the launch was planned for)
+  const int* skip_silent;    // null, or: the launch does nothing when *skip_silent != 0 (unlike `skip`, no flag is raised)
   const int* gate2;          // null, or a second condition like gate (round 5: the layer-wise forward as the repeat behind the fused training forward --
                              // its bf16x6 twins run only if the fused kernels left the range AND their own f16x3 product did)
 };

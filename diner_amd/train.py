@@ -143,19 +143,22 @@ def fused_forward_enabled(P=None, scene=None):
 _PROJ = {}
 
 
-def _shared(pool, dev, nbytes):
+def _shared(pool, dev, nbytes, zero=False):
     """A buffer that lives inside one library call only, shared by the objects of a step (and the steps): one per device AND stream -- calls
-    on a stream run one after the other; it only grows (the caching allocator keeps a replaced one alive for the work already enqueued)."""
+    on a stream run one after the other; it only grows (the caching allocator keeps a replaced one alive for the work already enqueued).
+    zero: zero-filled when (re)allocated."""
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     buf = pool.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = pool[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        buf = pool[key] = (torch.zeros if zero else torch.empty)(int(nbytes), dtype=torch.uint8, device=dev)
     return buf
 
 
 def _proj_buffer(scene, dev):
     """The latent map projected through lin_z[0..2] with the step's weights: written and read inside the forward call only."""
-    return _shared(_PROJ, dev, int(lib.diner_scene_proj_bytes(scene.ref)))
+    # zero-filled once: round 6 projects only the texel rows a batch touches; a texel that another rounding of a tap's last bit would name is read
+    # with a weight of ~1e-7 and must hold a finite value (zeros, later older projections), never an unwritten NaN
+    return _shared(_PROJ, dev, int(lib.diner_scene_proj_bytes(scene.ref)), zero=True)
 
 
 _SCRATCH = {}
@@ -298,7 +301,7 @@ class FieldBatchFunction(torch.autograd.Function):
             _lib.check(lib.diner_field_train_batch_workspace_split(P, NV, SB, C.byref(a), C.byref(b)))
             ws = torch.empty(int(a.value), dtype=torch.uint8, device=dev)
             scratch = _shared(_SCRATCH, dev, int(b.value))
-            proj = _shared(_PROJ, dev, max(int(lib.diner_scene_proj_bytes(sc.ref)) for sc in scenes))
+            proj = _shared(_PROJ, dev, max(int(lib.diner_scene_proj_bytes(sc.ref)) for sc in scenes), zero=True)
             out = torch.empty(SB, P, 4, device=dev)
             ps, keep = _param_struct(params, freq_factor)
             mlp = _step_handle(params, freq_factor)

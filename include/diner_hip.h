@@ -324,7 +324,9 @@ int diner_field_train_backward_s_f32(const DinerScene* scene, const DinerMlpPara
  * the layer-wise forward uses (diner_field_train_ws_layout), so that diner_field_train_backward_f32 follows unchanged.  `mlp`: the
  * packed-weights handle of THIS step's parameters.  latent_proj_out (diner_scene_proj_bytes; free again when the call's work is done):
  * the library projects scene->latent_cl through lin_z[0..2] into it on the training products' kernel (f16x3 with its bf16x6 repeat)
- * and gathers from it; NULL: `scene->latent_proj` prepared with `mlp` (diner_scene_prepare_f32) is used.  The exact repeat is the layer-wise
+ * and gathers from it (round 6: only the texel rows the batch's taps name are projected -- a 64 x 64 ray patch touches 2-3 % of a 400 x 300 map;
+ * the buffer must hold FINITE values before its first use (zero it once): a texel that another rounding of a tap's last bit would name is read
+ * with a weight of ~1e-7; DINER_TRAIN_PROJ_TOUCHED=0: the whole map); NULL: `scene->latent_proj` prepared with `mlp` (diner_scene_prepare_f32) is used.  The exact repeat is the layer-wise
  * forward, enqueued by this call behind the fused kernels and gated on their range flag (no host synchronisation);
  * diner_field_train_fused_overflowed reads that flag back after a stream wait (a test aid).  DINER_E_UNSUPPORTED (weights outside the fp16
  * split, a projected map of 4 GiB or more): call diner_field_train_forward_f32 (pixelnerf.py:55-145, resnetfc.py:129-159). */

@@ -737,3 +737,50 @@ def test_shipped_step_four_objects_equals_the_sum_of_its_objects(ops):
     print(f"SB = 4 x 4096 rays x 40 samples: peak device memory {peak:.1f} GiB; parameter gradients against the sum of the four single-object steps: "
           f"worst {worst[0]} {worst[1]:.2e}; latent gradient slabs within 1e-5, rgb bit-equal per object")
     assert worst[1] < 1e-5
+
+
+def test_touched_texel_projection_equals_the_whole_map_projection(ops, monkeypatch):
+    """Round 6: the fused training forward projects through lin_z[0..2] only the latent rows its batch touches (k_mark_rows / k_compact_rows,
+    a product over a device-side row count, rows scattered back).  Per row the product is the same arithmetic as the whole-map projection, so
+    outputs must be BIT-EQUAL (and the gradients equal to the round-off of their atomics) -- with the list (default), with the whole map (DINER_TRAIN_PROJ_TOUCHED=0) and when the
+    list overflows its capacity and the dense projection takes over ON THE DEVICE (DINER_TRAIN_PROJ_CAP=64: the flag `dense`, no host decision);
+    the latent gradient (float atomics in the scatter) to round-off."""
+    from diner_amd import train
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict
+    from tests.tests_train_util import module_param_list
+    from src.util.depth2normal import depth2normal
+    monkeypatch.setenv("DINER_TRAIN_FUSED_FWD", "1")
+    sc = make_scene(64, 64, seed=3)
+    sc["normals"] = depth2normal(sc["depths"], sc["src_intrinsics"])
+    Kin = sc["src_intrinsics"]
+    P = 5120
+    g = torch.Generator().manual_seed(11)
+    xyz = (torch.rand(P, 3, generator=g) - 0.5) * 0.2          # a compact cloud at the object: a few hundred texels per view, far below the list's capacity
+    dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    Gm = torch.randn(P, 4, generator=g).cuda()
+    msd = make_mlp_state_dict()
+    res = {}
+    for tag, env in (("touched", {}), ("whole", {"DINER_TRAIN_PROJ_TOUCHED": "0"}), ("overflow", {"DINER_TRAIN_PROJ_CAP": "64"})):
+        for k in ("DINER_TRAIN_PROJ_TOUCHED", "DINER_TRAIN_PROJ_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        train.release_buffers()
+        params, _ = module_param_list(msd)
+        lat = sc["latent"].cuda().requires_grad_(True)
+        scene = ops.HipScene(lat.detach(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(), sc["src_extrinsics"],
+                             Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"], sc["feature_padding"])
+        out = train.field_train(scene, xyz.cuda(), dirs.cuda(), lat, params)
+        (out * Gm).sum().backward()
+        res[tag] = (out.detach().clone(), [p.grad.clone() for p in params], lat.grad.clone())
+    o0, g0, l0 = res["touched"]
+    assert torch.isfinite(o0).all() and all(torch.isfinite(t).all() for t in g0)
+    for tag in ("whole", "overflow"):
+        o, gs, l = res[tag]
+        print(f"{tag}: forward max |d| {float((o - o0).abs().max()):.3e} ({int((o != o0).any(-1).sum())} of {P} points differ), worst parameter gradient "
+              f"{max(max_norm_rel(a.cpu(), b.cpu()) for a, b in zip(gs, g0)):.3e}, d latent {max_norm_rel(l.cpu(), l0.cpu()):.3e}")
+        assert torch.equal(o, o0), f"{tag}: the forward differs from the touched-rows projection"
+        # (the backward is the same launch sequence on bit-equal saved activations; lin_in's / lin_out's weight gradients and the latent scatter
+        # sum with float atomics, so their last bits are not reproducible from run to run)
+        assert max(max_norm_rel(a.cpu(), b.cpu()) for a, b in zip(gs, g0)) < 1e-5, f"{tag}: parameter gradients differ"
+        assert max_norm_rel(l.cpu(), l0.cpu()) < 1e-5
