@@ -125,19 +125,17 @@ def _param_struct(tensors, freq_factor=6.28):
 
 
 def fused_forward_enabled(P=None, scene=None):
-    """DINER_TRAIN_FUSED_FWD: 1 = always, 0 = never, unset = by size.  The fused forward projects the WHOLE latent map through lin_z[0..2]
-    (the inference path's hoist) where the layer-wise forward projects the P x NV gathered rows: it pays from about 0.7 of a map of sample
-    points per object (the shipped 4096 rays x 40 samples: 3 maps' worth -- 157.0 -> 143.0 ms per four-object step; a 128-ray batch: a
-    tenth of a map: profiles/r05_train_fused_forward.txt)."""
+    """DINER_TRAIN_FUSED_FWD: 1 = always, 0 = never, unset = by size (from 16384 sample points per object on)."""
     if scene is not None and scene.nv != 4:          # the fused kernels are built for four source views (the layer-wise forward: any)
         return False
     e = os.environ.get("DINER_TRAIN_FUSED_FWD", "")
     if e in ("0", "1"):
         return e == "1"
-    # break-even from the measured parts at 400 x 300 / 4096 rays x 40 samples (fused 7.1 + 1.1 + 0.4 ms + 5.2 us per 1000 map rows projected,
-    # layer-wise 13.3 ms; everything but the projection scales with P): maps up to ~1.4 x the sample points per view.  Checked on either side:
-    # 800 x 600 maps (1.03 x) fused 38.75 / layer-wise 39.97 ms per object, 1024 x 1024 (2.0 x) 43.93 / 41.49 (profiles/r05_train_fused_forward.txt)
-    return P is None or scene is None or 7 * P >= 5 * scene.Hf * scene.Wf
+    # round 6: the projection now costs the TOUCHED texel rows, not the map (csrc/train.hip, k_mark_rows), so the map size is out of the rule:
+    # 800 x 600 maps 32.6 ms fused against 38.1 layer-wise per 4096-ray object; what is left is the fixed cost of the fused kernels' launches at
+    # tiny batches -- 128 rays x 40 samples (5120 points): 13.0 ms fused against 12.4 layer-wise per four-object step
+    # (profiles/r06_train_touched_texel_projection.txt)
+    return P is None or P >= 16384
 
 
 _PROJ = {}
