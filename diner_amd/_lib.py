@@ -112,7 +112,7 @@ SIGNATURES = {
     "diner_field_train_forward_batch_f32": (C.c_int, [C.POINTER(C.POINTER(DinerScene)), C.c_int, C.c_void_p, C.POINTER(DinerMlpParams), C.c_void_p,
                                                       C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "diner_field_train_backward_batch_f32": (C.c_int, [C.POINTER(C.POINTER(DinerScene)), C.c_int, C.POINTER(DinerMlpParams), C.POINTER(DinerMlpParams),
-                                                       C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+                                                       C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     "diner_quantize_rgb_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "diner_minmax_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "diner_colormap_u8": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),

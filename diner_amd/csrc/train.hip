@@ -34,6 +34,7 @@ struct GemmArgs {
   long long M;
   int N, K, lda, ldb, ldc, flags, k_chunk;      // k_chunk: K range per blockIdx.z (split-K, needs kAtomic)
   const int* gate;      // null, or: the launch does nothing unless *gate != 0 (bf16x6 kernel: the layer-wise repeat behind the fused training forward)
+  const int* k_dev;     // null, or (bf16x6 kernel): the contraction runs over min(K, *k_dev) indices -- a row list whose length only the device knows
 };
 
 // C tile 64 x 64 per workgroup, four waves 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles; operands staged k-major in LDS.
@@ -387,7 +388,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
   }
   const long long m0 = (long long)by * XM;
   const int n0 = bx * XN;
-  const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+  const int kbeg = bz * g.k_chunk, kend = min(Keff, kbeg + g.k_chunk);
+  if (kbeg >= kend) return;                                   // (k_dev: the chunks past the list's end)
   const bool ta = g.flags & kTA, tb = g.flags & kTB, ra = g.flags & kReluA, rb = g.flags & kReluB;
   // op(A) is M x K: stored [M][lda] (contraction contiguous) unless kTA; op(B) is K x N: stored [K][ldb] (output contiguous) unless kTB
   const bool a_kc = !ta, b_kc = tb;
@@ -706,8 +709,30 @@ __global__ __launch_bounds__(256) void k_move_rows(const float* __restrict__ src
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
     const size_t a = (size_t)(scatter ? r : idx[r]) * kLatent, b = (size_t)(scatter ? idx[r] : r) * kLatent;
-    reinterpret_cast<f32x4*>(d + b)[lane] = reinterpret_cast<const f32x4*>(s + a)[lane];
-    reinterpret_cast<f32x4*>(d + b)[64 + lane] = reinterpret_cast<const f32x4*>(s + a)[64 + lane];
+    f32x4 v0 = reinterpret_cast<const f32x4*>(s + a)[lane], v1 = reinterpret_cast<const f32x4*>(s + a)[64 + lane];
+    if (scatter == 2) {                                      // dst[idx[r]] += src[r] (the list's rows are distinct: no atomics)
+      v0 += reinterpret_cast<const f32x4*>(d + b)[lane];
+      v1 += reinterpret_cast<const f32x4*>(d + b)[64 + lane];
+    }
+    reinterpret_cast<f32x4*>(d + b)[lane] = v0;
+    reinterpret_cast<f32x4*>(d + b)[64 + lane] = v1;
+  }
+}
+// dst[idx[r]] = 0 for r < *count (rows of 512 floats)
+__global__ __launch_bounds__(256) void k_zero_rows(float* __restrict__ dst, const int* __restrict__ idx, const int* __restrict__ count) {
+  const int n = *count, lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+    f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)idx[r] * kLatent);
+    d[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    d[64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+// seg[s] = rows of list segment s: clamp(*count - s cap, 0, cap)
+__global__ void k_segment_counts(const int* __restrict__ count, int cap, int n_seg, int* __restrict__ seg) {
+  const int s = threadIdx.x;
+  if (s < n_seg) {
+    const int left = *count - s * cap;
+    seg[s] = left < 0 ? 0 : (left > cap ? cap : left);
   }
 }
 
@@ -980,7 +1005,7 @@ using namespace diner::train;
 
 static int gemm_launch(const float* A, const float* B, float* C, long long M, int N, int K, int lda, int ldb, int ldc,
                        int flags, const float* bias, const float* mask, int k_split, hipStream_t stream,
-                       const float* resid = nullptr, float* rowsum = nullptr, const int* gate = nullptr) {
+                       const float* resid = nullptr, float* rowsum = nullptr, const int* gate = nullptr, const int* k_dev = nullptr) {
   DINER_CHECK_ARG(A && B && C, "gemm: null pointer argument");
   DINER_CHECK_ARG(!gate || !(flags & kExact), "gemm: a gated launch runs on the bf16x6 kernel");
   DINER_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad sizes M=%lld N=%d K=%d", M, N, K);
@@ -995,7 +1020,8 @@ static int gemm_launch(const float* A, const float* B, float* C, long long M, in
   chunk = (chunk + XK - 1) / XK * XK;               // (a multiple of every kernel's k-tile)
   static const bool no_xcd = [] { const char* e = getenv("DINER_TRAIN_NO_XCD"); return e && *e == '1'; }();
   if (no_xcd) flags |= kNoXcdOrder;
-  GemmArgs g{A, B, C, bias, mask, resid, rowsum, M, N, K, lda, ldb, ldc, flags, chunk, gate};
+  DINER_CHECK_ARG(!k_dev || !(flags & kExact), "gemm: a device-side contraction length runs on the bf16x6 kernel");
+  GemmArgs g{A, B, C, bias, mask, resid, rowsum, M, N, K, lda, ldb, ldc, flags, chunk, gate, k_dev};
   if (!(flags & kExact)) {
     // split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6); ragged and skinny shapes (lin_out: N = 4,
     // its adjoints: K = 4 / M = 4) ride along zero-padded -- a partly empty 128 x 128 tile is still faster than the fp32 kernels
@@ -1618,7 +1644,8 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
 // per-view tensor are [o cols, (o + 1) cols), of a post-mean tensor [o P, (o + 1) P)): the layer products run ONCE over all rows; per object
 // only the view-mean adjoint and the scatter of the latent gradient into that object's feature-map gradient d_latent_cl[o] (or null)
 static int backward_core(const DinerScene* const* scenes, int n_obj, const DinerMlpParams* p, const DinerMlpParams* grads, long long P_obj,
-                         const float* d_out, float* ws, float* sc, const TrainWs& w, float* const* d_latent_cl, hipStream_t st) {
+                         const float* d_out, float* ws, float* sc, const TrainWs& w, float* const* d_latent_cl, hipStream_t st,
+                         float* map_scratch = nullptr) {
   int rc = 0;
   const DinerScene* scene = scenes[0];
   const long long P = P_obj * n_obj;
@@ -1666,6 +1693,90 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
   // saved pre-activations themselves, A/B measurement)
   static const bool maskbits_on = [] { const char* e = getenv("DINER_TRAIN_MASKBITS"); return !(e && *e == '0'); }();
   auto bits = [&](size_t off) { return maskbits_on ? reinterpret_cast<const unsigned*>(ws + off) : nullptr; };
+  // ---- round 6: the adjoint of the three lin_z terms in MAP space ------------------------------------------------------------------------
+  // X_b = in_b + interp(lin_z[b](latent map)) (the forward's hoist), so with D_b = the gradient of X_b scattered through the bilinear taps into
+  // map shape:  dWz_b = D_b^T L,  dbz_b = column sums of D_b,  d latent = sum_b D_b Wz_b  -- over the TEXEL rows the batch touches (2.4 % of a
+  // 400 x 300 map: 5.5 k rows per object) instead of three data-gradient and three weight-gradient products over the 2.6 M per-view sample
+  // rows (20 ms of the 120 ms step) + the gather of the interpolated latent.  Per block and object: zero the touched rows of one map-shaped
+  // plane (map_scratch: the forward's projection buffer, free in the backward), scatter dx into it (the merged-tap scatter that served d_lat),
+  // then per list segment: gather D and L rows, dWz += D^T L and dbz (general bf16x6 GEMM, split-K with atomics, contraction length on the
+  // device), T = D Wz (k_lin512_rows), d_latent_cl[rows] += T.  The list (mark / compact) is rebuilt from the saved tap rows; segments of
+  // `cap` rows (what the object's share of the d_lat region holds in three buffers) cover any count without a host decision.
+  // DINER_TRAIN_LINZ_MAPSPACE=0: the round-5 products over the sample rows.
+  const char* e_ms = getenv("DINER_TRAIN_LINZ_MAPSPACE");
+  bool mapspace = map_scratch && !(e_ms && *e_ms == '0') && use_lin512() && cols_obj >= 4096;
+  for (int o = 0; o < n_obj && mapspace; ++o)
+    mapspace = scenes[o]->latent_cl && scenes[o]->C == kLatent && (long long)scenes[o]->nv * scenes[o]->Hf * scenes[o]->Wf < (1ll << 30) &&
+               (!d_latent_cl || !d_latent_cl[o] || (reinterpret_cast<size_t>(d_latent_cl[o]) & 15) == 0);
+  struct ObjList { int* idx; int* cnt; int* seg; float* Dc; float* Lc; float* Tc; long long rows, cap; int n_seg; };
+  ObjList ol[64];
+  if (mapspace) {
+    for (int o = 0; o < n_obj; ++o) {
+      ObjList& L = ol[o];
+      L.rows = (long long)scenes[o]->nv * scenes[o]->Hf * scenes[o]->Wf;
+      float* base = sc + w.d_lat + (size_t)o * cols_obj * kLatent;          // the object's share of the d_lat region (cols_obj x 512 floats), unused in this mode
+      int* mark = reinterpret_cast<int*>(base);
+      L.idx = mark + L.rows;
+      L.cnt = L.idx + L.rows;                                                // [0] marked rows, [1] unused, [2 ..] segment counts
+      L.seg = L.cnt + 2;
+      const long long ints = 2 * L.rows + 64 + 64;
+      L.cap = (cols_obj - (ints + 511) / 512 - 2) / 3;
+      if (L.cap < 64) { mapspace = false; break; }
+      L.n_seg = (int)((L.rows + L.cap - 1) / L.cap);
+      if (L.n_seg > 60) { mapspace = false; break; }
+      L.Dc = base + ((ints + 511) / 512 + 1) * 512;
+      L.Lc = L.Dc + (size_t)L.cap * kLatent;
+      L.Tc = L.Lc + (size_t)L.cap * kLatent;
+    }
+  }
+  if (mapspace) {
+    for (int o = 0; o < n_obj; ++o) {
+      ObjList& L = ol[o];
+      int* mark = L.idx - L.rows;
+      DINER_HIP_OK(hipMemsetAsync(mark, 0, (size_t)L.rows * sizeof(int), st));
+      DINER_HIP_OK(hipMemsetAsync(L.cnt, 0, 128 * sizeof(int), st));
+      hipLaunchKernelGGL(k_mark_rows, dim3(grid1d(cols_obj * 4)), dim3(256), 0, st, (const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4, cols_obj * 4, mark);
+      hipLaunchKernelGGL(k_compact_rows, dim3(grid1d(L.rows)), dim3(256), 0, st, mark, (int)L.rows, (int)L.rows, L.idx, L.cnt, L.cnt + 1);
+      hipLaunchKernelGGL(k_segment_counts, dim3(1), dim3(64), 0, st, L.cnt, (int)L.cap, L.n_seg, L.seg);
+      if (d_latent_cl && d_latent_cl[o]) DINER_HIP_OK(hipMemsetAsync(d_latent_cl[o], 0, (size_t)L.rows * kLatent * sizeof(float), st));
+    }
+    for (int b = 0; b < 3; ++b) {
+      DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_z_w[b], 0, (size_t)kHidden * kLatent * sizeof(float), st));
+      DINER_HIP_OK(hipMemsetAsync((void*)grads->lin_z_b[b], 0, (size_t)kHidden * sizeof(float), st));
+    }
+    DINER_LAUNCH_OK();
+  }
+  auto linz_backward_mapspace = [&](int b, const float* dxb) -> int {
+    for (int o = 0; o < n_obj; ++o) {
+      ObjList& L = ol[o];
+      float* D = map_scratch;                                                // one map-shaped plane (rows x 512), dense; only the touched rows are used
+      hipLaunchKernelGGL(k_zero_rows, dim3(1024), dim3(256), 0, st, D, L.idx, L.cnt);
+      int r = scatter_latent_launch(dxb + (size_t)o * cols_obj * kHidden, (const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4,
+                                    ws + w.tap_w + (size_t)o * cols_obj * 4, cols_obj, D, st);
+      if (r) return r;
+      for (int sgi = 0; sgi < L.n_seg; ++sgi) {
+        const int* n_dev = L.seg + sgi;
+        const int* ix = L.idx + (size_t)sgi * L.cap;
+        hipLaunchKernelGGL(k_move_rows, dim3(1024, 1), dim3(256), 0, st, (const float*)D, L.Dc, ix, n_dev, (int)L.cap, 0, (size_t)0, (size_t)0, (const int*)nullptr);
+        hipLaunchKernelGGL(k_move_rows, dim3(1024, 1), dim3(256), 0, st, (const float*)scenes[o]->latent_cl, L.Lc, ix, n_dev, (int)L.cap, 0, (size_t)0, (size_t)0,
+                           (const int*)nullptr);
+        // dWz_b (512 f x 512 k) += Dc^T Lc over the segment's rows, dbz_b += column sums of Dc: op(A) = Dc^T (kTA), contraction length on the device
+        long long split = (L.cap + 511) / 512;
+        split = split < 1 ? 1 : (split > 512 ? 512 : split);
+        if ((r = gemm_launch(L.Dc, L.Lc, (float*)grads->lin_z_w[b], kHidden, kLatent, (int)L.cap, kHidden, kLatent, kLatent, kTA | kAtomic, nullptr, nullptr,
+                             (int)split, st, nullptr, (float*)grads->lin_z_b[b], nullptr, n_dev))) return r;
+        if (d_latent_cl && d_latent_cl[o]) {
+          Lin512Args a{L.Dc, wpack_slot(ws, w, kSlotLinZ + b, true), L.Tc, nullptr, nullptr, nullptr, L.cap, kHidden, kLatent, 0};
+          a.m_dev = n_dev;
+          if ((r = lin512_launch(a, st))) return r;
+          hipLaunchKernelGGL(k_move_rows, dim3(1024, 1), dim3(256), 0, st, (const float*)L.Tc, d_latent_cl[o], ix, n_dev, (int)L.cap, 2, (size_t)0, (size_t)0,
+                             (const int*)nullptr);
+        }
+      }
+    }
+    DINER_LAUNCH_OK();
+    return 0;
+  };
   for (int b = 4; b >= 0; --b) {
     const long long M = b < 3 ? cols : P;
     const float* X = ws + w.X[b];
@@ -1679,9 +1790,11 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
                          kHidden, kHidden, dx, X, true, st, wt(p->fc0_w[b], kSlotFc0 + b), part(kSlotFc0 + b), job(),
                          arith(kSlotFc0 + b, a_h, a_x), bits(w.bX[b])))) return rc;
     a_cur = a_x;
-    if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
-                                  (float*)grads->lin_z_b[b], M, kHidden, kLatent, sc + w.d_lat, nullptr, b < 2, st,
-                                  wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job(), arith(kSlotLinZ + b, a_cur, -1)))) return rc;
+    if (b < 3 && mapspace) {
+      if ((rc = linz_backward_mapspace(b, dx))) return rc;
+    } else if (b < 3 && (rc = linear_bwd(dx, kHidden, ws + w.lat, kLatent, false, p->lin_z_w[b], (float*)grads->lin_z_w[b],
+                                         (float*)grads->lin_z_b[b], M, kHidden, kLatent, sc + w.d_lat, nullptr, b < 2, st,
+                                         wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job(), arith(kSlotLinZ + b, a_cur, -1)))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
       const int a_b = a_next++;
       for (int o = 0; o < n_obj; ++o)
@@ -1706,7 +1819,7 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
       if (jobs.job[i].part) jobs.job[n++] = jobs.job[i];
     if ((rc = wgrad512_reduce_many(jobs, n, true, st))) return rc;
   }
-  for (int o = 0; o < n_obj; ++o) {
+  for (int o = 0; o < n_obj && !mapspace; ++o) {
     if (!d_latent_cl || !d_latent_cl[o]) continue;
     DINER_HIP_OK(hipMemsetAsync(d_latent_cl[o], 0, (size_t)scenes[o]->nv * scenes[o]->Hf * scenes[o]->Wf * kLatent * sizeof(float), st));
     if ((rc = scatter_latent_launch(sc + w.d_lat + (size_t)o * cols_obj * kLatent, (const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4,
@@ -1794,12 +1907,13 @@ extern "C" int diner_field_train_forward_batch_f32(const DinerScene* const* scen
 
 extern "C" int diner_field_train_backward_batch_f32(const DinerScene* const* scenes, int n_obj, const DinerMlpParams* p, const DinerMlpParams* grads,
                                                     long long P, const float* d_out, void* saved, void* scratch, float* const* d_latent_cl,
-                                                    void* stream) {
+                                                    float* map_scratch, void* stream) {
   int rc = check_batch(scenes, n_obj, P);
   if (rc) return rc;
   DINER_CHECK_ARG(d_out && saved && scratch, "field_train_backward_batch: null pointer argument");
   if ((rc = check_train_params(p, false))) return rc;
   if ((rc = check_train_params(grads, false))) return rc;
   const TrainWs wt = train_ws(P * n_obj, scenes[0]->nv);
-  return backward_core(scenes, n_obj, p, grads, P, d_out, (float*)saved, (float*)scratch, wt, d_latent_cl, (hipStream_t)stream);
+  DINER_CHECK_ARG((reinterpret_cast<size_t>(map_scratch) & 15) == 0, "field_train_backward_batch: map_scratch must be 16-byte aligned");
+  return backward_core(scenes, n_obj, p, grads, P, d_out, (float*)saved, (float*)scratch, wt, d_latent_cl, (hipStream_t)stream, map_scratch);
 }

@@ -339,8 +339,10 @@ class FieldBatchFunction(torch.autograd.Function):
             _lib.check(lib.diner_field_train_batch_workspace_split(ctx.P, ctx.scenes[0].nv, SB, C.byref(a), C.byref(b)))
             scratch = _shared(_SCRATCH, dev, int(b.value))
             dl = (C.c_void_p * SB)(*[d_cl[o].data_ptr() if want_lat else None for o in range(SB)])
+            # the forward's projection buffer is free in the backward: one map-shaped plane of it carries the lin_z adjoint in map space
+            proj = _shared(_PROJ, dev, max(int(lib.diner_scene_proj_bytes(sc.ref)) for sc in ctx.scenes), zero=True)
             _lib.check(lib.diner_field_train_backward_batch_f32(ctx.arr, SB, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out), _ptr(ws), _ptr(scratch),
-                                                                dl, _stream()))
+                                                                dl, _ptr(proj), _stream()))
             d_lat = None
             if want_lat:                     # channels-last -> the encoder's (SB, nv, C, Hf, Wf), contiguous: autograd takes it as it is
                 sb, nv, Cc, Hf, Wf = ctx.latent_shape

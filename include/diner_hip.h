@@ -345,13 +345,18 @@ int diner_field_train_fused_overflowed(const void* workspace, long long P, int n
  * diner_scene_proj_bytes; reused object after object) and runs the fused storing kernels with the gated layer-wise repeat behind them.
  * backward: the 13 x (data gradient, weight gradient) products ONCE over n_obj x P x nv rows -- n_obj times fewer launches, one partial-tile
  * sum, weight gradients of the step summed in-kernel -- then per object the scatter into d_latent_cl[o] (HOST array of n_obj device
- * pointers, entries or the array may be NULL).  DINER_E_UNSUPPORTED as diner_field_train_forward_fused_f32 (before anything is enqueued). */
+ * pointers, entries or the array may be NULL).  map_scratch (or NULL): one map-shaped plane, diner_scene_proj_bytes / 3 bytes of the largest
+ * object (the forward's latent_proj_scratch serves) -- with it the adjoint of the three lin_z terms runs in MAP space over the texel rows the
+ * batch touches (dWz_b = D_b^T L, d latent = sum_b D_b Wz_b with D_b = the stream's gradient scattered through the bilinear taps) instead of
+ * six products over the per-view sample rows; NULL: those products.  DINER_E_UNSUPPORTED as diner_field_train_forward_fused_f32 (before
+ * anything is enqueued). */
 int diner_field_train_batch_workspace_split(long long P, int nv, int n_obj, size_t* saved_bytes, size_t* scratch_bytes);
 int diner_field_train_forward_batch_f32(const DinerScene* const* scenes, int n_obj, DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
                                         const float* viewdirs, long long P, float* out, void* saved, void* scratch,
                                         float* latent_proj_scratch, void* stream);
 int diner_field_train_backward_batch_f32(const DinerScene* const* scenes, int n_obj, const DinerMlpParams* p, const DinerMlpParams* grads,
-                                         long long P, const float* d_out, void* saved, void* scratch, float* const* d_latent_cl, void* stream);
+                                         long long P, const float* d_out, void* saved, void* scratch, float* const* d_latent_cl,
+                                         float* map_scratch, void* stream);
 /* Test aid: float offsets into the training workspace of the pre-activations the forward saved -- [0..4] X_b, the residual stream
  * entering block b (P*nv rows of 512 for b < 3, P rows behind the view mean), [5..9] H_b, the fc_0 outputs of block b, [10] the
  * stream entering lin_out (P x 512), [11] lin_out's raw outputs (P x 4).  The signs of these values are the relu decisions of the
