@@ -508,7 +508,8 @@ __global__ __launch_bounds__(256) void k_train_inputs(SceneDev sc, FieldArgs fa,
 // lat[col][c] = sum_k w_k latent_cl[row_k][c]      (SpatialEncoder.index, bilinear / border, image_encoder.py:97-146)
 __global__ __launch_bounds__(256) void k_gather_latent(const float* __restrict__ latent_cl, const int* __restrict__ tap_row,
                                                        const float* __restrict__ tap_w, long long cols,
-                                                       float* __restrict__ lat) {
+                                                       float* __restrict__ lat, const int* __restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;
   const long long col = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (col >= cols) return;
   const int lane = threadIdx.x & 63;
@@ -1073,8 +1074,16 @@ extern "C" int diner_wgrad512_f32(const float* dY, const float* X, float* dW, fl
   return wgrad512_launch(dY, ldy, X, ldx, relu_x != 0, dW, db, M, (hipStream_t)stream, static_cast<float*>(scratch));
 }
 
+// gather: also the interpolated latent rows (`lat`: the operand of the layer-wise lin_z products and of their sample-space adjoint; the fused
+// forward with the map-space adjoint needs it only in its gated repeat)
+static int train_inputs(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P, float freq_factor, float* feat, int* tap_row,
+                        float* tap_w, float* lat, void* stream, bool gather);
 extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P,
                                       float freq_factor, float* feat, int* tap_row, float* tap_w, float* lat, void* stream) {
+  return train_inputs(scene, xyz, viewdirs, P, freq_factor, feat, tap_row, tap_w, lat, stream, true);
+}
+static int train_inputs(const DinerScene* scene, const float* xyz, const float* viewdirs, long long P, float freq_factor, float* feat, int* tap_row,
+                        float* tap_w, float* lat, void* stream, bool gather) {
   DINER_CHECK_ARG(scene && xyz && viewdirs && feat && tap_row && tap_w && lat, "train_inputs: null pointer argument");
   DINER_CHECK_ARG(P > 0, "train_inputs: P must be positive");
   SceneDev sd;
@@ -1092,8 +1101,9 @@ extern "C" int diner_train_inputs_f32(const DinerScene* scene, const float* xyz,
   hipLaunchKernelGGL(k_train_inputs, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sd, fa, feat,
                      tap_row, tap_w);
   const long long cols = P * sd.nv;
-  hipLaunchKernelGGL(k_gather_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)scene->latent_cl, tap_row, tap_w, cols, lat);
+  if (gather)
+    hipLaunchKernelGGL(k_gather_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scene->latent_cl, tap_row, tap_w, cols, lat, (const int*)nullptr);
   DINER_LAUNCH_OK();
   return 0;
 }
@@ -1358,10 +1368,14 @@ extern "C" int diner_field_train_ws_layout(long long P, int nv, long long* float
 // object's view of the step's workspace (obj_view below; wpack and flags are the step's).  pack: pack the step's weights and clear the flag block
 // (the first object of a step; gate == null only).
 static int forward_layerwise(const DinerScene* scene, const DinerMlpParams* p, const float* xyz, const float* viewdirs, long long P,
-                             float* out, float* ws, float* sc, const TrainWs& w, void* stream, const int* gate, bool pack = true) {
+                             float* out, float* ws, float* sc, const TrainWs& w, void* stream, const int* gate, bool pack = true,
+                             bool lat_missing = false) {
   int rc = 0;
   hipStream_t st = (hipStream_t)stream;
   const long long cols = P * scene->nv;
+  if (gate && lat_missing)      // the repeat behind a fused forward that skipped the gather: the interpolated latent rows, only if the repeat runs
+    hipLaunchKernelGGL(k_gather_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, (const float*)scene->latent_cl,
+                       (const int*)(ws + w.tap_row), ws + w.tap_w, cols, ws + w.lat, gate);
   if (!gate) {
     rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
     if (rc) return rc;
@@ -1512,11 +1526,12 @@ enum { kFlagFusedOvf = 14 };
 int field_forward_save_supported(const DinerScene* scene, const DinerMlp* mlp);
 // one object of a step: its inputs, (first: the step's packed weights + flag block,) its projected maps, the fused kernels, the gated repeat
 static int fused_forward_core(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz, const float* viewdirs,
-                              long long P, float* out, float* ws, float* sc, const TrainWs& w, float* latent_proj_out, hipStream_t st, bool first) {
+                              long long P, float* out, float* ws, float* sc, const TrainWs& w, float* latent_proj_out, hipStream_t st, bool first,
+                              bool gather_lat = true) {
   int rc = field_forward_save_supported(scene, mlp);      // host-known reasons to keep the layer-wise forward: before anything is enqueued
   if (rc) return rc;
   void* stream = (void*)st;
-  rc = diner_train_inputs_f32(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream);
+  rc = train_inputs(scene, xyz, viewdirs, P, p->freq_factor, ws + w.feat, (int*)(ws + w.tap_row), ws + w.tap_w, ws + w.lat, stream, gather_lat);
   if (rc) return rc;
   if (first) {   // packed weights of the backward's products + the flag block, as the layer-wise forward leaves them
     PackMany pm;
@@ -1605,7 +1620,7 @@ static int fused_forward_core(const DinerScene* scene, const DinerMlp* mlp, cons
   hipLaunchKernelGGL(k_copy_flag, dim3(1), dim3(1), 0, st, ovf, reinterpret_cast<int*>(ws + w.flags) + kFlagFusedOvf);
   DINER_LAUNCH_OK();
   // the exact repeat, on the device: the layer-wise forward behind the flag (its ~25 launches return at once when it stayed down)
-  return forward_layerwise(scene, p, xyz, viewdirs, P, out, ws, sc, w, stream, reinterpret_cast<const int*>(ws + w.flags) + kFlagFusedOvf);
+  return forward_layerwise(scene, p, xyz, viewdirs, P, out, ws, sc, w, stream, reinterpret_cast<const int*>(ws + w.flags) + kFlagFusedOvf, true, !gather_lat);
 }
 
 extern "C" int diner_field_train_forward_fused_f32(const DinerScene* scene, const DinerMlp* mlp, const DinerMlpParams* p, const float* xyz,
@@ -1645,7 +1660,7 @@ extern "C" int diner_field_train_backward_f32(const DinerScene* scene, const Din
 // only the view-mean adjoint and the scatter of the latent gradient into that object's feature-map gradient d_latent_cl[o] (or null)
 static int backward_core(const DinerScene* const* scenes, int n_obj, const DinerMlpParams* p, const DinerMlpParams* grads, long long P_obj,
                          const float* d_out, float* ws, float* sc, const TrainWs& w, float* const* d_latent_cl, hipStream_t st,
-                         float* map_scratch = nullptr) {
+                         float* map_scratch = nullptr, bool lat_missing = false) {
   int rc = 0;
   const DinerScene* scene = scenes[0];
   const long long P = P_obj * n_obj;
@@ -1746,6 +1761,11 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
     }
     DINER_LAUNCH_OK();
   }
+  if (!mapspace && lat_missing)      // the batched forward skipped the interpolated latent rows: the sample-space adjoint reads them
+    for (int o = 0; o < n_obj; ++o)
+      hipLaunchKernelGGL(k_gather_latent, dim3((unsigned)((cols_obj + 3) / 4)), dim3(256), 0, st, (const float*)scenes[o]->latent_cl,
+                         (const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4, ws + w.tap_w + (size_t)o * cols_obj * 4, cols_obj,
+                         ws + w.lat + (size_t)o * cols_obj * kLatent, (const int*)nullptr);
   auto linz_backward_mapspace = [&](int b, const float* dxb) -> int {
     for (int o = 0; o < n_obj; ++o) {
       ObjList& L = ol[o];
@@ -1899,8 +1919,10 @@ extern "C" int diner_field_train_forward_batch_f32(const DinerScene* const* scen
   const TrainWs wt = train_ws(P * n_obj, nv);
   for (int o = 0; o < n_obj; ++o) {
     const TrainWs w = obj_view(wt, P, nv, o);
+    // (no gather of the interpolated latent rows: the batched backward's map-space lin_z adjoint does not read them, its sample-space
+    // fall-back gathers them itself, the gated layer-wise repeat gathers behind its gate)
     if ((rc = fused_forward_core(scenes[o], mlp, p, xyz + (size_t)o * P * 3, viewdirs + (size_t)o * P * 3, P, out + (size_t)o * P * 4, ws,
-                                 (float*)scratch, w, latent_proj_scratch, (hipStream_t)stream, o == 0))) return rc;
+                                 (float*)scratch, w, latent_proj_scratch, (hipStream_t)stream, o == 0, /*gather_lat=*/false))) return rc;
   }
   return 0;
 }
@@ -1915,5 +1937,5 @@ extern "C" int diner_field_train_backward_batch_f32(const DinerScene* const* sce
   if ((rc = check_train_params(grads, false))) return rc;
   const TrainWs wt = train_ws(P * n_obj, scenes[0]->nv);
   DINER_CHECK_ARG((reinterpret_cast<size_t>(map_scratch) & 15) == 0, "field_train_backward_batch: map_scratch must be 16-byte aligned");
-  return backward_core(scenes, n_obj, p, grads, P, d_out, (float*)saved, (float*)scratch, wt, d_latent_cl, (hipStream_t)stream, map_scratch);
+  return backward_core(scenes, n_obj, p, grads, P, d_out, (float*)saved, (float*)scratch, wt, d_latent_cl, (hipStream_t)stream, map_scratch, /*lat_missing=*/true);
 }

@@ -459,7 +459,7 @@ def test_scatter_latent_merged_and_layout_pass_against_torch():
         assert torch.equal(dst, src.permute(0, 3, 1, 2).contiguous()), (n, H, W, C)
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["layerwise", "fused_forward"])
+@pytest.mark.parametrize("fused", [False, True, "batched"], ids=["layerwise", "fused_forward", "fused_forward_batched_node"])
 def test_training_forward_beyond_the_fp16_range(ops, fused, monkeypatch):
     """fused_forward (the default since round 5): the storing inference kernels raise their flag and the host repeats the object on the
     layer-wise forward.  The layer-wise training forward runs its 512 x 512 products in the f16x3 arithmetic first; an operand beyond the fp16 range raises the product's
@@ -485,9 +485,13 @@ def test_training_forward_beyond_the_fp16_range(ops, fused, monkeypatch):
                       sc["image_shape"], sc["feature_padding"])
     latent = sc["latent"].detach().cuda().requires_grad_(True)
     params, names = module_param_list(big)
-    out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
+    if fused == "batched":      # round 6: the one-node path skips the gather of the interpolated latent rows -- the gated repeat gathers them behind
+        out = train.field_train_batch([hs], xyz.cuda()[None], dirs.cuda()[None], latent[None], params)[0]      # its gate, the backward's sample-space
+        assert "Batch" in type(out.grad_fn).__name__ or "Batch" in type(out.grad_fn.next_functions[0][0]).__name__   # lin_z adjoint (300 points) regathers
+    else:
+        out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
     assert torch.isfinite(out).all()
-    if fused:       # the fused kernels did raise their flag: what is compared below is the gated layer-wise repeat
+    if fused is True:       # the fused kernels did raise their flag: what is compared below is the gated layer-wise repeat
         import ctypes as C
         from diner_amd import _lib
         ovf = C.c_int(0)
