@@ -554,7 +554,7 @@ typedef float f32x2s __attribute__((ext_vector_type(2)));
 template <int COLS>
 __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __restrict__ d_lat, const int* __restrict__ tap_row,
                                                                const float* __restrict__ tap_w, long long cols,
-                                                               float* __restrict__ d_latent_cl) {
+                                                               float* __restrict__ d_latent_cl, const int* __restrict__ perm) {
   constexpr int NT = 4 * COLS;                                                    // taps of the workgroup (threads 0 .. NT - 1 own one each)
   extern __shared__ __attribute__((aligned(16))) char smem_scat[];
   f32x2s* dl = reinterpret_cast<f32x2s*>(smem_scat);                             // [COLS][256] pairs of channels
@@ -564,10 +564,11 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   __shared__ unsigned char s_tcol[NT];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long long col0 = (long long)blockIdx.x * COLS;
-  const long long mycol = col0 + (t >> 2);
+  const long long mypos = col0 + (t >> 2);
   int id = -1;
   float w = 0.0f;
-  if (t < NT && mycol < cols) {
+  if (t < NT && mypos < cols) {
+    const long long mycol = perm ? perm[mypos] : mypos;        // round 6: the columns in the order of a list sorted by texel (see k_fill_perm)
     id = tap_row[mycol * 4 + (t & 3)];
     w = tap_w[mycol * 4 + (t & 3)];
     if (w == 0.0f) id = -1;
@@ -579,8 +580,10 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   }
   // (2) the block of d_lat, COLS rows of 2 KB (rows past the end: never referenced)
   const long long last = cols - col0 < COLS ? cols - col0 : COLS;
-  for (int g = 0; g < (int)last; ++g)
-    dl[g * 256 + t] = *reinterpret_cast<const f32x2s*>(d_lat + (size_t)(col0 + g) * kLatent + 2 * t);
+  for (int g = 0; g < (int)last; ++g) {
+    const long long c = perm ? perm[col0 + g] : col0 + g;
+    dl[g * 256 + t] = *reinterpret_cast<const f32x2s*>(d_lat + (size_t)c * kLatent + 2 * t);
+  }
   __syncthreads();
   // (1) leaders, slots
   int leader = t;
@@ -634,7 +637,8 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   }
 }
 template <int COLS>
-static int scatter_merged_launch(const float* d_lat, const int* tap_row, const float* tap_w, long long cols, float* d_latent_cl, hipStream_t st) {
+static int scatter_merged_launch(const float* d_lat, const int* tap_row, const float* tap_w, long long cols, float* d_latent_cl, hipStream_t st,
+                                 const int* perm) {
   static std::atomic<int> attr_set[64];
   int dev = 0;
   DINER_HIP_OK(hipGetDevice(&dev));
@@ -644,17 +648,73 @@ static int scatter_merged_launch(const float* d_lat, const int* tap_row, const f
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_scatter_latent_merged<COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set[dev].store(1);
   }
-  hipLaunchKernelGGL(k_scatter_latent_merged<COLS>, dim3((unsigned)((cols + COLS - 1) / COLS)), dim3(256), lds, st, d_lat, tap_row, tap_w, cols, d_latent_cl);
+  hipLaunchKernelGGL(k_scatter_latent_merged<COLS>, dim3((unsigned)((cols + COLS - 1) / COLS)), dim3(256), lds, st, d_lat, tap_row, tap_w, cols, d_latent_cl, perm);
   DINER_LAUNCH_OK();
   return 0;
 }
-int scatter_latent_launch(const float* d_lat, const int* tap_row, const float* tap_w, long long cols, float* d_latent_cl, hipStream_t st) {
+// round 6: the columns of one object sorted by the texel row of their first tap (counting sort: histogram, exclusive scan in two kernels,
+// fill).  A 64 x 64 patch of rays x 40 samples x 4 views names 2.6 M taps on 11.5 k texel rows -- 227 taps per row -- but 32 CONSECUTIVE
+// columns (most of one ray in one view) still fall on ~30 distinct texels, so the merged scatter issued 605 k row-atomics per launch
+// (1.24 GB of atomic traffic beside the 1.34 GB it reads).  32 columns that are neighbours in the sorted order share their 2 x 2 footprint.
+// The order inside a key is the atomics' (as the float atomics' own order: the sums differ in the last bits between runs, as before).
+__global__ __launch_bounds__(256) void k_hist_first_tap(const int* __restrict__ tap_row, long long cols, int* __restrict__ hist) {
+  for (long long c = blockIdx.x * 256ll + threadIdx.x; c < cols; c += gridDim.x * 256ll) atomicAdd(hist + tap_row[c * 4], 1);
+}
+constexpr int kScanBlock = 2048;       // elements per workgroup of the scan (8 per thread)
+__global__ __launch_bounds__(256) void k_scan_sums(const int* __restrict__ v, int n, int* __restrict__ sums) {
+  __shared__ int s_w[4];
+  const int base = blockIdx.x * kScanBlock + threadIdx.x * 8;
+  int a = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a += base + i < n ? v[base + i] : 0;
+  for (int o = 32; o; o >>= 1) a += __shfl_xor(a, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// v[i] <- sum of v[0 .. i) : the workgroup's base = the sums of the workgroups before it (a few hundred values), then a scan of its 2048
+__global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ v, int n, const int* __restrict__ sums) {
+  __shared__ int s_w[4], s_base[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int b = 0;
+  for (int i = t; i < (int)blockIdx.x; i += 256) b += sums[i];
+  for (int o = 32; o; o >>= 1) b += __shfl_xor(b, o);
+  if (lane == 0) s_base[wave] = b;
+  const int base = blockIdx.x * kScanBlock + t * 8;
+  int x[8], a = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { x[i] = base + i < n ? v[base + i] : 0; a += x[i]; }
+  int incl = a;
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int run = s_base[0] + s_base[1] + s_base[2] + s_base[3] + incl - a;
+  for (int i = 0; i < wave; ++i) run += s_w[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { if (base + i < n) v[base + i] = run; run += x[i]; }
+}
+__global__ __launch_bounds__(256) void k_fill_perm(const int* __restrict__ tap_row, long long cols, int* __restrict__ offs, int* __restrict__ perm) {
+  for (long long c = blockIdx.x * 256ll + threadIdx.x; c < cols; c += gridDim.x * 256ll) perm[atomicAdd(offs + tap_row[c * 4], 1)] = (int)c;
+}
+// perm (cols ints) from the taps; hist: rows ints (destroyed), sums: (rows + 2047) / 2048 ints
+static int sort_columns_by_texel(const int* tap_row, long long cols, long long rows, int* hist, int* sums, int* perm, hipStream_t st) {
+  DINER_HIP_OK(hipMemsetAsync(hist, 0, (size_t)rows * sizeof(int), st));
+  const unsigned nb = (unsigned)((rows + kScanBlock - 1) / kScanBlock);
+  hipLaunchKernelGGL(k_hist_first_tap, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, tap_row, cols, hist);
+  hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, st, (const int*)hist, (int)rows, sums);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, hist, (int)rows, (const int*)sums);
+  hipLaunchKernelGGL(k_fill_perm, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, tap_row, cols, hist, perm);
+  DINER_LAUNCH_OK();
+  return 0;
+}
+int scatter_latent_launch(const float* d_lat, const int* tap_row, const float* tap_w, long long cols, float* d_latent_cl, hipStream_t st,
+                          const int* perm = nullptr) {
   static const bool merged = [] { const char* e = getenv("DINER_TRAIN_SCATTER_MERGED"); return !(e && *e == '0'); }();
   static const int ncols = [] { const char* e = getenv("DINER_TRAIN_SCATTER_COLS"); return e ? atoi(e) : 32; }();      // same-box A/B 64 / 32 / 16: 123.6 / 121.9 / 122.2 ms per SB 4 step (profiles/r06_train_scatter_cols_ab.txt)
   if (merged && (reinterpret_cast<size_t>(d_lat) & 7) == 0) {
-    if (ncols == 16) return scatter_merged_launch<16>(d_lat, tap_row, tap_w, cols, d_latent_cl, st);
-    if (ncols == 32) return scatter_merged_launch<32>(d_lat, tap_row, tap_w, cols, d_latent_cl, st);
-    return scatter_merged_launch<64>(d_lat, tap_row, tap_w, cols, d_latent_cl, st);
+    if (ncols == 16) return scatter_merged_launch<16>(d_lat, tap_row, tap_w, cols, d_latent_cl, st, perm);
+    if (ncols == 32) return scatter_merged_launch<32>(d_lat, tap_row, tap_w, cols, d_latent_cl, st, perm);
+    return scatter_merged_launch<64>(d_lat, tap_row, tap_w, cols, d_latent_cl, st, perm);
   }
   hipLaunchKernelGGL(k_scatter_latent, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, d_lat, tap_row, tap_w, cols, d_latent_cl);
   DINER_LAUNCH_OK();
@@ -1723,7 +1783,8 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
   for (int o = 0; o < n_obj && mapspace; ++o)
     mapspace = scenes[o]->latent_cl && scenes[o]->C == kLatent && (long long)scenes[o]->nv * scenes[o]->Hf * scenes[o]->Wf < (1ll << 30) &&
                (!d_latent_cl || !d_latent_cl[o] || (reinterpret_cast<size_t>(d_latent_cl[o]) & 15) == 0);
-  struct ObjList { int* idx; int* cnt; int* seg; float* Dc; float* Lc; float* Tc; long long rows, cap; int n_seg; };
+  struct ObjList { int* idx; int* cnt; int* seg; int* perm; int* hist; float* Dc; float* Lc; float* Tc; long long rows, cap; int n_seg; };
+  static const bool sort_cols = [] { const char* e = getenv("DINER_TRAIN_SCATTER_SORTED"); return !(e && *e == '0'); }();
   ObjList ol[64];
   if (mapspace) {
     for (int o = 0; o < n_obj; ++o) {
@@ -1734,11 +1795,13 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
       L.idx = mark + L.rows;
       L.cnt = L.idx + L.rows;                                                // [0] marked rows, [1] unused, [2 ..] segment counts
       L.seg = L.cnt + 2;
-      const long long ints = 2 * L.rows + 64 + 64;
+      L.hist = L.seg + 64;                                                   // [rows] histogram -> offsets, [2048] sums of the scan's workgroups
+      L.perm = L.hist + L.rows + 2048;                                       // [cols_obj] the columns sorted by texel (sort_columns_by_texel)
+      const long long ints = 3 * L.rows + cols_obj + 64 + 64 + 2048;
       L.cap = (cols_obj - (ints + 511) / 512 - 2) / 3;
       if (L.cap < 64) { mapspace = false; break; }
       L.n_seg = (int)((L.rows + L.cap - 1) / L.cap);
-      if (L.n_seg > 60) { mapspace = false; break; }
+      if (L.n_seg > 60 || L.rows > 2048ll * kScanBlock) { mapspace = false; break; }
       L.Dc = base + ((ints + 511) / 512 + 1) * 512;
       L.Lc = L.Dc + (size_t)L.cap * kLatent;
       L.Tc = L.Lc + (size_t)L.cap * kLatent;
@@ -1753,6 +1816,8 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
       hipLaunchKernelGGL(k_mark_rows, dim3(grid1d(cols_obj * 4)), dim3(256), 0, st, (const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4, cols_obj * 4, mark);
       hipLaunchKernelGGL(k_compact_rows, dim3(grid1d(L.rows)), dim3(256), 0, st, mark, (int)L.rows, (int)L.rows, L.idx, L.cnt, L.cnt + 1);
       hipLaunchKernelGGL(k_segment_counts, dim3(1), dim3(64), 0, st, L.cnt, (int)L.cap, L.n_seg, L.seg);
+      if (sort_cols && (rc = sort_columns_by_texel((const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4, cols_obj, L.rows, L.hist, L.hist + L.rows, L.perm, st)))
+        return rc;
       if (d_latent_cl && d_latent_cl[o]) DINER_HIP_OK(hipMemsetAsync(d_latent_cl[o], 0, (size_t)L.rows * kLatent * sizeof(float), st));
     }
     for (int b = 0; b < 3; ++b) {
@@ -1772,7 +1837,7 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
       float* D = map_scratch;                                                // one map-shaped plane (rows x 512), dense; only the touched rows are used
       hipLaunchKernelGGL(k_zero_rows, dim3(1024), dim3(256), 0, st, D, L.idx, L.cnt);
       int r = scatter_latent_launch(dxb + (size_t)o * cols_obj * kHidden, (const int*)(ws + w.tap_row) + (size_t)o * cols_obj * 4,
-                                    ws + w.tap_w + (size_t)o * cols_obj * 4, cols_obj, D, st);
+                                    ws + w.tap_w + (size_t)o * cols_obj * 4, cols_obj, D, st, sort_cols ? L.perm : nullptr);
       if (r) return r;
       for (int sgi = 0; sgi < L.n_seg; ++sgi) {
         const int* n_dev = L.seg + sgi;
