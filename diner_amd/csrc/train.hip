@@ -551,45 +551,94 @@ __global__ __launch_bounds__(256) void k_scatter_latent(const float* __restrict_
 // share a CU (DINER_TRAIN_SCATTER_COLS, default below; consecutive columns are samples along one ray, so the texel merge still finds its
 // duplicates within 16-32 columns).
 typedef float f32x2s __attribute__((ext_vector_type(2)));
+#ifdef DINER_L512_PROF
+__device__ unsigned long long g_scat_prof[8];      // clocks of thread 0 per phase: [0] load issue + taps, [1] wait for the block, [2] leaders .. sort, [3] sums + atomics, [4] workgroups
+#define SCAT_T(i) do { if (t == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_scat_prof[i], now_ - pt_); pt_ = now_; } } while (0)
+#else
+#define SCAT_T(i) do { } while (0)
+#endif
 template <int COLS>
 __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __restrict__ d_lat, const int* __restrict__ tap_row,
                                                                const float* __restrict__ tap_w, long long cols,
                                                                float* __restrict__ d_latent_cl, const int* __restrict__ perm) {
+  // round 6, from the kernel's phase timer (55 k clocks per workgroup: 36 k in the load loop -- a dynamic trip count, one 8-byte load per
+  // thread and trip, each waited for -- 5 k in a serial leader search + a one-thread prefix sum, 13 k in the sums, one texel after the
+  // other with 256 threads x 2 channels): (2) all of the block's rows requested at once, 16 bytes per lane; (1) the leader = the smallest
+  // matching index from a vectorised compare against all taps, the prefix sum by one wave; (3) a WAVE per texel (64 lanes x 8 channels,
+  // four taps per trip): four texels in flight per workgroup.
   constexpr int NT = 4 * COLS;                                                    // taps of the workgroup (threads 0 .. NT - 1 own one each)
+  constexpr int NL = COLS / 2;                                                    // row requests per thread: a trip brings two rows (128 lanes x 16 B each)
   extern __shared__ __attribute__((aligned(16))) char smem_scat[];
-  f32x2s* dl = reinterpret_cast<f32x2s*>(smem_scat);                             // [COLS][256] pairs of channels
-  __shared__ int s_id[NT], s_uniq[NT], s_start[NT + 1], s_fill[NT], s_wave_n[4];
-  __shared__ float s_w[NT], s_tw[NT];
+  float* dl = reinterpret_cast<float*>(smem_scat);                               // [COLS][512]
+  __shared__ __attribute__((aligned(16))) int s_id[NT];
+  __shared__ int s_uniq[NT], s_start[NT + 1], s_fill[NT], s_wave_n[4];
+  __shared__ float s_tw[NT];
   __shared__ short s_lead_slot[NT];
   __shared__ unsigned char s_tcol[NT];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const long long col0 = (long long)blockIdx.x * COLS;
-  const long long mypos = col0 + (t >> 2);
-  int id = -1;
-  float w = 0.0f;
-  if (t < NT && mypos < cols) {
-    const long long mycol = perm ? perm[mypos] : mypos;        // round 6: the columns in the order of a list sorted by texel (see k_fill_perm)
-    id = tap_row[mycol * 4 + (t & 3)];
-    w = tap_w[mycol * 4 + (t & 3)];
-    if (w == 0.0f) id = -1;
-  }
+#ifdef DINER_L512_PROF
+  const bool no_atomics = g_scat_prof[7] != 0;               // measurement switch, read once in front of everything
+  unsigned long long pt_ = __builtin_readcyclecounter();
+#endif
+  // (2) the block of d_lat, COLS rows of 2 KB (rows past the end: the last row again, never referenced).  round 6: the workgroup walks
+  // blocks blockIdx.x, + gridDim.x, ... and requests block i + 1 (rows into registers, its own tap) in front of the phases of block i:
+  // a workgroup per block spent 31 k of its 46 k clocks waiting for its rows with nothing else to do
+  const long long nblk = (cols + COLS - 1) / COLS;
+  const int half = t >> 7, q = t & 127;
+  f32x4 v[NL];
+  int id_n = -1;
+  float w_n = 0.0f;
+  auto request = [&](long long blk) {
+    const long long col0 = blk * COLS;
+    const int last = (int)(cols - col0 < COLS ? cols - col0 : COLS);
+    long long src[NL];
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int g = 2 * it + half;
+      const long long pos = col0 + (g < last ? g : last - 1);
+      src[it] = perm ? (long long)perm[pos] : pos;       // round 6: the columns in the order of a list sorted by texel (see k_fill_perm)
+    }
+#pragma unroll
+    for (int it = 0; it < NL; ++it) v[it] = *reinterpret_cast<const f32x4*>(d_lat + (size_t)src[it] * kLatent + 4 * q);
+    const long long mypos = col0 + (t >> 2);
+    id_n = -1;
+    w_n = 0.0f;
+    if (t < NT && mypos < cols) {
+      const long long mycol = perm ? perm[mypos] : mypos;
+      id_n = tap_row[mycol * 4 + (t & 3)];
+      w_n = tap_w[mycol * 4 + (t & 3)];
+      if (w_n == 0.0f) id_n = -1;
+    }
+  };
+  if ((long long)blockIdx.x < nblk) request(blockIdx.x);
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  const int id = id_n;
+  const float w = w_n;
   if (t < NT) {
     s_id[t] = id;
-    s_w[t] = w;
     s_fill[t] = 0;
   }
-  // (2) the block of d_lat, COLS rows of 2 KB (rows past the end: never referenced)
-  const long long last = cols - col0 < COLS ? cols - col0 : COLS;
-  for (int g = 0; g < (int)last; ++g) {
-    const long long c = perm ? perm[col0 + g] : col0 + g;
-    dl[g * 256 + t] = *reinterpret_cast<const f32x2s*>(d_lat + (size_t)c * kLatent + 2 * t);
-  }
+  SCAT_T(0);
+#pragma unroll
+  for (int it = 0; it < NL; ++it) *reinterpret_cast<f32x4*>(dl + (2 * it + half) * kLatent + 4 * q) = v[it];
   __syncthreads();
+  if (blk + gridDim.x < nblk) request(blk + gridDim.x);
+  SCAT_T(1);
   // (1) leaders, slots
   int leader = t;
-  if (id >= 0)
-    for (int j = 0; j < t; ++j)
-      if (s_id[j] == id) { leader = j; break; }
+  if (id >= 0) {
+    int best = NT;
+#pragma unroll 8
+    for (int j4 = 0; j4 < NT / 4; ++j4) {
+      const int4 o = reinterpret_cast<const int4*>(s_id)[j4];
+      int m = o.w == id ? 4 * j4 + 3 : NT;
+      m = o.z == id ? 4 * j4 + 2 : m;
+      m = o.y == id ? 4 * j4 + 1 : m;
+      m = o.x == id ? 4 * j4 : m;
+      best = m < best ? m : best;
+    }
+    leader = best;                                             // <= t: the tap matches itself
+  }
   const bool is_leader = id >= 0 && leader == t;
   const unsigned long long ball = __ballot(is_leader);
   if (lane == 0) s_wave_n[wave] = __popcll(ball);
@@ -605,14 +654,32 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   const int slot = id >= 0 ? (int)s_lead_slot[leader] : -1;
   if (slot >= 0) atomicAdd(&s_fill[slot], 1);               // taps per texel
   __syncthreads();
-  if (t == 0) {                                              // exclusive prefix over <= NT counts (a few hundred cycles once per workgroup)
-    int run = 0;
-    for (int i = 0; i < n_unique; ++i) {
-      s_start[i] = run;
-      run += s_fill[i];
-      s_fill[i] = 0;
+  if (wave == 0) {                                           // exclusive prefix over <= NT counts: PER consecutive counts per lane, a wave scan
+    constexpr int PER = (NT + 63) / 64;
+    int x[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = lane * PER + k;
+      x[k] = i < n_unique ? s_fill[i] : 0;
+      sum += x[k];
     }
-    s_start[n_unique] = run;
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    int run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = lane * PER + k;
+      if (i < n_unique) {
+        s_start[i] = run;
+        s_fill[i] = 0;
+      }
+      run += x[k];
+    }
+    if (lane == 63) s_start[n_unique] = run;
   }
   __syncthreads();
   if (slot >= 0) {
@@ -621,19 +688,63 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
     s_tw[at] = w;
   }
   __syncthreads();
-  // (3) one sum and one atomic per distinct texel and channel
-  for (int sl = 0; sl < n_unique; ++sl) {
+  SCAT_T(2);
+  // (3) one sum and one atomic per distinct texel and channel: wave `wave` takes texels wave, wave + 4, ...; a lane owns channels
+  // [4 lane, +4) and [256 + 4 lane, +4) (16-byte LDS reads, lanes 16 bytes apart); four taps per trip, a trip past the texel's end repeats
+  // its last tap with weight 0
+  for (int sl = wave; sl < n_unique; sl += 4) {
     const int b = s_start[sl], e = s_start[sl + 1];
-    f32x2s a = {0.f, 0.f};
-    for (int i = b; i < e; ++i) {
-      const f32x2s d = dl[(int)s_tcol[i] * 256 + t];
-      const float wk = s_tw[i];
-      a[0] = fmaf(wk, d[0], a[0]);
-      a[1] = fmaf(wk, d[1], a[1]);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    for (int i = b; i < e; i += 4) {
+      int c[4];
+      float wk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int at = i + k < e ? i + k : e - 1;
+        c[k] = (int)s_tcol[at];
+        wk[k] = i + k < e ? s_tw[at] : 0.0f;
+      }
+      f32x4 d0[4], d1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d0[k] = *reinterpret_cast<const f32x4*>(dl + c[k] * kLatent + 4 * lane);
+        d1[k] = *reinterpret_cast<const f32x4*>(dl + c[k] * kLatent + 256 + 4 * lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] = fmaf(wk[0], d0[0][j], a0[j]);
+        a1[j] = fmaf(wk[0], d1[0][j], a1[j]);
+        b0[j] = fmaf(wk[1], d0[1][j], b0[j]);
+        b1[j] = fmaf(wk[1], d1[1][j], b1[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] = fmaf(wk[2], d0[2][j], a0[j]);
+        a1[j] = fmaf(wk[2], d1[2][j], a1[j]);
+        b0[j] = fmaf(wk[3], d0[3][j], b0[j]);
+        b1[j] = fmaf(wk[3], d1[3][j], b1[j]);
+      }
     }
-    float* dst = d_latent_cl + (size_t)s_uniq[sl] * kLatent + 2 * t;
-    atomicAdd(dst, a[0]);
-    atomicAdd(dst + 1, a[1]);
+    a0 += b0;
+    a1 += b1;
+    float* dst = d_latent_cl + (size_t)s_uniq[sl] * kLatent + 4 * lane;
+#ifdef DINER_L512_PROF
+    if (no_atomics) {                                        // measurement: the kernel without its atomics (one plain store per wave and texel keeps the sums alive)
+      if (a0[0] + a0[1] + a0[2] + a0[3] + a1[0] + a1[1] + a1[2] + a1[3] == 12345.678f) dst[0] = 1.0f;
+      continue;
+    }
+#endif
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      atomicAdd(dst + j, a0[j]);
+      atomicAdd(dst + 256 + j, a1[j]);
+    }
+  }
+  SCAT_T(3);
+#ifdef DINER_L512_PROF
+  if (t == 0) atomicAdd(&g_scat_prof[4], 1ull);
+#endif
+  __syncthreads();                                           // the block and the lists are free for the next trip
   }
 }
 template <int COLS>
@@ -643,12 +754,21 @@ static int scatter_merged_launch(const float* d_lat, const int* tap_row, const f
   int dev = 0;
   DINER_HIP_OK(hipGetDevice(&dev));
   dev &= 63;
-  constexpr int lds = COLS * 256 * (int)sizeof(f32x2s);      // the COLS x 512 block of d_lat
+  constexpr int lds = COLS * kLatent * (int)sizeof(float);      // the COLS x 512 block of d_lat
   if (!attr_set[dev].load()) {
     DINER_HIP_OK(hipFuncSetAttribute((const void*)k_scatter_latent_merged<COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set[dev].store(1);
   }
-  hipLaunchKernelGGL(k_scatter_latent_merged<COLS>, dim3((unsigned)((cols + COLS - 1) / COLS)), dim3(256), lds, st, d_lat, tap_row, tap_w, cols, d_latent_cl, perm);
+  static const int per_cu = [] { const char* e = getenv("DINER_TRAIN_SCATTER_WG_PER_CU"); return e ? atoi(e) : 64 / COLS; }();      // workgroups per CU walking the blocks (what LDS holds); 0: a workgroup per block (no walk)
+  static std::atomic<int> cus[64];
+  if (per_cu > 0 && !cus[dev].load()) {
+    int c = 0;
+    DINER_HIP_OK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+    cus[dev].store(c > 0 ? c : 256);
+  }
+  const long long nblk = (cols + COLS - 1) / COLS;
+  const long long grid = per_cu > 0 && (long long)per_cu * cus[dev].load() < nblk ? (long long)per_cu * cus[dev].load() : nblk;
+  hipLaunchKernelGGL(k_scatter_latent_merged<COLS>, dim3((unsigned)grid), dim3(256), lds, st, d_lat, tap_row, tap_w, cols, d_latent_cl, perm);
   DINER_LAUNCH_OK();
   return 0;
 }
@@ -710,8 +830,10 @@ static int sort_columns_by_texel(const int* tap_row, long long cols, long long r
 int scatter_latent_launch(const float* d_lat, const int* tap_row, const float* tap_w, long long cols, float* d_latent_cl, hipStream_t st,
                           const int* perm = nullptr) {
   static const bool merged = [] { const char* e = getenv("DINER_TRAIN_SCATTER_MERGED"); return !(e && *e == '0'); }();
-  static const int ncols = [] { const char* e = getenv("DINER_TRAIN_SCATTER_COLS"); return e ? atoi(e) : 32; }();      // same-box A/B 64 / 32 / 16: 123.6 / 121.9 / 122.2 ms per SB 4 step (profiles/r06_train_scatter_cols_ab.txt)
-  if (merged && (reinterpret_cast<size_t>(d_lat) & 7) == 0) {
+  // same-box A/B, SB 4 step, round 6 (profiles/r06_train_scatter_*): 64 / 32 / 16 columns with the one-block workgroups of the first version 123.6 /
+  // 121.9 / 122.2 ms; with sorted columns and the rewritten phases 102.2 / 102.7 / 108.5; 64 columns + one walking workgroup per CU 101.8
+  static const int ncols = [] { const char* e = getenv("DINER_TRAIN_SCATTER_COLS"); return e ? atoi(e) : 64; }();
+  if (merged && (reinterpret_cast<size_t>(d_lat) & 15) == 0) {
     if (ncols == 16) return scatter_merged_launch<16>(d_lat, tap_row, tap_w, cols, d_latent_cl, st, perm);
     if (ncols == 32) return scatter_merged_launch<32>(d_lat, tap_row, tap_w, cols, d_latent_cl, st, perm);
     return scatter_merged_launch<64>(d_lat, tap_row, tap_w, cols, d_latent_cl, st, perm);
@@ -2004,3 +2126,15 @@ extern "C" int diner_field_train_backward_batch_f32(const DinerScene* const* sce
   DINER_CHECK_ARG((reinterpret_cast<size_t>(map_scratch) & 15) == 0, "field_train_backward_batch: map_scratch must be 16-byte aligned");
   return backward_core(scenes, n_obj, p, grads, P, d_out, (float*)saved, (float*)scratch, wt, d_latent_cl, (hipStream_t)stream, map_scratch, /*lat_missing=*/true);
 }
+
+#ifdef DINER_L512_PROF
+extern "C" int diner_debug_scatter_prof(unsigned long long* out8, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(diner::train::g_scat_prof), 8 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, reset == 2 ? 1ull : 0ull};      // reset == 2: the following launches without their atomics
+    hipMemcpyToSymbol(HIP_SYMBOL(diner::train::g_scat_prof), z, sizeof(z));
+  }
+  return 0;
+}
+#endif

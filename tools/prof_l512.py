@@ -81,7 +81,7 @@ try:
     gt = torch.rand(1, NR, 3, device=dev)
     ren = R(n_samples=K, n_depth_candidates=1000, n_gaussian=15, white_bkgd=True)
     a8 = (C.c_ulonglong * 8)()
-    for rep in range(2):
+    for rep in range(4):
         for p in nerf.parameters():
             p.grad = None
         nerf.encoder.latent.grad = None
@@ -94,5 +94,14 @@ try:
             print(f"k_wgrad512_w8 over the step: waves {waves:.0f}, slabs/wave {slabs / waves:.0f}; clocks per 32-row slab {tot / slabs:.0f} = slab section "
                   f"{mf / slabs:.0f} + barrier {bar / slabs:.0f} + rest {(tot - mf - bar) / slabs:.0f}  (MFMA issue alone: 48 x 32 = 1536 clocks per wave and slab, two waves per SIMD: 3072)",
                   flush=True)
+        try:      # the merged latent-gradient scatter (k_scatter_latent_merged): thread 0's clocks per phase
+            raw.diner_debug_scatter_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+            raw.diner_debug_scatter_prof(a8, 2 if rep == 1 else 1)      # third step: the scatter without its atomics (wrong gradients, a measurement)
+            n = float(a8[4])
+            if n:
+                print(("(no atomics) " if rep == 2 else "") + "k_scatter_latent_merged over the step: %.0f workgroups; clocks per workgroup: issue loads %.0f, wait for the block %.0f, "
+                      "leaders / sort %.0f, sums + atomics %.0f" % (n, a8[0] / n, a8[1] / n, a8[2] / n, a8[3] / n), flush=True)
+        except AttributeError:
+            pass
 except AttributeError:
     pass
