@@ -389,8 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
   const long long m0 = (long long)by * XM;
   const int n0 = bx * XN;
   const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
-  const int kbeg = bz * g.k_chunk, kend = min(Keff, kbeg + g.k_chunk);
-  if (kbeg >= kend) return;                                   // (k_dev: the chunks past the list's end)
+  if (bz * g.k_chunk >= Keff) return;                         // (k_dev: the chunks past the list's end)
   const bool ta = g.flags & kTA, tb = g.flags & kTB, ra = g.flags & kReluA, rb = g.flags & kReluB;
   // op(A) is M x K: stored [M][lda] (contraction contiguous) unless kTA; op(B) is K x N: stored [K][ldb] (output contiguous) unless kTB
   const bool a_kc = !ta, b_kc = tb;
@@ -402,10 +401,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   TileRegs ra_t, rb_t;
-  tile_fetch(ra_t, g.A, g.lda, a_kc, m0, g.M, kbeg, kend, ra, tid);
-  tile_fetch(rb_t, g.B, g.ldb, b_kc, n0, g.N, kbeg, kend, rb, tid);
   const bool do_rowsum = EPI == 2 && g.rowsum && bx == 0;          // (one N-tile column of workgroups sums the rows of op(A))
   float rs0 = 0.0f, rs1 = 0.0f;
+  // round 6: the workgroup takes chunks bz, bz + gridDim.z, ... into ONE accumulator (a launch covers K in gridDim.z chunks and this loop runs
+  // once, except a device-side contraction length: there the host sizes the grid for a few dozen chunk walkers instead of one workgroup
+  // per chunk of the list's capacity -- 6816 workgroups of which 368 had work, at ~10 ns of dispatch each)
+  for (int kbeg = bz * g.k_chunk; kbeg < Keff; kbeg += (int)gridDim.z * g.k_chunk) {
+  const int kend = min(Keff, kbeg + g.k_chunk);
+  tile_fetch(ra_t, g.A, g.lda, a_kc, m0, g.M, kbeg, kend, ra, tid);
+  tile_fetch(rb_t, g.B, g.ldb, b_kc, n0, g.N, kbeg, kend, rb, tid);
   for (int k0 = kbeg; k0 < kend; k0 += XK) {
     __syncthreads();                                   // the previous tile's fragment reads are done
     if (EPI == 2 && do_rowsum) {                       // op(A) stored [K][lda]: this thread holds rows 2 (tid % 64), +1, 8 contraction indices
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x6(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
         }
     }
+  }
   }
   if (EPI == 2 && do_rowsum) {
     const long long row = m0 + 2 * (tid & 63);
@@ -1208,7 +1213,11 @@ static int gemm_launch(const float* A, const float* B, float* C, long long M, in
   if (!(flags & kExact)) {
     // split-bf16 on the bf16 matrix pipe (fp32-class products, see k_gemm_bf16x6); ragged and skinny shapes (lin_out: N = 4,
     // its adjoints: K = 4 / M = 4) ride along zero-padded -- a partly empty 128 x 128 tile is still faster than the fp32 kernels
-    const dim3 grid((N + XN - 1) / XN, (unsigned)((M + XM - 1) / XM), (K + chunk - 1) / chunk);
+    dim3 grid((N + XN - 1) / XN, (unsigned)((M + XM - 1) / XM), (K + chunk - 1) / chunk);
+    if (k_dev) {                                                // chunk walkers (see the kernel's chunk loop)
+      static const int walkers = [] { const char* e = getenv("DINER_TRAIN_GEMM_WALKERS"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();      // same-box A/B chunk x walkers, SB 4 step: one workgroup per 512-row chunk 102.7 ms, 128 x 64 100.5, 64 x 96 101.0, 256 x 32 100.1, 512 x 24 100.3, 128 x 128 101.6
+      if (grid.z > (unsigned)walkers) grid.z = walkers;
+    }
     if (resid) hipLaunchKernelGGL(k_gemm_bf16x6<1>, grid, dim3(256), 0, stream, g);
     else if (rowsum) hipLaunchKernelGGL(k_gemm_bf16x6<2>, grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL(k_gemm_bf16x6<0>, grid, dim3(256), 0, stream, g);
@@ -1968,8 +1977,11 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
         hipLaunchKernelGGL(k_move_rows, dim3(1024, 1), dim3(256), 0, st, (const float*)scenes[o]->latent_cl, L.Lc, ix, n_dev, (int)L.cap, 0, (size_t)0, (size_t)0,
                            (const int*)nullptr);
         // dWz_b (512 f x 512 k) += Dc^T Lc over the segment's rows, dbz_b += column sums of Dc: op(A) = Dc^T (kTA), contraction length on the device
-        long long split = (L.cap + 511) / 512;
-        split = split < 1 ? 1 : (split > 512 ? 512 : split);
+        // (contraction chunks of `linz_chunk` rows: the list holds ~11 k of the segment's 200 k rows, so the chunk sets how many workgroups have
+        // work -- 512 rows: 1.4 per CU, each waiting for its operand tiles alone, 0.24 ms per product)
+        static const int linz_chunk = [] { const char* e = getenv("DINER_TRAIN_LINZ_CHUNK"); const int v = e ? atoi(e) : 256; return v < 16 ? 16 : v; }();
+        long long split = (L.cap + linz_chunk - 1) / linz_chunk;
+        split = split < 1 ? 1 : (split > 8192 ? 8192 : split);
         if ((r = gemm_launch(L.Dc, L.Lc, (float*)grads->lin_z_w[b], kHidden, kLatent, (int)L.cap, kHidden, kLatent, kLatent, kTA | kAtomic, nullptr, nullptr,
                              (int)split, st, nullptr, (float*)grads->lin_z_b[b], nullptr, n_dev))) return r;
         if (d_latent_cl && d_latent_cl[o]) {
