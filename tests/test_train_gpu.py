@@ -487,7 +487,8 @@ def test_training_forward_beyond_the_fp16_range(ops, fused, monkeypatch):
     params, names = module_param_list(big)
     if fused == "batched":      # round 6: the one-node path skips the gather of the interpolated latent rows -- the gated repeat gathers them behind
         out = train.field_train_batch([hs], xyz.cuda()[None], dirs.cuda()[None], latent[None], params)[0]      # its gate, the backward's sample-space
-        assert "Batch" in type(out.grad_fn).__name__ or "Batch" in type(out.grad_fn.next_functions[0][0]).__name__   # lin_z adjoint (300 points) regathers
+        if os.environ.get("DINER_TRAIN_BATCH", "") != "0":                                                              # lin_z adjoint (300 points) regathers
+            assert "Batch" in type(out.grad_fn).__name__ or "Batch" in type(out.grad_fn.next_functions[0][0]).__name__
     else:
         out = train.field_train(hs, xyz.cuda(), dirs.cuda(), latent, params)
     assert torch.isfinite(out).all()
