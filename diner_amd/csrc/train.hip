@@ -977,6 +977,37 @@ __global__ void k_view_bcast(const float* __restrict__ dy, int nv, long long PC,
   }
 }
 
+// round 6: behind the view mean every view's rows of dy are the same row (the broadcast), so block 2's fc_1 data gradient (dy W) is ONE
+// product per point: T sits in the rows of view 0 (rows [0, P) of the object, PC = P x 512 floats), this kernel writes view v's rows
+// T x [relu decision of H[v]] for v = nv - 1 .. 0 (view 0 in place: the same thread read its four floats before).  bits: the layout of
+// k_make_bits (16 dwords per row); the maximum of what is stored goes to amax_out (atomic, slot zeroed by the step).
+__global__ __launch_bounds__(256) void k_mask_views(float* __restrict__ dH, const unsigned* __restrict__ bits, int nv, long long P,
+                                                    unsigned* __restrict__ amax_out) {
+  float m = 0.0f;
+  const long long n4 = P * (kHidden / 4);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+    const long long row = i >> 7;
+    const int j = (int)(i & 127);                             // features 4 j .. 4 j + 3: dword 4 (j / 32) + j % 4, bits 4 ((j / 4) % 8) + c
+    const f32x4 t = *reinterpret_cast<const f32x4*>(dH + (size_t)row * kHidden + 4 * j);
+    const int dw = 4 * (j >> 5) + (j & 3), sh = 4 * ((j >> 2) & 7);
+    for (int v = nv - 1; v >= 0; --v) {
+      const size_t r = (size_t)v * P + row;
+      const unsigned nib = bits[r * 16 + dw] >> sh;
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        o[c] = (nib >> c) & 1u ? t[c] : 0.0f;
+        m = fmaxf(m, fabsf(o[c]));
+      }
+      *reinterpret_cast<f32x4*>(dH + r * kHidden + 4 * j) = o;
+    }
+  }
+  if (amax_out) {
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(amax_out, __float_as_uint(m));
+  }
+}
+
 // db[n] += sum_m dY[m][n]
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, long long M, int N, int ld, float* __restrict__ db) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -2001,6 +2032,31 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
     const float* X = ws + w.X[b];
     const float* H = ws + w.H[b];
     const int a_h = a_next++;                                 // dH = (dx W1) masked
+    // round 6: behind the view mean (b == 2) dx is the same row for every view: the product once per point, the views differ in their mask only
+    // (k_mask_views) -- a quarter of the rows of this data gradient; the weight gradient keeps all rows.  DINER_TRAIN_VIEW_SHARED=0: as every block
+    static const bool view_shared_on = [] { const char* e = getenv("DINER_TRAIN_VIEW_SHARED"); return !(e && *e == '0'); }();
+    const bool view_shared = b == 2 && view_shared_on && bwd16 && maskbits_on && scene->nv > 1 && P_obj >= 256 &&
+                             lin512_ok(dx, kHidden, dH, kHidden, nullptr, nullptr);
+    if (view_shared) {
+      if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
+                           kHidden, kHidden, nullptr, nullptr, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job(),
+                           arith(kSlotFc1 + b, a_cur, -1), nullptr))) return rc;
+      const int a_t = a_next++;                               // the maximum of T (the product's scale bookkeeping; dH's own goes to a_h)
+      for (int o = 0; o < n_obj; ++o) {
+        const size_t off = (size_t)o * cols_obj * kHidden;
+        Lin512Args dh{dx + off, wpack_slot(ws, w, kSlotFc1 + b, true, true), dH + off, nullptr, nullptr, nullptr, P_obj, kHidden, kHidden, 0};
+        dh.amax_in = amax + a_cur;
+        dh.amax_out = amax + a_t;
+        dh.skip = flags + kFlagWBad;
+        if ((rc = lin512_launch(dh, st, 1))) return rc;
+        Lin512Args da{dx + off, wpack_slot(ws, w, kSlotFc1 + b, true), dH + off, nullptr, nullptr, nullptr, P_obj, kHidden, kHidden, 0};
+        da.gate = flags + kFlagWBad;                          // the bf16x6 twin: exactly one of the two runs
+        if ((rc = lin512_launch(da, st, 0))) return rc;
+        hipLaunchKernelGGL(k_mask_views, dim3(grid1d(P_obj * (kHidden / 4))), dim3(256), 0, st, dH + off,
+                           bits(w.bH[b]) + (size_t)o * cols_obj * 16, scene->nv, P_obj, amax + a_h);
+      }
+      DINER_LAUNCH_OK();
+    } else
     if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
                          kHidden, kHidden, dH, H, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job(),
                          arith(kSlotFc1 + b, a_cur, a_h), bits(w.bH[b])))) return rc;
