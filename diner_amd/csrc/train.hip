@@ -548,14 +548,12 @@ __global__ __launch_bounds__(256) void k_scatter_latent(const float* __restrict_
 // bilinear taps fall on a few dozen texels of the epipolar segment, and the 42 M atomics of the reference batch (200 us, 5 % of the step;
 // 3.2 ms of the 2048-ray step) become one atomic per distinct texel and channel.  A workgroup (1) finds the distinct texels of its 256 taps
 // (first occurrence = leader, compacted by a block prefix sum) and sorts the taps by texel (counting sort in LDS), (2) brings its 64 x 512
-// block of d_lat into LDS, (3) per distinct texel sums w * d_lat over that texel's taps -- a thread owns two channels, independent LDS
-// reads, no read-modify-write chain (a first version accumulated into a (slot, channel) table in LDS: one dependent LDS round trip per tap)
-// -- and adds the sum to the texel with one atomic per channel.
-// round 6: COLS columns per workgroup as a template parameter -- 64 columns stage 128 KB of d_lat in LDS, i.e. ONE workgroup per CU whose
-// load, sort and atomic phases nothing overlaps (1.7 ms per object at 4096 rays x 40 samples, 1.25 TB/s); 32 / 16 columns let 2 / 4 workgroups
-// share a CU (DINER_TRAIN_SCATTER_COLS, default below; consecutive columns are samples along one ray, so the texel merge still finds its
-// duplicates within 16-32 columns).
-typedef float f32x2s __attribute__((ext_vector_type(2)));
+// block of d_lat into LDS, (3) per distinct texel sums w * d_lat over that texel's taps -- independent LDS reads, no read-modify-write
+// chain (a first version accumulated into a (slot, channel) table in LDS: one dependent LDS round trip per tap) -- and adds the sum to the
+// texel with one atomic per channel.
+// round 6: COLS columns per workgroup as a template parameter (DINER_TRAIN_SCATTER_COLS: 64 columns stage 128 KB of d_lat in LDS = one
+// workgroup per CU, 32 / 16 columns let 2 / 4 share a CU); the map-space lin_z adjoint hands the columns over SORTED by texel (perm), where
+// 64 neighbours share a handful of texels.
 #ifdef DINER_L512_PROF
 __device__ unsigned long long g_scat_prof[8];      // clocks of thread 0 per phase: [0] load issue + taps, [1] wait for the block, [2] leaders .. sort, [3] sums + atomics, [4] workgroups
 #define SCAT_T(i) do { if (t == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_scat_prof[i], now_ - pt_); pt_ = now_; } } while (0)
@@ -586,8 +584,9 @@ __global__ __launch_bounds__(256) void k_scatter_latent_merged(const float* __re
   unsigned long long pt_ = __builtin_readcyclecounter();
 #endif
   // (2) the block of d_lat, COLS rows of 2 KB (rows past the end: the last row again, never referenced).  round 6: the workgroup walks
-  // blocks blockIdx.x, + gridDim.x, ... and requests block i + 1 (rows into registers, its own tap) in front of the phases of block i:
-  // a workgroup per block spent 31 k of its 46 k clocks waiting for its rows with nothing else to do
+  // blocks blockIdx.x, + gridDim.x, ... and requests block i + 1 (rows into registers, its own tap) in front of the phases of block i
+  // (a workgroup per block spends 31 k of its 46 k clocks waiting for its rows; measured: the walk is worth 0.5 % of the step at 64 columns
+  // x one workgroup per CU, nothing at 32 x 2 -- the memory system's rate on random 2 KB rows is the limit either way)
   const long long nblk = (cols + COLS - 1) / COLS;
   const int half = t >> 7, q = t & 127;
   f32x4 v[NL];
@@ -1946,7 +1945,8 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
     mapspace = scenes[o]->latent_cl && scenes[o]->C == kLatent && (long long)scenes[o]->nv * scenes[o]->Hf * scenes[o]->Wf < (1ll << 30) &&
                (!d_latent_cl || !d_latent_cl[o] || (reinterpret_cast<size_t>(d_latent_cl[o]) & 15) == 0);
   struct ObjList { int* idx; int* cnt; int* seg; int* perm; int* hist; float* Dc; float* Lc; float* Tc; long long rows, cap; int n_seg; };
-  static const bool sort_cols = [] { const char* e = getenv("DINER_TRAIN_SCATTER_SORTED"); return !(e && *e == '0'); }();
+  const char* e_sorted = getenv("DINER_TRAIN_SCATTER_SORTED");      // (read per call, as DINER_TRAIN_LINZ_MAPSPACE: the tests compare the routes in one process)
+  const bool sort_cols = !(e_sorted && *e_sorted == '0');
   ObjList ol[64];
   if (mapspace) {
     for (int o = 0; o < n_obj; ++o) {
@@ -2034,7 +2034,8 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
     const int a_h = a_next++;                                 // dH = (dx W1) masked
     // round 6: behind the view mean (b == 2) dx is the same row for every view: the product once per point, the views differ in their mask only
     // (k_mask_views) -- a quarter of the rows of this data gradient; the weight gradient keeps all rows.  DINER_TRAIN_VIEW_SHARED=0: as every block
-    static const bool view_shared_on = [] { const char* e = getenv("DINER_TRAIN_VIEW_SHARED"); return !(e && *e == '0'); }();
+    const char* e_vs = getenv("DINER_TRAIN_VIEW_SHARED");
+    const bool view_shared_on = !(e_vs && *e_vs == '0');
     const bool view_shared = b == 2 && view_shared_on && bwd16 && maskbits_on && scene->nv > 1 && P_obj >= 256 &&
                              lin512_ok(dx, kHidden, dH, kHidden, nullptr, nullptr);
     if (view_shared) {

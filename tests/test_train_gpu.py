@@ -789,3 +789,49 @@ def test_touched_texel_projection_equals_the_whole_map_projection(ops, monkeypat
         # sum with float atomics, so their last bits are not reproducible from run to run)
         assert max(max_norm_rel(a.cpu(), b.cpu()) for a, b in zip(gs, g0)) < 1e-5, f"{tag}: parameter gradients differ"
         assert max_norm_rel(l.cpu(), l0.cpu()) < 1e-5
+
+
+def test_backward_routes_of_round_6_agree(ops, monkeypatch):
+    """Round 6 gave the batched backward three new routes, each behind a switch read per call: the lin_z adjoint in map space over the touched
+    texel rows (DINER_TRAIN_LINZ_MAPSPACE), its scatter over columns sorted by texel (DINER_TRAIN_SCATTER_SORTED) and block 2's fc_1 data
+    gradient once per point behind the view mean (DINER_TRAIN_VIEW_SHARED).  With a switch at 0 the step runs the round-5 launch sequence for
+    that part; forward outputs are bit-equal (the forward does not change), all gradients agree to round-off (float atomics, another
+    summation order; the map-space dWz is a bf16x6 product over texel rows where the sample-space one is f16x3 over sample rows)."""
+    from diner_amd import train
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict
+    from tests.tests_train_util import module_param_list
+    from src.util.depth2normal import depth2normal
+    monkeypatch.setenv("DINER_TRAIN_FUSED_FWD", "1")
+    sc = make_scene(64, 64, seed=5)
+    sc["normals"] = depth2normal(sc["depths"], sc["src_intrinsics"])
+    Kin = sc["src_intrinsics"]
+    P = 5120                                                   # 20480 per-view rows: the map-space route takes batches of >= 4096
+    g = torch.Generator().manual_seed(13)
+    xyz = (torch.rand(P, 3, generator=g) - 0.5) * 0.2
+    dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    Gm = torch.randn(1, P, 4, generator=g).cuda()
+    msd = make_mlp_state_dict()
+    switches = ("DINER_TRAIN_LINZ_MAPSPACE", "DINER_TRAIN_SCATTER_SORTED", "DINER_TRAIN_VIEW_SHARED")
+    res = {}
+    for tag in ("default",) + switches:
+        for k in switches:
+            monkeypatch.delenv(k, raising=False)
+        if tag != "default":
+            monkeypatch.setenv(tag, "0")
+        train.release_buffers()
+        params, _ = module_param_list(msd)
+        lat = sc["latent"].cuda().requires_grad_(True)
+        scene = ops.HipScene(lat.detach(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(), sc["src_extrinsics"],
+                             Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"], sc["feature_padding"])
+        out = train.field_train_batch([scene], xyz.cuda()[None], dirs.cuda()[None], lat[None], params)
+        (out * Gm).sum().backward()
+        res[tag] = (out.detach().clone(), [p.grad.clone() for p in params], lat.grad.clone())
+    o0, g0, l0 = res["default"]
+    assert torch.isfinite(o0).all() and all(torch.isfinite(t).all() for t in g0) and torch.isfinite(l0).all()
+    for tag in switches:
+        o, gs, l = res[tag]
+        worst = max(max_norm_rel(a.cpu(), b.cpu()) for a, b in zip(gs, g0))
+        print(f"{tag}=0: worst parameter gradient {worst:.3e}, d latent {max_norm_rel(l.cpu(), l0.cpu()):.3e}")
+        assert torch.equal(o, o0), f"{tag}=0: the forward differs"
+        assert worst < 1e-5, f"{tag}=0: parameter gradients differ"      # measured 6.6e-7 - 7.6e-7
+        assert max_norm_rel(l.cpu(), l0.cpu()) < 1e-5, f"{tag}=0: latent gradient differs"      # measured 3.3e-7 - 8.9e-7
