@@ -947,6 +947,19 @@ __global__ void k_make_bits(MakeBits m, const int* __restrict__ gate) {
 }
 
 // y[p][c] = mean_v x[v][p][c]   (combine_interleaved, resnetfc.py:150-152); adjoint: dx[v][p][c] = dy[p][c] / nv
+// y = mean_v relu(x[v]) (round 6: the activation operand of block 2's fc_1 weight gradient behind the view mean, see view_shared); PC4 = P x 128
+__global__ __launch_bounds__(256) void k_view_mean_relu(const float* __restrict__ x, int nv, long long PC4, float* __restrict__ y) {
+  const float inv = 1.0f / (float)nv;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < PC4; i += gridDim.x * 256ll) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < nv; ++v) {
+      const f32x4 t = reinterpret_cast<const f32x4*>(x)[(size_t)v * PC4 + i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[c] += fmaxf(t[c], 0.0f);
+    }
+    reinterpret_cast<f32x4*>(y)[i] = s * inv;
+  }
+}
 __global__ void k_view_mean(const float* __restrict__ x, int nv, long long PC, float* __restrict__ y, const int* __restrict__ gate = nullptr) {
   if (gate && *gate == 0) return;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < PC; i += (long long)gridDim.x * blockDim.x) {
@@ -2027,6 +2040,7 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
     DINER_LAUNCH_OK();
     return 0;
   };
+  int a_mean = -1;                                            // slot of the view mean's upstream gradient (set at b == 3)
   for (int b = 4; b >= 0; --b) {
     const long long M = b < 3 ? cols : P;
     const float* X = ws + w.X[b];
@@ -2039,6 +2053,18 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
     const bool view_shared = b == 2 && view_shared_on && bwd16 && maskbits_on && scene->nv > 1 && P_obj >= 256 &&
                              lin512_ok(dx, kHidden, dH, kHidden, nullptr, nullptr);
     if (view_shared) {
+      // the weight gradient: dW = sum over (v, p) of (g[p] / nv)^T relu(H[v][p]) = g^T S with S = mean_v relu(H[v]) -- one pass over H (HBM-bound)
+      // and a product over P rows instead of P nv; db = column sums of g.  g (the view mean's upstream gradient) still sits in rows [0, P) of
+      // the buffer dH names now, S goes to its rows [P, 2 P); both are overwritten by the data gradient below.  DINER_TRAIN_VIEW_SHARED=2: all rows
+      if (a_mean >= 0 && !(e_vs && *e_vs == '2')) {
+        float* S = dH + (size_t)P * kHidden;
+        for (int o = 0; o < n_obj; ++o)
+          hipLaunchKernelGGL(k_view_mean_relu, dim3(grid1d(P_obj * (kHidden / 4))), dim3(256), 0, st, H + (size_t)o * cols_obj * kHidden, scene->nv,
+                             P_obj * (kHidden / 4), S + (size_t)o * P_obj * kHidden);
+        if ((rc = linear_bwd(dH, kHidden, S, kHidden, false, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], P,
+                             kHidden, kHidden, nullptr, nullptr, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job(),
+                             arith(kSlotFc1 + b, a_mean, -1), nullptr))) return rc;
+      } else
       if ((rc = linear_bwd(dx, kHidden, H, kHidden, true, p->fc1_w[b], (float*)grads->fc1_w[b], (float*)grads->fc1_b[b], M,
                            kHidden, kHidden, nullptr, nullptr, false, st, wt(p->fc1_w[b], kSlotFc1 + b), part(kSlotFc1 + b), job(),
                            arith(kSlotFc1 + b, a_cur, -1), nullptr))) return rc;
@@ -2073,6 +2099,7 @@ static int backward_core(const DinerScene* const* scenes, int n_obj, const Diner
                                          wt(p->lin_z_w[b], kSlotLinZ + b), part(kSlotLinZ + b), job(), arith(kSlotLinZ + b, a_cur, -1)))) return rc;
     if (b == 3) {          // adjoint of the view mean: dH is free here
       const int a_b = a_next++;
+      a_mean = a_cur;
       for (int o = 0; o < n_obj; ++o)
         hipLaunchKernelGGL(k_view_bcast, dim3(grid1d(P_obj * kHidden)), dim3(256), 0, st, dx + (size_t)o * P_obj * kHidden, scene->nv, P_obj * kHidden,
                            dH + (size_t)o * cols_obj * kHidden, bwd16 ? amax + a_cur : nullptr, bwd16 ? amax + a_b : nullptr);

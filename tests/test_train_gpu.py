@@ -794,7 +794,7 @@ def test_touched_texel_projection_equals_the_whole_map_projection(ops, monkeypat
 def test_backward_routes_of_round_6_agree(ops, monkeypatch):
     """Round 6 gave the batched backward three new routes, each behind a switch read per call: the lin_z adjoint in map space over the touched
     texel rows (DINER_TRAIN_LINZ_MAPSPACE), its scatter over columns sorted by texel (DINER_TRAIN_SCATTER_SORTED) and block 2's fc_1 data
-    gradient once per point behind the view mean (DINER_TRAIN_VIEW_SHARED).  With a switch at 0 the step runs the round-5 launch sequence for
+    gradient once per point behind the view mean + its weight gradient over view-mean activations (DINER_TRAIN_VIEW_SHARED).  With a switch at 0 the step runs the round-5 launch sequence for
     that part; forward outputs are bit-equal (the forward does not change), all gradients agree to round-off (float atomics, another
     summation order; the map-space dWz is a bf16x6 product over texel rows where the sample-space one is f16x3 over sample rows)."""
     from diner_amd import train
@@ -811,13 +811,14 @@ def test_backward_routes_of_round_6_agree(ops, monkeypatch):
     dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
     Gm = torch.randn(1, P, 4, generator=g).cuda()
     msd = make_mlp_state_dict()
-    switches = ("DINER_TRAIN_LINZ_MAPSPACE", "DINER_TRAIN_SCATTER_SORTED", "DINER_TRAIN_VIEW_SHARED")
+    names = ("DINER_TRAIN_LINZ_MAPSPACE", "DINER_TRAIN_SCATTER_SORTED", "DINER_TRAIN_VIEW_SHARED")
+    switches = tuple(n + "=0" for n in names) + ("DINER_TRAIN_VIEW_SHARED=2",)      # = 2: the data gradient once per point, the weight gradient over all rows
     res = {}
     for tag in ("default",) + switches:
-        for k in switches:
+        for k in names:
             monkeypatch.delenv(k, raising=False)
         if tag != "default":
-            monkeypatch.setenv(tag, "0")
+            monkeypatch.setenv(*tag.split("="))
         train.release_buffers()
         params, _ = module_param_list(msd)
         lat = sc["latent"].cuda().requires_grad_(True)
@@ -831,7 +832,7 @@ def test_backward_routes_of_round_6_agree(ops, monkeypatch):
     for tag in switches:
         o, gs, l = res[tag]
         worst = max(max_norm_rel(a.cpu(), b.cpu()) for a, b in zip(gs, g0))
-        print(f"{tag}=0: worst parameter gradient {worst:.3e}, d latent {max_norm_rel(l.cpu(), l0.cpu()):.3e}")
-        assert torch.equal(o, o0), f"{tag}=0: the forward differs"
-        assert worst < 1e-5, f"{tag}=0: parameter gradients differ"      # measured 6.6e-7 - 7.6e-7
-        assert max_norm_rel(l.cpu(), l0.cpu()) < 1e-5, f"{tag}=0: latent gradient differs"      # measured 3.3e-7 - 8.9e-7
+        print(f"{tag}: worst parameter gradient {worst:.3e}, d latent {max_norm_rel(l.cpu(), l0.cpu()):.3e}")
+        assert torch.equal(o, o0), f"{tag}: the forward differs"
+        assert worst < 1e-5, f"{tag}: parameter gradients differ"      # measured 6.6e-7 - 7.6e-7
+        assert max_norm_rel(l.cpu(), l0.cpu()) < 1e-5, f"{tag}: latent gradient differs"      # measured 3.3e-7 - 8.9e-7
