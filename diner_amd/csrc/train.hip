@@ -1002,17 +1002,23 @@ __global__ __launch_bounds__(256) void k_mask_views(float* __restrict__ dH, cons
     const int j = (int)(i & 127);                             // features 4 j .. 4 j + 3: dword 4 (j / 32) + j % 4, bits 4 ((j / 4) % 8) + c
     const f32x4 t = *reinterpret_cast<const f32x4*>(dH + (size_t)row * kHidden + 4 * j);
     const int dw = 4 * (j >> 5) + (j & 3), sh = 4 * ((j >> 2) & 7);
-    for (int v = nv - 1; v >= 0; --v) {
-      const size_t r = (size_t)v * P + row;
-      const unsigned nib = bits[r * 16 + dw] >> sh;
+    unsigned nb[4];                                           // (the first four views' decisions requested together, in front of the stores)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) nb[v] = v < nv ? bits[((size_t)v * P + row) * 16 + dw] : 0u;
+    auto put = [&](int v, unsigned word) {
+      const unsigned nib = word >> sh;
       f32x4 o;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         o[c] = (nib >> c) & 1u ? t[c] : 0.0f;
         m = fmaxf(m, fabsf(o[c]));
       }
-      *reinterpret_cast<f32x4*>(dH + r * kHidden + 4 * j) = o;
-    }
+      *reinterpret_cast<f32x4*>(dH + ((size_t)v * P + row) * kHidden + 4 * j) = o;
+    };
+    for (int v = nv - 1; v >= 4; --v) put(v, bits[((size_t)v * P + row) * 16 + dw]);
+#pragma unroll
+    for (int v = 3; v >= 0; --v)
+      if (v < nv) put(v, nb[v]);
   }
   if (amax_out) {
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
