@@ -297,7 +297,8 @@ def train_entry(torch, ops, dev, msd, make_scene, build_modules, n_steps, SB=4, 
     scs = [make_scene(Wt, Ht, seed=s) for s in range(SB)]
     nerf, R = build_modules(scs, msd, dev)
     nerf.train()
-    nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+    from diner_amd.synthetic import as_encoded
+    nerf.encoder.latent = as_encoded(nerf.encoder.latent.detach()).requires_grad_(True)      # channels-last strides, as PixelNeRF.encode emits it
     E = torch.stack([s["target_extrinsics"] for s in scs])
     Km = torch.stack([s["target_intrinsics"] for s in scs])
     rays_all = ops.gen_rays(E, Km, Wt, Ht, scs[0]["znear"], scs[0]["zfar"], dev)
@@ -369,7 +370,7 @@ def train_entry(torch, ops, dev, msd, make_scene, build_modules, n_steps, SB=4, 
             "batched": T.batch_enabled(P, [nerf.hip_scene(sb) for sb in range(SB)]),
             "config": {"workload": f"row f1: SB {SB} objects x {NR} rays (a {side} x {side} patch) x {K} samples ({G} gaussian, 1000 candidates), 4 source views of "
                                    f"{Wt}x{Ht}, NeRFRendererDGS.forward in grad mode + MSE + backward into the MLP parameters and encoder.latent; "
-                                   f"parameters written in place before every step", "objects": SB, "rays_per_object": NR, "samples_per_ray": K},
+                                   f"parameters written in place before every step; the latent leaf in channels-last strides, the format PixelNeRF.encode of this repo emits on the device", "objects": SB, "rays_per_object": NR, "samples_per_ray": K},
             "note": "ms_per_step = median period between the steps' first HIP events (steps enqueued back to back, nothing synchronised in "
                     "between); tflops_fp32_equivalent = 3 x the reference's forward FLOPs (forward + data gradient + weight gradient) / time; "
                     "mfma_issued = 3 fp16 MFMA products per fp32 product of the EXECUTED work (forward with lin_z hoisted to the maps, backward as the "

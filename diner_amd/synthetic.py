@@ -227,3 +227,11 @@ def realistic_mlp_state_dict(seed=4321, n_planted=3, planted_lo=10.0, planted_hi
             v = torch.randn(v.shape, generator=g) * bias_std
         out[k] = v.contiguous()
     return out
+
+
+def as_encoded(latent):
+    """A (SB, NV, C, Hf, Wf) latent in the memory format `PixelNeRF.encode` of this repo emits on a HIP device: NCHW shape, channels-last
+    strides (src/models/image_encoder.py concatenates the pyramid in that format).  Synthetic leaf latents of the training timers use it so
+    that the timed step sees the latent the way a real encoder hands it over."""
+    import torch as _t
+    return latent.flatten(0, 1).contiguous(memory_format=_t.channels_last).view(latent.shape)

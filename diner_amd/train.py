@@ -206,6 +206,23 @@ def release_buffers():
     _STEP_MLP.clear()
 
 
+def _channels_last(latent):
+    """True when a (..., C, Hf, Wf) latent already lies channels-last in memory (what PixelNeRF.encode of this repo emits on a HIP device: the
+    pyramid is concatenated in that format, image_encoder.py).  HipScene then takes it without a copy, and the backward hands autograd the
+    channels-last gradient as a view shaped like the latent instead of transposing it (round 6: 0.7 + 0.8 ms of the shipped step)."""
+    return latent.dim() >= 3 and latent.movedim(-3, -1).is_contiguous()
+
+
+def _latent_grad(d_cl, channels_last, n_img, latent_shape, dev):
+    """channels-last gradient buffer (..., Hf, Wf, C) -> the gradient autograd takes for a latent of `latent_shape` (..., C, Hf, Wf)."""
+    if channels_last:
+        return d_cl.movedim(-1, -3)
+    Cc, Hf, Wf = latent_shape[-3:]
+    d_lat = torch.empty(*latent_shape, device=dev)
+    _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), n_img, Hf * Wf, Cc, _ptr(d_lat), _stream()))
+    return d_lat
+
+
 class FieldFunction(torch.autograd.Function):
     """PixelNeRF.forward (pixelnerf.py:55-145) for one object: (xyz, viewdirs) (P,3) -> (P,4) [sigmoid rgb, relu sigma],
     differentiable with respect to the encoder's latent (NV,512,Hf,Wf) and the MLP parameters.  One library call for the
@@ -251,6 +268,7 @@ class FieldFunction(torch.autograd.Function):
             # device waits for at the start of the backward (64 us of the reference batch's 3.9 ms step)
             ctx.ps = (ps, keep)
             ctx.latent_shape = tuple(latent.shape)
+            ctx.latent_cl = _channels_last(latent)
             ctx.prealloc = FieldFunction._alloc_outputs(params, ctx.latent_shape, dev) if any(ctx.needs_input_grad) else None
         ctx.scene, ctx.P = scene, P
         ctx.save_for_backward(ws, *params)
@@ -272,10 +290,8 @@ class FieldFunction(torch.autograd.Function):
             _lib.check(lib.diner_field_train_backward_s_f32(ctx.scene.ref, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out),
                                                             _ptr(ws), _ptr(scratch), _ptr(d_cl), _stream()))
             d_lat = None
-            if d_cl is not None:             # channels-last -> the encoder's (nv, C, Hf, Wf), contiguous: autograd takes it as it is
-                nv, Cc, Hf, Wf = ctx.latent_shape
-                d_lat = torch.empty(nv, Cc, Hf, Wf, device=d_out.device)
-                _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), nv, Hf * Wf, Cc, _ptr(d_lat), _stream()))
+            if d_cl is not None:             # channels-last -> the encoder's (nv, C, Hf, Wf) in the latent's own memory format
+                d_lat = _latent_grad(d_cl, ctx.latent_cl, ctx.latent_shape[0], ctx.latent_shape, d_out.device)
         return (None, None, None, d_lat, None) + tuple(grads)
 
 
@@ -312,6 +328,7 @@ class FieldBatchFunction(torch.autograd.Function):
             mlp._range = None
             ctx.ps = (ps, keep)
             ctx.latent_shape = tuple(latent.shape)
+            ctx.latent_cl = _channels_last(latent)
             ctx.prealloc = FieldBatchFunction._alloc_outputs(params, ctx.latent_shape, dev) if any(ctx.needs_input_grad) else None
         ctx.scenes, ctx.P, ctx.arr = list(scenes), P, arr
         ctx.save_for_backward(ws, *params)
@@ -344,10 +361,8 @@ class FieldBatchFunction(torch.autograd.Function):
             _lib.check(lib.diner_field_train_backward_batch_f32(ctx.arr, SB, C.byref(ps), C.byref(gs), ctx.P, _ptr(d_out), _ptr(ws), _ptr(scratch),
                                                                 dl, _ptr(proj), _stream()))
             d_lat = None
-            if want_lat:                     # channels-last -> the encoder's (SB, nv, C, Hf, Wf), contiguous: autograd takes it as it is
-                sb, nv, Cc, Hf, Wf = ctx.latent_shape
-                d_lat = torch.empty(sb, nv, Cc, Hf, Wf, device=dev)
-                _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), sb * nv, Hf * Wf, Cc, _ptr(d_lat), _stream()))
+            if want_lat:                     # channels-last -> the encoder's (SB, nv, C, Hf, Wf) in the latent's own memory format
+                d_lat = _latent_grad(d_cl, ctx.latent_cl, ctx.latent_shape[0] * ctx.latent_shape[1], ctx.latent_shape, dev)
         return (None, None, None, d_lat, None) + tuple(grads)
 
 
@@ -487,6 +502,7 @@ class _GenericInputs(torch.autograd.Function):
             _lib.check(lib.diner_field_inputs_generic_f32(scene.ref, None, None, 0, _ptr(xyz), _ptr(viewdirs), P, int(num_freqs), int(include_input),
                                                           float(freq_factor), _ptr(zx), _stream()))
         ctx.scene, ctx.d_row, ctx.latent_shape = scene, d_row, tuple(latent.shape)
+        ctx.latent_cl = _channels_last(latent)
         ctx.save_for_backward(xyz, viewdirs)
         return zx
 
@@ -500,8 +516,7 @@ class _GenericInputs(torch.autograd.Function):
                 d_cl = torch.empty(nv, Hf, Wf, Cc, device=xyz.device)
                 _lib.check(lib.diner_field_inputs_generic_bwd_f32(ctx.scene.ref, _ptr(xyz), _ptr(viewdirs), xyz.shape[0], ctx.d_row, _ptr(_f32c(d_zx)),
                                                                   _ptr(d_cl), _stream()))
-                d_lat = torch.empty(nv, Cc, Hf, Wf, device=xyz.device)
-                _lib.check(lib.diner_channels_last_to_nchw_f32(_ptr(d_cl), nv, Hf * Wf, Cc, _ptr(d_lat), _stream()))
+                d_lat = _latent_grad(d_cl, ctx.latent_cl, nv, ctx.latent_shape, xyz.device)
         return (None, None, None, d_lat, None, None, None, None)
 
 

@@ -198,6 +198,11 @@ class SpatialEncoder(nn.Module):
             latents.append(x)
         align = None if self.index_interp == "nearest " else True
         size = latents[0].shape[-2:]
+        if x.is_cuda and getattr(self, "latent_channels_last", True):      # (the attribute: a test switch, not a constructor argument of the reference)
+            # the pyramid levels in channels-last memory format BEFORE they are upsampled (small maps; level 0 is an eighth of the latent): the
+            # interpolation and the concatenation keep the format, so the latent arrives the way the HIP kernels read it (one contiguous 2 KB
+            # row per texel) without the NCHW -> channels-last copy of a whole latent per encode, and its gradient returns the same way
+            latents = [l.contiguous(memory_format=torch.channels_last) for l in latents]
         latents = [F.interpolate(l, size, mode=self.upsample_interp, align_corners=align) for l in latents]
         lat = torch.cat(latents, dim=1)
         self.latent = lat.view(SB, NV, -1, *lat.shape[-2:])

@@ -152,6 +152,19 @@ def test_encode_then_predict_image():
         nerf.encode(imgs, sc["depths"][None].cuda(), sc["depths_std"][None].cuda(), sc["src_extrinsics"][None].cuda(),
                     sc["src_intrinsics"][None].cuda())
     assert nerf.encoder.latent.shape == (1, 4, 512, (H + 128) // 2, (W + 128) // 2)
+    # round 6: on a HIP device the pyramid is concatenated channels-last (NCHW shape, channels-last strides)
+    lat_gpu = nerf.encoder.latent
+    assert lat_gpu.movedim(-3, -1).is_contiguous()
+    nerf.encoder.latent_channels_last = False                  # the same encode with the pyramid left NCHW-contiguous: the same values
+    with torch.no_grad():
+        nerf.encode(imgs, sc["depths"][None].cuda(), sc["depths_std"][None].cuda(), sc["src_extrinsics"][None].cuda(),
+                    sc["src_intrinsics"][None].cuda())
+    assert nerf.encoder.latent.is_contiguous()
+    assert float((lat_gpu - nerf.encoder.latent).abs().max()) <= 1e-5 * float(lat_gpu.abs().max())
+    nerf.encoder.latent_channels_last = True
+    with torch.no_grad():
+        nerf.encode(imgs, sc["depths"][None].cuda(), sc["depths_std"][None].cuda(), sc["src_extrinsics"][None].cuda(),
+                    sc["src_intrinsics"][None].cuda())
     ren = import_obj("src.models.nerf_renderer.NeRFRendererDGS")(n_samples=64, n_gaussian=24, white_bkgd=True)
     torch.manual_seed(0)
     rgb, depth = predict_image(nerf, ren, sc["target_extrinsics"][None].cuda(), sc["target_intrinsics"][None].cuda(),

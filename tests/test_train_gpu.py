@@ -355,6 +355,8 @@ def test_gradient_reaches_the_image_encoder(ops):
     nerf.encode(imgs, sc["depths"][None].cuda(), sc["depths_std"][None].cuda(), sc["src_extrinsics"][None].cuda(),
                 sc["src_intrinsics"][None].cuda())
     assert nerf.encoder.latent.requires_grad
+    from diner_amd import train as _tr
+    assert _tr._channels_last(nerf.encoder.latent)      # round 6: the pyramid is concatenated channels-last on a HIP device; its gradient returns as a view in that format
     rays = gen_rays(sc["target_extrinsics"].view(1, 4, 4).cuda(), sc["target_intrinsics"].view(1, 3, 3).cuda(), W, H,
                     torch.tensor([sc["znear"]]).cuda(), torch.tensor([sc["zfar"]]).cuda()).view(1, -1, 8)
     ren = import_obj("src.models.nerf_renderer.NeRFRendererDGS")(n_samples=40, n_gaussian=15, white_bkgd=True)
@@ -836,3 +838,44 @@ def test_backward_routes_of_round_6_agree(ops, monkeypatch):
         assert torch.equal(o, o0), f"{tag}: the forward differs"
         assert worst < 1e-5, f"{tag}: parameter gradients differ"      # measured 6.6e-7 - 7.6e-7
         assert max_norm_rel(l.cpu(), l0.cpu()) < 1e-5, f"{tag}: latent gradient differs"      # measured 3.3e-7 - 8.9e-7
+
+
+def test_channels_last_latent_is_taken_and_returned_without_a_copy(ops, monkeypatch):
+    """Round 6: a latent that already lies channels-last in memory (NCHW shape, channels-last strides -- what image_encoder.py emits on a HIP
+    device) is read in place by HipScene and its gradient comes back as a view of the backward's channels-last buffer; an NCHW-contiguous latent
+    keeps the two transposing copies.  Same forward bits, same gradients (to the round-off of the scatter's atomics), on the per-object node and
+    on the batched node."""
+    from diner_amd import train
+    from diner_amd.synthetic import make_scene, make_mlp_state_dict, as_encoded
+    from tests.tests_train_util import module_param_list
+    from src.util.depth2normal import depth2normal
+    sc = make_scene(64, 64, seed=7)
+    sc["normals"] = depth2normal(sc["depths"], sc["src_intrinsics"])
+    Kin = sc["src_intrinsics"]
+    g = torch.Generator().manual_seed(17)
+    msd = make_mlp_state_dict()
+    for batched, P in ((False, 300), (True, 5120)):
+        if batched:
+            monkeypatch.setenv("DINER_TRAIN_FUSED_FWD", "1")
+        xyz = ((torch.rand(P, 3, generator=g) - 0.5) * 0.2).cuda()
+        dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).cuda()
+        Gm = torch.randn(P, 4, generator=g).cuda()
+        res = {}
+        for fmt in ("nchw", "channels_last"):
+            train.release_buffers()
+            params, _ = module_param_list(msd)
+            lat = sc["latent"].cuda()
+            if fmt == "channels_last":
+                lat = as_encoded(lat[None])[0]
+            lat.requires_grad_(True)
+            scene = ops.HipScene(lat.detach(), sc["depths"].cuda(), sc["depths_std"].cuda(), sc["normals"].cuda(), sc["src_extrinsics"],
+                                 Kin[:, [0, 1], [0, 1]], Kin[:, :2, -1], sc["image_shape"], sc["feature_padding"])
+            assert (scene.latent_cl.data_ptr() == lat.data_ptr()) == (fmt == "channels_last")
+            out = train.field_train_batch([scene], xyz[None], dirs[None], lat[None], params)[0] if batched else train.field_train(scene, xyz, dirs, lat, params)
+            (out * Gm).sum().backward()
+            assert train._channels_last(lat.grad) if fmt == "channels_last" else lat.grad.is_contiguous()
+            res[fmt] = (out.detach().clone(), lat.grad.clone(), [p.grad.clone() for p in params])
+        (o0, l0, g0), (o1, l1, g1) = res["nchw"], res["channels_last"]
+        assert torch.equal(o0, o1)
+        assert max_norm_rel(l1.cpu(), l0.cpu()) < 1e-5
+        assert max(max_norm_rel(a.cpu(), b.cpu()) for a, b in zip(g1, g0)) < 1e-5

@@ -74,7 +74,8 @@ try:
     scs = [make_scene(Wt, Ht, seed=0)]
     nerf, R = build_modules(scs, make_mlp_state_dict(), dev)
     nerf.train()
-    nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+    from diner_amd.synthetic import as_encoded
+    nerf.encoder.latent = as_encoded(nerf.encoder.latent.detach()).requires_grad_(True)      # channels-last strides, as PixelNeRF.encode emits it
     rays_all = ops.gen_rays(torch.stack([scs[0]["target_extrinsics"]]), torch.stack([scs[0]["target_intrinsics"]]), Wt, Ht, scs[0]["znear"], scs[0]["zfar"], dev)
     ys, xs = torch.meshgrid(torch.arange(64) + (Ht - 64) // 2, torch.arange(64) + (Wt - 64) // 2, indexing="ij")
     r = rays_all[:, (ys * Wt + xs).reshape(-1).to(dev)].contiguous()

@@ -36,7 +36,8 @@ G = int(15 * K / 40)
 scs = [make_scene(W, H, seed=s) for s in range(SB)]
 nerf, R = build_modules(scs, make_mlp_state_dict(), dev)
 nerf.train()
-nerf.encoder.latent = nerf.encoder.latent.detach().requires_grad_(True)
+from diner_amd.synthetic import as_encoded
+nerf.encoder.latent = as_encoded(nerf.encoder.latent.detach()).requires_grad_(True)      # channels-last strides, as PixelNeRF.encode emits it
 lib = _lib.load()
 E = torch.stack([s["target_extrinsics"] for s in scs])
 Km = torch.stack([s["target_intrinsics"] for s in scs])
